@@ -1,0 +1,214 @@
+"""Build-owned meshes: uniform interval in time, red-refined triangulations in space.
+
+Replaces the reference's Netgen/NGSolve meshing (reference source/mesh.py:4-43,
+source/problem.py:7-41), which cannot be installed here.  Only the properties
+the hot path relies on are kept:
+
+* the time mesh is the uniform interval [0, T] with N = 2^J_time + 1 nodes
+  (reference mesh.py:4-18, problem.py:13-14);
+* the space mesh is a conforming triangulation, uniformly (red) refined
+  ``nrefines`` times, and vertices are numbered *hierarchically*: the vertices
+  of level l are a prefix of the vertices of level l+1, which is what
+  MeshHierarchy relies on (reference multigrid.py:20-32, 53-55).
+
+Within one refinement level the numbering is free (Netgen's own order is not
+knowable here).  We use that freedom for the GPU: the new vertices of a level
+are grouped by *edge colour* (no two edges of one triangle share a colour, and
+red refinement propagates a valid colouring to the children), and sorted
+lexicographically inside a colour.  New vertices of one colour are then never
+adjacent, old vertices are never adjacent to each other in the refined mesh,
+and therefore a Gauss-Seidel sweep in dof order (reference multigrid.py:89-97)
+has a dependency DAG of depth (#colours + 1) -- 4 for the square -- while still
+being exactly the sequential sweep of the reference.
+"""
+import numpy as np
+
+
+class IntervalMesh:
+    """Uniform mesh of [0, T] with N_el elements (reference mesh.py:4-18)."""
+    def __init__(self, N_el=16, T=1.0):
+        self.N_el = int(N_el)
+        self.T = float(T)
+        self.nodes = self.T * np.arange(self.N_el + 1) / self.N_el
+        self.h = self.T / self.N_el
+
+    @property
+    def nv(self):
+        return self.N_el + 1
+
+
+class TriangleMesh:
+    """A hierarchy of red-refined triangulations with hierarchical numbering.
+
+    Attributes (finest level unless stated):
+      points (nv, 2), tris (nt, 3), boundary (nv,) bool,
+      nverts[l]   -- number of vertices of level l (prefix sizes),
+      parents (nv, 2) -- parent vertex pair of every vertex (-1 on level 0),
+                          the analogue of NGSolve's GetParentVertices
+                          (reference multigrid.py:20-21),
+      vcolor (nv,) -- colour class of the edge a vertex bisected (-1 on level 0).
+    """
+    def __init__(self, points, tris, boundary_fn):
+        self.points = np.asarray(points, dtype=np.float64)
+        self.tris = np.asarray(tris, dtype=np.int64)
+        self.boundary_fn = boundary_fn
+        nv = len(self.points)
+        self.nverts = [nv]
+        self.parents = -np.ones((nv, 2), dtype=np.int64)
+        self.vcolor = -np.ones(nv, dtype=np.int64)
+        self._tri_edge_color = self._greedy_edge_colouring()
+        self.boundary = boundary_fn(self.points)
+
+    # ------------------------------------------------------------------
+    def _edges(self):
+        """Unique edges, and for every triangle the ids of its 3 edges
+        (edge k is opposite to local vertex k)."""
+        t = self.tris
+        e = np.stack([t[:, [1, 2]], t[:, [2, 0]], t[:, [0, 1]]], axis=1)
+        e = np.sort(e.reshape(-1, 2), axis=1)
+        nv = len(self.points)
+        key = e[:, 0] * nv + e[:, 1]
+        ukey, inv = np.unique(key, return_inverse=True)
+        edges = np.stack([ukey // nv, ukey % nv], axis=1)
+        return edges, inv.reshape(-1, 3)
+
+    def _greedy_edge_colouring(self):
+        """Colour the edges of the (tiny) coarsest mesh so that the 3 edges of
+        every triangle get 3 different colours.  Returns per-triangle colours
+        (nt, 3) aligned with the local edge numbering."""
+        edges, te = self._edges()
+        ne = len(edges)
+        # edges conflict when they share a triangle
+        nbrs = [set() for _ in range(ne)]
+        for tri in te:
+            for a in tri:
+                for b in tri:
+                    if a != b:
+                        nbrs[a].add(b)
+        # process edges grouped by direction so that structured meshes get the
+        # natural (horizontal, vertical, diagonal) classes
+        d = self.points[edges[:, 1]] - self.points[edges[:, 0]]
+        ang = np.round(np.mod(np.arctan2(d[:, 1], d[:, 0]), np.pi), 9)
+        order = np.lexsort((np.arange(ne), ang))
+        col = -np.ones(ne, dtype=np.int64)
+        for e in order:
+            used = {col[n] for n in nbrs[e] if col[n] >= 0}
+            c = 0
+            while c in used:
+                c += 1
+            col[e] = c
+        return col[te]
+
+    # ------------------------------------------------------------------
+    def refine(self):
+        """One uniform red refinement; new vertices are appended."""
+        edges, te = self._edges()
+        ne = len(edges)
+        nv = len(self.points)
+        # colour per unique edge (consistent by construction)
+        ecol = np.empty(ne, dtype=np.int64)
+        ecol[te.reshape(-1)] = self._tri_edge_color.reshape(-1)
+        mid = 0.5 * (self.points[edges[:, 0]] + self.points[edges[:, 1]])
+        # numbering of the new vertices: by colour, then y, then x
+        order = np.lexsort((mid[:, 0], mid[:, 1], ecol))
+        rank = np.empty(ne, dtype=np.int64)
+        rank[order] = np.arange(ne)
+        new_id = nv + rank
+
+        self.points = np.vstack([self.points, mid[order]])
+        self.parents = np.vstack([self.parents, edges[order]])
+        self.vcolor = np.concatenate([self.vcolor, ecol[order]])
+        self.nverts.append(nv + ne)
+
+        t = self.tris
+        m = new_id[te]  # m[:, k] = midpoint of the edge opposite vertex k
+        c = self._tri_edge_color
+        v0, v1, v2 = t[:, 0], t[:, 1], t[:, 2]
+        m0, m1, m2 = m[:, 0], m[:, 1], m[:, 2]
+        c0, c1, c2 = c[:, 0], c[:, 1], c[:, 2]
+        # children; edge k of a child is opposite its local vertex k and carries
+        # the colour of the parent edge it is parallel to / a half of.
+        tris = np.concatenate([
+            np.stack([v0, m2, m1], 1),
+            np.stack([v1, m0, m2], 1),
+            np.stack([v2, m1, m0], 1),
+            np.stack([m0, m1, m2], 1),
+        ])
+        cols = np.concatenate([
+            np.stack([c0, c1, c2], 1),
+            np.stack([c1, c2, c0], 1),
+            np.stack([c2, c0, c1], 1),
+            np.stack([c0, c1, c2], 1),
+        ])
+        self.tris = tris
+        self._tri_edge_color = cols
+        self.boundary = self.boundary_fn(self.points)
+
+    @property
+    def nv(self):
+        return len(self.points)
+
+    @property
+    def J(self):
+        return len(self.nverts) - 1
+
+    def levels(self):
+        lv = np.zeros(self.nv, dtype=np.int64)
+        for l in range(1, len(self.nverts)):
+            lv[self.nverts[l - 1]:self.nverts[l]] = l
+        return lv
+
+
+def _on_box_boundary(lo, hi, eps=1e-12):
+    def fn(p):
+        return ((np.abs(p[:, 0] - lo[0]) < eps) | (np.abs(p[:, 0] - hi[0]) < eps)
+                | (np.abs(p[:, 1] - lo[1]) < eps)
+                | (np.abs(p[:, 1] - hi[1]) < eps))
+    return fn
+
+
+def construct_interval(N=16, T=1):
+    """Counterpart of reference mesh.py:4-18."""
+    return IntervalMesh(N, T)
+
+
+def construct_2d_square_mesh(nrefines=1):
+    """Unit square: 2 triangles, refined once (the analogue of the Netgen-side
+    ``ngmesh.Refine()``, reference mesh.py:25-26) and then ``nrefines`` times
+    (mesh.py:28-29).  The hierarchy keeps every level that has at least one
+    interior vertex, so level 0 of the multigrid hierarchy has exactly 1 dof
+    and the finest level has (2^(nrefines+1) - 1)^2."""
+    pts = np.array([[0., 0.], [1., 0.], [1., 1.], [0., 1.]])
+    tris = np.array([[0, 1, 2], [0, 2, 3]])
+    mesh = TriangleMesh(pts, tris, _on_box_boundary((0., 0.), (1., 1.)))
+    mesh.refine()
+    for _ in range(nrefines):
+        mesh.refine()
+    return mesh, "default"
+
+
+def construct_2d_lshape_mesh(nrefines=1):
+    """L-shaped domain (-1,1)^2 \\ [0,1)x(-1,0]; not in the reference
+    (reference problem.py:35-41 only knows square and cube), named by
+    BASELINE.json config 4.  The coarse triangulation is deliberately not a
+    three-direction mesh (alternating diagonals), so the dof order and the CSR
+    rows are irregular."""
+    pts = np.array([[-1., -1.], [0., -1.], [-1., 0.], [0., 0.], [1., 0.],
+                    [-1., 1.], [0., 1.], [1., 1.]])
+    tris = np.array([[0, 1, 3], [0, 3, 2], [2, 3, 5], [3, 6, 5], [3, 4, 7],
+                     [3, 7, 6]])
+
+    def bnd(p, eps=1e-12):
+        x, y = p[:, 0], p[:, 1]
+        outer = (np.abs(x + 1) < eps) | (np.abs(y - 1) < eps) | (
+            (np.abs(x - 1) < eps) & (y > -eps)) | ((np.abs(y + 1) < eps) &
+                                                    (x < eps))
+        inner = ((np.abs(x) < eps) & (y < eps)) | ((np.abs(y) < eps) &
+                                                   (x > -eps))
+        return outer | inner
+
+    mesh = TriangleMesh(pts, tris, bnd)
+    mesh.refine()
+    for _ in range(nrefines):
+        mesh.refine()
+    return mesh, "default"

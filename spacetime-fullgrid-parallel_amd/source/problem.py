@@ -1,0 +1,43 @@
+"""Model problems (counterpart of reference source/problem.py:7-41).
+
+``square``: u(t,x,y) = exp(-2 pi^2 t) sin(pi x) sin(pi y) on [0,1]^2, no forcing
+(problem.py:7-19).  ``lshape`` is not in the reference (anything but square /
+cube asserts there, problem.py:35-41); BASELINE.json config 4 names it, so it
+is defined here with the same data on the L-shaped domain.  ``cube`` needs a
+tetrahedral mesh generator and is not provided.
+"""
+import numpy as np
+
+from .mesh import (construct_2d_lshape_mesh, construct_2d_square_mesh,
+                   construct_interval)
+
+
+def _time_mesh(J_space, J_time):
+    if not J_time:
+        J_time = J_space
+    return construct_interval(N=2**int(J_time + 0.5))
+
+
+def _u0(x, y):
+    return np.sin(np.pi * x) * np.sin(np.pi * y)
+
+
+def square(J_space, J_time=None):
+    mesh_space, bc = construct_2d_square_mesh(nrefines=J_space)
+    data = {'g': [], 'u0': _u0}
+    return mesh_space, bc, _time_mesh(J_space, J_time), data, "square"
+
+
+def lshape(J_space, J_time=None):
+    mesh_space, bc = construct_2d_lshape_mesh(nrefines=J_space)
+    data = {'g': [], 'u0': _u0}
+    return mesh_space, bc, _time_mesh(J_space, J_time), data, "lshape"
+
+
+def problem_helper(problem, J_space, J_time=None):
+    if problem == 'square':
+        return square(J_space, J_time)
+    elif problem == 'lshape':
+        return lshape(J_space, J_time)
+    else:
+        assert (False)
