@@ -1,0 +1,166 @@
+/* stk.h -- C ABI of libstk, the MI355X (gfx950) hot path of the space-time
+ * Kronecker solver.
+ *
+ * The reference (Jannertje/spacetime-fullgrid-parallel) has no FFI: its
+ * boundary is the duck-typed Python protocol LinearOperatorMPI / KronVectorMPI
+ * (reference source/mpi_kron.py:13-36, source/mpi_vector.py:41-122).  Every
+ * entry point below names the reference method whose arithmetic it replaces;
+ * the Python classes in spacetime-fullgrid-parallel_amd/source/ bind them with
+ * ctypes and keep the reference's class names and call signatures.
+ *
+ * Conventions
+ *  - extern "C", int status return (0 = ok, nonzero = error; text from
+ *    stk_last_error()).  No exceptions cross the ABI.
+ *  - All array arguments are DEVICE pointers unless the name ends in _host.
+ *    The caller owns every buffer.  float64 values, int32 indices
+ *    (reference source/mpi_shared_mem.py:46-48).
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  All
+ *    work is enqueued asynchronously on it; nothing synchronises.
+ *  - One caller thread per process, one process per GPU.
+ *
+ * Vector layout ("space-major"): the local slab of a KronVectorMPI, which the
+ * reference stores as X_loc[t][i] (mpi_vector.py:62-71), lives on the device
+ * as x[i * ld + t], i in [0, M), t in [0, n_loc), ld >= n_loc.  Entries
+ * t in [n_loc, ld) are padding and are kept zero by every kernel.  A time
+ * column is therefore contiguous: a CSR gather of neighbour j fetches n_loc
+ * consecutive doubles.  Ghost time rows t = -1 and t = n_loc (the reference's
+ * X_loc_bdr[0], X_loc_bdr[-1], mpi_vector.py:148-175) are separate contiguous
+ * arrays of length M.
+ */
+#ifndef STK_H
+#define STK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STK_MAX_TERMS 4
+
+/* ---- library ------------------------------------------------------------ */
+const char *stk_last_error(void);
+int stk_version(void);
+/* Device properties the host side sizes launches with (CUs, wavefront). */
+int stk_device_info(int32_t *n_cu, int32_t *wave_size, int64_t *hbm_bytes);
+
+/* ---- BLAS-1 on flat arrays (KronVectorMPI arithmetic, mpi_vector.py:84-122,
+ *      and dot, mpi_vector.py:205-210, local part) -------------------------- */
+/* y = a * x + b * y   (b == 0 ignores the old y; x == y allowed) */
+int stk_axpby(void *stream, int64_t n, double a, const double *x, double b,
+              double *y);
+/* z = a * x + b * y   (three-operand form, z may alias x or y) */
+int stk_axpbyz(void *stream, int64_t n, double a, const double *x, double b,
+               const double *y, double *z);
+/* out[0] = sum x[k] * y[k].  Deterministic two-stage reduction; `work` holds
+ * at least stk_dot_work_size() doubles. */
+int64_t stk_dot_work_size(void);
+int stk_dot(void *stream, int64_t n, const double *x, const double *y,
+            double *work, double *out);
+/* PCG update pair of reference linalg.py:29-30 plus the next dot in one pass:
+ * w += alpha p ; r -= alpha t ; out[0] = r . r   (alpha read from device) */
+int stk_pcg_update(void *stream, int64_t n, const double *alpha_dev,
+                   const double *p, const double *t, double *w, double *r,
+                   double *work, double *out);
+
+/* ---- sum of Kronecker terms  y = beta*y + sum_k (T_k kron X_k) x_k --------
+ * Replaces TridiagKronMatMPI._matvec (mpi_kron.py:214-219), i.e.
+ * TridiagKronIdentityMPI (:186-201) followed by IdentityKronMatMPI (:143-150),
+ * and the accumulation loop of SumMPI._matvec (:77-90), in one pass.
+ * All X_k share one CSR pattern (indptr/indices); vals differ per term. */
+typedef struct {
+    /* 3*n_loc coefficients [sub | diag | super]: output time row t takes
+     * sub[t]*z[t-1] + diag[t]*z[t] + super[t]*z[t+1].  NULL = identity. */
+    const double *tri;
+    const double *vals; /* nnz values of X_k on the shared pattern */
+    const double *x;    /* input vector, M x ld */
+    const double *x_lo; /* ghost time row t = -1 (length M) or NULL */
+    const double *x_hi; /* ghost time row t = n_loc (length M) or NULL */
+} stk_kron_term;
+
+int stk_kron_sum_apply(void *stream, int32_t M, int32_t n_loc, int32_t ld,
+                       const int32_t *indptr, const int32_t *indices,
+                       int32_t n_terms, const stk_kron_term *terms_host,
+                       double beta, double *y);
+
+/* ---- (I_t kron A) for a general, possibly rectangular CSR A ---------------
+ * y = alpha * A x + beta * z  on `rows` x n_loc outputs (IdentityKronMatMPI,
+ * mpi_kron.py:143-150; residual / restriction / prolongation steps of
+ * MultiGrid.MGM, multigrid.py:174-180).  The entries of A may depend on the
+ * time slice: a(t) = ca * vals_a + cm[t] * vals_m (vals_m, cm may be NULL).
+ * z may be NULL (treated as 0) or alias y. */
+int stk_csr_spmm(void *stream, int32_t rows, int32_t n_loc, int32_t ld,
+                 const int32_t *indptr, const int32_t *indices,
+                 const double *vals_a, double ca, const double *vals_m,
+                 const double *cm, const double *x, double alpha, double beta,
+                 const double *z, double *y);
+
+/* ---- (A_t kron I) for a small sparse time matrix ---------------------------
+ * y[., t] = (add_identity ? x[., t] : 0) + sum_e val[e] * src(col[e]) over the
+ * CSR row t of the LOCAL rows of the time matrix; col < n_loc addresses the
+ * local slab, col >= n_loc addresses row (col - n_loc) of `recv`, a
+ * (n_recv x M) array of time rows fetched from other ranks
+ * (SparseKronIdentityMPI._matvec, mpi_kron.py:285-317;
+ * TridiagKronIdentityMPI._matvec, :186-201). */
+int stk_time_csr_apply(void *stream, int32_t M, int32_t n_loc, int32_t ld,
+                       const int32_t *t_indptr, const int32_t *t_cols,
+                       const double *t_vals, const double *x,
+                       const double *recv, int32_t add_identity, double *y);
+
+/* ---- wavelet transform in time, whole time axis on this GPU ---------------
+ * y = (W_t kron I) x or (W_t^T kron I) x in the interleaved numbering, all
+ * J levels in one pass (WaveletTransformOp._matmat / _rmatmat,
+ * wavelets.py:106-134; same operator as the composite of
+ * wavelets.py:172-198 on one rank).  Requires n_loc == 2^J + 1. */
+int stk_wavelet_apply(void *stream, int32_t M, int32_t J, int32_t ld,
+                      int32_t transposed, const double *x, double *y);
+
+/* ---- multigrid V-cycles with Gauss-Seidel smoothing ------------------------
+ * MultiGrid._matvec / MGM (multigrid.py:168-193), PETScSMoother / Smoother
+ * (multigrid.py:83-127), batched over the n_loc time slices. */
+typedef struct {
+    int32_t n; /* dofs on this level */
+    const int32_t *indptr, *indices;
+    const double *vals_a, *vals_m; /* a(t) = ca*vals_a + cm[t]*vals_m */
+    const int32_t *diag;           /* CSR position of the diagonal of row i */
+    /* Gauss-Seidel dependency schedule: rows grouped into DAG levels; rows of
+     * one group are mutually independent.  *_ptr_host has n_groups+1 entries
+     * (host memory), *_rows is a device array of row indices. */
+    int32_t n_fwd;
+    const int32_t *fwd_ptr_host;
+    const int32_t *fwd_rows;
+    int32_t n_bwd;
+    const int32_t *bwd_ptr_host;
+    const int32_t *bwd_rows;
+    /* prolongation from the next coarser level (n x n_coarse) and its
+     * transpose; NULL on level 0 */
+    const int32_t *p_indptr, *p_indices;
+    const double *p_vals;
+    const int32_t *r_indptr, *r_indices;
+    const double *r_vals;
+} stk_mg_level;
+
+typedef struct stk_mg stk_mg;
+
+/* coarse_inv: n_kinds dense (n0 x n0) inverses of the level-0 matrix, row
+ * major, one per distinct time-slice coefficient (device).  max_ld bounds the
+ * ld of later applies (workspace is allocated here). */
+int stk_mg_create(int32_t n_levels, const stk_mg_level *levels_host,
+                  int32_t smoothsteps, int32_t vcycles, int32_t n_kinds,
+                  const double *coarse_inv, int32_t max_ld, stk_mg **out);
+int stk_mg_destroy(stk_mg *mg);
+/* u = MG(f): `vcycles` V-cycles from u = 0.  cm/kind: per-time-slice mass
+ * coefficient and coarse-inverse index (device, n_loc) or NULL. */
+int stk_mg_apply(stk_mg *mg, void *stream, int32_t n_loc, int32_t ld,
+                 double ca, const double *cm, const int32_t *kind,
+                 const double *f, double *u);
+/* `its` forward (backward = 0) or backward Gauss-Seidel sweeps on one level
+ * (exposed for tests; multigrid.py:116-127). */
+int stk_mg_smooth(stk_mg *mg, void *stream, int32_t level, int32_t n_loc,
+                  int32_t ld, double ca, const double *cm, int32_t its,
+                  int32_t backward, const double *f, double *u);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STK_H */

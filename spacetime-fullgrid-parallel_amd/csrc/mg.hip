@@ -1,0 +1,235 @@
+// Spatial multigrid V-cycle with Gauss-Seidel smoothing, batched over the
+// n_loc time slices of a slab.  Replaces MultiGrid._matvec / MGM
+// (reference source/multigrid.py:168-193) and the PETSc MatSOR calls of
+// PETScSMoother (multigrid.py:100-127), whose semantics are the sequential
+// sweep of Smoother (multigrid.py:83-97).
+//
+// Gauss-Seidel on a GPU without changing the result: rows are grouped by depth
+// in the dependency DAG of the sweep (row i waits for its neighbours j < i in a
+// forward sweep, j > i in a backward one).  Groups run in order, one launch
+// each; inside a group every (row, time slice) pair is independent.  Each row
+// performs exactly the arithmetic of the sequential sweep
+//     u_i += (1 / a_ii) * (f_i - sum_j a_ij u_j)        (CSR order, j = i included)
+// on exactly the same inputs, so the sweep is the reference's sweep, not a
+// re-coloured variant.  With the build's vertex numbering (source/mesh.py)
+// the DAG has 4 groups on the square.
+//
+// Matrix entries may depend on the time slice: a(t) = ca*vals_a + cm[t]*vals_m.
+// That is how the block-diagonal preconditioner's matrices 2^j M_x + alpha A_x
+// (reference heateq_mpi.py:97-98) share one stored hierarchy: Galerkin
+// coarsening is linear, so R(2^j M + alpha A)P = 2^j RMP + alpha RAP.
+#include <vector>
+
+#include "stk_common.h"
+
+namespace {
+
+constexpr int GBS = 256;
+
+__global__ __launch_bounds__(GBS) void gs_group_kernel(int64_t total, const int32_t *__restrict__ rows,
+                                                       int32_t n_loc, int32_t ld,
+                                                       const int32_t *__restrict__ indptr,
+                                                       const int32_t *__restrict__ indices,
+                                                       const double *__restrict__ va, double ca,
+                                                       const double *__restrict__ vm,
+                                                       const double *__restrict__ cm,
+                                                       const int32_t *__restrict__ diag,
+                                                       const double *__restrict__ f, double *u)
+{
+    const int64_t stride = (int64_t)gridDim.x * GBS;
+    for (int64_t idx = (int64_t)blockIdx.x * GBS + threadIdx.x; idx < total; idx += stride) {
+        const int q = (int)(idx / n_loc);
+        const int t = (int)(idx - (int64_t)q * n_loc);
+        const int i = rows[q];
+        const int e0 = indptr[i], e1 = indptr[i + 1];
+        const double *ut = u + t;
+        double ax = 0.0, d;
+        if (vm != nullptr) {
+            const double c = cm[t];
+#pragma unroll 4
+            for (int e = e0; e < e1; ++e)
+                ax = fma(fma(c, vm[e], ca * va[e]), ut[(size_t)indices[e] * ld], ax);
+            const int ed = diag[i];
+            d = fma(c, vm[ed], ca * va[ed]);
+        } else {
+#pragma unroll 4
+            for (int e = e0; e < e1; ++e) ax = fma(ca * va[e], ut[(size_t)indices[e] * ld], ax);
+            d = ca * va[diag[i]];
+        }
+        const size_t o = (size_t)i * ld + t;
+        u[o] += (1.0 / d) * (f[o] - ax);
+    }
+}
+
+// u0[i, t] = sum_j inv[kind[t]][i][j] f0[j, t]   (exact coarse solve,
+// multigrid.py:161-165, 169-170; the inverse is formed on the host at setup)
+__global__ __launch_bounds__(GBS) void coarse_kernel(int32_t n0, int32_t n_loc, int32_t ld,
+                                                     const double *__restrict__ inv, double ca_inv,
+                                                     const int32_t *__restrict__ kind,
+                                                     const double *__restrict__ f, double *__restrict__ u)
+{
+    const int idx = blockIdx.x * GBS + threadIdx.x;
+    if (idx >= n0 * n_loc) return;
+    const int i = idx / n_loc, t = idx - i * n_loc;
+    const double *A = inv + (size_t)(kind ? kind[t] : 0) * n0 * n0 + (size_t)i * n0;
+    double s = 0.0;
+    for (int j = 0; j < n0; ++j) s = fma(A[j], f[(size_t)j * ld + t], s);
+    u[(size_t)i * ld + t] = ca_inv * s;
+}
+
+}  // namespace
+
+struct stk_mg {
+    std::vector<stk_mg_level> lv;
+    std::vector<std::vector<int32_t>> fwd_ptr, bwd_ptr;
+    int smoothsteps, vcycles, n_kinds, max_ld;
+    const double *coarse_inv;
+    // workspaces per level (level J uses the caller's u, f)
+    std::vector<double *> u, f, r;
+};
+
+static int smooth_level(stk_mg *mg, hipStream_t st, int level, int n_loc, int ld, double ca, const double *cm,
+                        int its, bool backward, const double *f, double *u)
+{
+    const stk_mg_level &L = mg->lv[level];
+    const std::vector<int32_t> &ptr = backward ? mg->bwd_ptr[level] : mg->fwd_ptr[level];
+    const int32_t *rows = backward ? L.bwd_rows : L.fwd_rows;
+    const int ngroups = (int)ptr.size() - 1;
+    for (int it = 0; it < its; ++it) {
+        for (int g = 0; g < ngroups; ++g) {
+            const int nr = ptr[g + 1] - ptr[g];
+            if (nr == 0) continue;
+            const int64_t total = (int64_t)nr * n_loc;
+            hipLaunchKernelGGL(gs_group_kernel, dim3(stk_flat_grid(total, GBS)), dim3(GBS), 0, st, total,
+                               rows + ptr[g], n_loc, ld, L.indptr, L.indices, L.vals_a, ca,
+                               cm ? L.vals_m : nullptr, cm, L.diag, f, u);
+            STK_LAUNCH_CHECK();
+        }
+    }
+    return 0;
+}
+
+// multigrid.py:168-182
+static int mgm(stk_mg *mg, hipStream_t st, int j, int n_loc, int ld, double ca, const double *cm,
+               const int32_t *kind, const double *f_j, double *u_j)
+{
+    const stk_mg_level &L = mg->lv[j];
+    if (j == 0) {
+        const int total = L.n * n_loc;
+        // the stored inverses are those of (vals_a + cm*vals_m) for cm != NULL,
+        // and of vals_a alone otherwise; ca scales the latter
+        hipLaunchKernelGGL(coarse_kernel, dim3((total + GBS - 1) / GBS), dim3(GBS), 0, st, L.n, n_loc, ld,
+                           mg->coarse_inv, cm ? 1.0 : 1.0 / ca, cm ? kind : nullptr, f_j, u_j);
+        STK_LAUNCH_CHECK();
+        return 0;
+    }
+    int rc = smooth_level(mg, st, j, n_loc, ld, ca, cm, mg->smoothsteps, false, f_j, u_j);
+    if (rc) return rc;
+    const stk_mg_level &C = mg->lv[j - 1];
+    double *r_j = mg->r[j], *d_c = mg->f[j - 1], *u_c = mg->u[j - 1];
+    // r_j = A_j u_j - f_j
+    rc = stk_csr_spmm(st, L.n, n_loc, ld, L.indptr, L.indices, L.vals_a, ca, cm ? L.vals_m : nullptr, cm, u_j,
+                      1.0, -1.0, f_j, r_j);
+    if (rc) return rc;
+    // d_c = R r_j
+    rc = stk_csr_spmm(st, C.n, n_loc, ld, L.r_indptr, L.r_indices, L.r_vals, 1.0, nullptr, nullptr, r_j, 1.0,
+                      0.0, nullptr, d_c);
+    if (rc) return rc;
+    STK_HIP(hipMemsetAsync(u_c, 0, sizeof(double) * (size_t)C.n * ld, st));
+    rc = mgm(mg, st, j - 1, n_loc, ld, ca, cm, kind, d_c, u_c);
+    if (rc) return rc;
+    // u_j -= P u_c
+    rc = stk_csr_spmm(st, L.n, n_loc, ld, L.p_indptr, L.p_indices, L.p_vals, 1.0, nullptr, nullptr, u_c, -1.0,
+                      1.0, u_j, u_j);
+    if (rc) return rc;
+    return smooth_level(mg, st, j, n_loc, ld, ca, cm, mg->smoothsteps, true, f_j, u_j);
+}
+
+extern "C" int stk_mg_create(int32_t n_levels, const stk_mg_level *levels, int32_t smoothsteps, int32_t vcycles,
+                             int32_t n_kinds, const double *coarse_inv, int32_t max_ld, stk_mg **out)
+{
+    STK_REQUIRE(n_levels >= 1 && levels && out, "stk_mg_create: bad arguments");
+    STK_REQUIRE(smoothsteps >= 0 && vcycles >= 1 && max_ld >= 1, "stk_mg_create: bad parameters");
+    STK_REQUIRE(coarse_inv && n_kinds >= 1, "stk_mg_create: coarse inverse missing");
+    stk_mg *mg = new stk_mg();
+    mg->smoothsteps = smoothsteps;
+    mg->vcycles = vcycles;
+    mg->n_kinds = n_kinds;
+    mg->max_ld = max_ld;
+    mg->coarse_inv = coarse_inv;
+    mg->lv.assign(levels, levels + n_levels);
+    mg->fwd_ptr.resize(n_levels);
+    mg->bwd_ptr.resize(n_levels);
+    mg->u.assign(n_levels, nullptr);
+    mg->f.assign(n_levels, nullptr);
+    mg->r.assign(n_levels, nullptr);
+    for (int j = 0; j < n_levels; ++j) {
+        const stk_mg_level &L = mg->lv[j];
+        if (L.n <= 0 || !L.indptr || !L.indices || !L.vals_a || !L.diag) {
+            stk_set_error("stk_mg_create: level %d incomplete", j);
+            stk_mg_destroy(mg);
+            return 2;
+        }
+        if (j > 0) {
+            if (!L.fwd_ptr_host || !L.bwd_ptr_host || !L.fwd_rows || !L.bwd_rows || !L.p_indptr ||
+                !L.r_indptr) {
+                stk_set_error("stk_mg_create: level %d lacks schedule or transfer operators", j);
+                stk_mg_destroy(mg);
+                return 2;
+            }
+            mg->fwd_ptr[j].assign(L.fwd_ptr_host, L.fwd_ptr_host + L.n_fwd + 1);
+            mg->bwd_ptr[j].assign(L.bwd_ptr_host, L.bwd_ptr_host + L.n_bwd + 1);
+        }
+        const size_t bytes = sizeof(double) * (size_t)L.n * max_ld;
+        hipError_t e = hipSuccess;
+        if (j < n_levels - 1) {
+            e = hipMalloc((void **)&mg->u[j], bytes);
+            if (e == hipSuccess) e = hipMalloc((void **)&mg->f[j], bytes);
+        }
+        if (e == hipSuccess && j > 0) e = hipMalloc((void **)&mg->r[j], bytes);
+        if (e != hipSuccess) {
+            stk_set_error("stk_mg_create: hipMalloc failed on level %d: %s", j, hipGetErrorString(e));
+            stk_mg_destroy(mg);
+            return 1;
+        }
+    }
+    *out = mg;
+    return 0;
+}
+
+extern "C" int stk_mg_destroy(stk_mg *mg)
+{
+    if (!mg) return 0;
+    for (double *p : mg->u) (void)hipFree(p);
+    for (double *p : mg->f) (void)hipFree(p);
+    for (double *p : mg->r) (void)hipFree(p);
+    delete mg;
+    return 0;
+}
+
+extern "C" int stk_mg_apply(stk_mg *mg, void *stream, int32_t n_loc, int32_t ld, double ca, const double *cm,
+                            const int32_t *kind, const double *f, double *u)
+{
+    STK_REQUIRE(mg && f && u && f != u, "stk_mg_apply: bad pointers");
+    STK_REQUIRE(n_loc > 0 && ld >= n_loc && ld <= mg->max_ld, "stk_mg_apply: ld=%d exceeds plan max_ld=%d", ld,
+                mg->max_ld);
+    STK_REQUIRE(cm == nullptr || mg->lv[0].vals_m != nullptr, "stk_mg_apply: cm given but plan has no vals_m");
+    STK_REQUIRE(ca != 0.0 || cm, "stk_mg_apply: zero matrix");
+    hipStream_t st = stk_stream(stream);
+    const int J = (int)mg->lv.size() - 1;
+    STK_HIP(hipMemsetAsync(u, 0, sizeof(double) * (size_t)mg->lv[J].n * ld, st));  // multigrid.py:187
+    for (int v = 0; v < mg->vcycles; ++v) {
+        int rc = mgm(mg, st, J, n_loc, ld, ca, cm, kind, f, u);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int stk_mg_smooth(stk_mg *mg, void *stream, int32_t level, int32_t n_loc, int32_t ld, double ca,
+                             const double *cm, int32_t its, int32_t backward, const double *f, double *u)
+{
+    STK_REQUIRE(mg && f && u, "stk_mg_smooth: null pointer");
+    STK_REQUIRE(level >= 1 && level < (int)mg->lv.size(), "stk_mg_smooth: level %d out of range", level);
+    STK_REQUIRE(n_loc > 0 && ld >= n_loc, "stk_mg_smooth: bad sizes");
+    return smooth_level(mg, stk_stream(stream), level, n_loc, ld, ca, cm, its, backward != 0, f, u);
+}

@@ -1,0 +1,287 @@
+"""Parallel-in-time heat-equation solver on MI355X GPUs (counterpart of the
+reference's heateq_mpi.py; same class name, constructor arguments, operator
+attributes and command line).
+
+Launch one process per GPU:
+    python heateq_mpi.py --J_time=5 --J_space=8
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 \
+        heateq_mpi.py --J_time=6 --J_space=9
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from source import _lib
+from source.assembly import (prolongation_matrices, space_load,
+                             space_matrices, time_matrices)
+from source.comm import MPI
+from source.linalg import PCG
+from source.linop import CompositeLinOp, as_space_op, union_pattern
+from source.mpi_kron import (BlockDiagMPI, CompositeMPI, LinearOperatorMPI,
+                             MatKronIdentityMPI, SumMPI, TridiagKronMatMPI,
+                             _local_tridiag)
+from source.mpi_vector import DofDistributionMPI, KronVectorMPI
+from source.multigrid import MeshHierarchy, MultiGrid, MultiGridFamily
+from source.problem import problem_helper
+from source.wavelets import (TransposedWaveletTransformKronIdentityMPI,
+                             WaveletTransformKronIdentityMPI,
+                             WaveletTransformOp)
+
+
+def mem():
+    """Device memory in use by this process, MB (the reference reports host
+    RSS, heateq_mpi.py:24-26; the vectors and matrices live in HBM here)."""
+    if torch.cuda.is_available():
+        return torch.cuda.memory_allocated() / 1048576
+    return 0.0
+
+
+class SchurMPI(LinearOperatorMPI):
+    """The Schur complement S = B^T K B + G of the reference (sum of the five
+    Kronecker terms of heateq_mpi.py:166-181), regrouped so that the spatial
+    preconditioner K is applied twice instead of four times:
+
+        u1 = (A_t kron M_x + L_t   kron A_x) x      one fused kernel
+        u2 = (L_t^T kron M_x + M_t kron A_x) x      one fused kernel
+        S x = (I kron M_x) K u1 + (I kron A_x) K u2 + (G_t kron M_x) x
+                                                   one fused kernel
+    This equals the five-term sum in exact arithmetic because K (a fixed number
+    of V-cycles from zero) is linear; tests bound the difference."""
+    def __init__(self, dofs_distr, A_t, L_t, M_t, G_t, M_x, A_x, Kinv_x):
+        super().__init__(dofs_distr)
+        self.Kinv_x = as_space_op(Kinv_x)
+        indptr, indices, (vm, va) = union_pattern([M_x, A_x])
+        self.indptr, self.indices = _lib.to_dev(indptr), _lib.to_dev(indices)
+        self.vm, self.va = _lib.to_dev(vm), _lib.to_dev(va)
+        self.nnz = len(indices)
+        tri = lambda T: _lib.to_dev(_local_tridiag(dofs_distr, T))
+        self.tA, self.tL, self.tM, self.tG = tri(A_t), tri(L_t), tri(
+            M_t), tri(G_t)
+        self.tLT = tri(L_t.T.tocsr())
+        self._t2 = (_lib.KronTerm * 2)()
+        self._t3 = (_lib.KronTerm * 3)()
+
+    def _kron(self, terms, specs, n_loc, ld, beta, out):
+        for t, (tri, vals, x, lo, hi) in zip(terms, specs):
+            t.tri, t.vals, t.x = _lib.ptr(tri), _lib.ptr(vals), _lib.ptr(x)
+            t.x_lo, t.x_hi = _lib.ptr(lo), _lib.ptr(hi)
+        _lib.check(_lib.lib().stk_kron_sum_apply(
+            _lib.stream(), self.M, n_loc, ld, _lib.ptr(self.indptr),
+            _lib.ptr(self.indices), len(terms), terms, beta, _lib.ptr(out)))
+
+    def _matvec(self, vec_in, vec_out):
+        assert (vec_in is not vec_out)
+        self.time_communication = 0
+        if self.dofs_distr.size > 1:
+            self.time_communication = vec_in.communicate_bdr()
+        x, lo, hi = vec_in.buf, vec_in.X_lo, vec_in.X_hi
+        n_loc, ld = vec_in.n_loc, vec_in.ld
+        u = torch.empty_like(x)
+        self._kron(self._t2, [(self.tA, self.vm, x, lo, hi),
+                              (self.tL, self.va, x, lo, hi)], n_loc, ld, 0.0, u)
+        v1 = self.Kinv_x.apply(u, n_loc=n_loc)
+        self._kron(self._t2, [(self.tLT, self.vm, x, lo, hi),
+                              (self.tM, self.va, x, lo, hi)], n_loc, ld, 0.0, u)
+        v2 = self.Kinv_x.apply(u, n_loc=n_loc)
+        self._kron(self._t3, [(None, self.vm, v1, None, None),
+                              (None, self.va, v2, None, None),
+                              (self.tG, self.vm, x, lo, hi)], n_loc, ld, 0.0,
+                   vec_out.buf)
+        vec_out.communicated_bdr = False
+        return vec_out
+
+
+class HeatEquationMPI:
+    """Creates the operators for solving the heat equation in parallel in time
+    (reference heateq_mpi.py:29-201).  Matrices come from the build's own P1
+    assembly (source/assembly.py) instead of NGSolve; every rank assembles them
+    itself and uploads its own copy to its GPU (the reference shares them
+    through MPI-3 windows, which has no meaning across HBMs).
+
+    schur='fused' (default) builds S as SchurMPI; schur='reference' builds the
+    five-term SumMPI exactly as reference heateq_mpi.py:166-181."""
+    def __init__(self,
+                 J_space=2,
+                 J_time=None,
+                 problem='square',
+                 wavelettransform='composite',
+                 precond='multigrid',
+                 smoothsteps=3,
+                 alpha=0.3,
+                 vcycles=2,
+                 schur='fused',
+                 comm=None):
+        start_time = MPI.Wtime()
+        comm = MPI.COMM_WORLD if comm is None else comm
+        if J_time is None:
+            J_time = J_space
+        self.J_time = J_time
+        self.J_space = J_space
+        self.alpha = alpha
+
+        mesh_space, bc_space, mesh_time, data, fn = problem_helper(
+            problem, J_space=J_space, J_time=J_time)
+        # --- TIME --- (heateq_mpi.py:78-88)
+        self.A_t, self.L_t, self.M_t, self.G_t, self.u0_t = time_matrices(
+            mesh_time)
+        # --- SPACE --- (heateq_mpi.py:91-98)
+        self.M_x, self.A_x = space_matrices(mesh_space)
+        self.N = self.A_t.shape[0]
+        self.M = self.M_x.shape[0]
+        assert (len(data['g']) == 0)
+        self.u0_x = space_load(mesh_space, data['u0'])
+        self.dofs_distr = DofDistributionMPI(comm, self.N, self.M)
+
+        # --- Wavelet transform --- (heateq_mpi.py:126-139)
+        if wavelettransform == 'composite':
+            self.W = WaveletTransformKronIdentityMPI(self.dofs_distr,
+                                                     self.J_time)
+            self.WT = TransposedWaveletTransformKronIdentityMPI(
+                self.dofs_distr, self.J_time)
+        elif wavelettransform == 'original':
+            self.W_t = WaveletTransformOp(self.J_time)
+            self.W = MatKronIdentityMPI(self.dofs_distr, self.W_t)
+            self.WT = MatKronIdentityMPI(self.dofs_distr, self.W_t.T)
+        elif wavelettransform == 'interleaved':
+            self.W_t = WaveletTransformOp(self.J_time, interleaved=True)
+            self.W = MatKronIdentityMPI(self.dofs_distr, self.W_t)
+            self.WT = MatKronIdentityMPI(self.dofs_distr, self.W_t.T)
+        else:
+            raise ValueError(wavelettransform)
+
+        # ---- Preconditioners in space ---- (heateq_mpi.py:141-162)
+        assert (precond == 'multigrid'), 'only multigrid runs on the device'
+        hierarchy = MeshHierarchy(mesh_space)
+        self.hierarchy = hierarchy
+        self.Kinv_x = MultiGrid(self.A_x, hierarchy, smoothsteps=smoothsteps,
+                                vcycles=vcycles)
+        # C_j = multigrid for 2^j M_x + alpha A_x, all in one family
+        self.C_family = MultiGridFamily(self.A_x, self.M_x, hierarchy,
+                                        ca=alpha,
+                                        cms=[2**j for j in
+                                             range(self.J_time + 1)],
+                                        smoothsteps=smoothsteps,
+                                        vcycles=vcycles)
+        self.C_j = self.C_family.members
+        self.CAC_j = [
+            CompositeLinOp([self.C_j[j], self.A_x, self.C_j[j]])
+            for j in range(self.J_time + 1)
+        ]
+
+        # -- MPI objects -- (heateq_mpi.py:164-185)
+        dd = self.dofs_distr
+        if schur == 'reference':
+            M_x, A_x, K = self.M_x, self.A_x, self.Kinv_x
+            self.A_MKM = TridiagKronMatMPI(dd, self.A_t,
+                                           CompositeLinOp([M_x, K, M_x]))
+            self.L_MKA = TridiagKronMatMPI(dd, self.L_t,
+                                           CompositeLinOp([M_x, K, A_x]))
+            self.LT_AKM = TridiagKronMatMPI(dd, self.L_t.T.tocsr(),
+                                            CompositeLinOp([A_x, K, M_x]))
+            self.M_AKA = TridiagKronMatMPI(dd, self.M_t,
+                                           CompositeLinOp([A_x, K, A_x]))
+            self.G_M = TridiagKronMatMPI(dd, self.G_t, M_x)
+            self.S = SumMPI(
+                dd,
+                [self.A_MKM, self.L_MKA, self.LT_AKM, self.M_AKA, self.G_M])
+        else:
+            self.S = SchurMPI(dd, self.A_t, self.L_t, self.M_t, self.G_t,
+                              self.M_x, self.A_x, self.Kinv_x)
+
+        levels = (self.W.levels if hasattr(self.W, 'levels') else
+                  WaveletTransformOp(self.J_time, interleaved=True).levels)
+        self.P = BlockDiagMPI(dd, [self.CAC_j[j] for j in levels])
+        self.WT_S_W = CompositeMPI(dd, [self.WT, self.S, self.W])
+
+        # -- RHS -- (heateq_mpi.py:188-191)
+        self.rhs = KronVectorMPI(dd)
+        self.rhs.X_loc[:] = torch.from_numpy(
+            np.kron(self.u0_t[self.rhs.t_begin:self.rhs.t_end],
+                    self.u0_x).reshape(-1, self.M)).to(self.rhs.buf.device)
+
+        self.setup_time = MPI.Wtime() - start_time
+        self.mem_after_mpi = mem()
+
+    def print_time_per_apply(self):
+        print('W:  {:.5f}\t{:.5f}'.format(*self.W.time_per_apply()))
+        print('S:  {:.5f}\t{:.5f}'.format(*self.S.time_per_apply()))
+        print('WT: {:.5f}\t{:.5f}'.format(*self.WT.time_per_apply()))
+        print('P:  {:.5f}\t{:.5f}'.format(*self.P.time_per_apply()))
+        print('')
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser(
+        description='Solve heatequation on MI355X GPUs, one time slab each.')
+    parser.add_argument('--problem', default='square',
+                        help='problem type (square, lshape)')
+    parser.add_argument('--J_time', type=int, default=7,
+                        help='number of time refines')
+    parser.add_argument('--J_space', type=int, default=7,
+                        help='number of space refines')
+    parser.add_argument('--smoothsteps', type=int, default=3,
+                        help='number of smoothing steps')
+    parser.add_argument('--vcycles', type=int, default=2,
+                        help='number of vcycles')
+    parser.add_argument('--wavelettransform', default='composite',
+                        help='type of wavelettransform')
+    parser.add_argument('--alpha', type=float, default=0.3, help='alpha')
+    parser.add_argument('--schur', default='fused',
+                        help='fused (2 multigrid applies per S) or reference')
+    args = parser.parse_args(argv)
+    J_time, J_space = args.J_time, args.J_space
+
+    comm = MPI.COMM_WORLD
+    rank, size = comm.Get_rank(), comm.Get_size()
+    if size > 2**J_time + 1:
+        print('Too many ranks!')
+        sys.exit('1')
+    if rank == 0:
+        print('\n\nCreating mesh with {} time refines and {} space refines.'.
+              format(J_time, J_space))
+        print('GPU ranks: {} '.format(size))
+        print('Arguments: {}'.format(args))
+
+    heat_eq_mpi = HeatEquationMPI(J_space=J_space,
+                                  J_time=J_time,
+                                  problem=args.problem,
+                                  smoothsteps=args.smoothsteps,
+                                  vcycles=args.vcycles,
+                                  alpha=args.alpha,
+                                  wavelettransform=args.wavelettransform,
+                                  schur=args.schur)
+    if rank == 0:
+        print('N = {}. M = {}.'.format(heat_eq_mpi.N, heat_eq_mpi.M))
+        print('Constructed bilinear forms in {} s.'.format(
+            heat_eq_mpi.setup_time))
+        print('Device memory after construction: {}mb.'.format(mem()))
+
+    def cb(w, residual, k):
+        if rank == 0:
+            print('.', end='', flush=True)
+
+    LinearOperatorMPI.sync_timing = True
+    comm.Barrier()
+    solve_time = MPI.Wtime()
+    hist = []
+    u_mpi_P, iters = PCG(heat_eq_mpi.WT_S_W, heat_eq_mpi.P, heat_eq_mpi.rhs,
+                         callback=cb, history=hist)
+    comm.Barrier()
+    solve_time = MPI.Wtime() - solve_time
+    if rank == 0:
+        print('')
+        print('Completed in {} PCG steps.'.format(iters))
+        print('Total solve time: {}s.'.format(solve_time))
+        print('Final r.Pr: {}'.format(hist[-1]))
+        heat_eq_mpi.print_time_per_apply()
+        print('Device memory after solve: {}mb.'.format(mem()))
+    return heat_eq_mpi, u_mpi_P, iters, hist
+
+
+if __name__ == "__main__":
+    main()

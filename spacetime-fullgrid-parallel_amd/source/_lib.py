@@ -1,0 +1,143 @@
+"""ctypes binding of libstk.so (include/stk.h) and the torch plumbing around it.
+
+PyTorch is used for device memory, streams and torch.distributed only; every
+arithmetic kernel of the hot path is a hand-written HIP kernel in libstk.
+There is NO CPU fallback: if the library is missing, or a tensor does not live
+on a GPU, the call raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'libstk.so')
+
+c_i32, c_i64, c_f64, c_p = (ctypes.c_int32, ctypes.c_int64, ctypes.c_double,
+                            ctypes.c_void_p)
+
+
+class KronTerm(ctypes.Structure):
+    _fields_ = [('tri', c_p), ('vals', c_p), ('x', c_p), ('x_lo', c_p),
+                ('x_hi', c_p)]
+
+
+class MGLevel(ctypes.Structure):
+    _fields_ = [('n', c_i32), ('indptr', c_p), ('indices', c_p),
+                ('vals_a', c_p), ('vals_m', c_p), ('diag', c_p),
+                ('n_fwd', c_i32), ('fwd_ptr_host', c_p), ('fwd_rows', c_p),
+                ('n_bwd', c_i32), ('bwd_ptr_host', c_p), ('bwd_rows', c_p),
+                ('p_indptr', c_p), ('p_indices', c_p), ('p_vals', c_p),
+                ('r_indptr', c_p), ('r_indices', c_p), ('r_vals', c_p)]
+
+
+_PROTOTYPES = {
+    'stk_last_error': (ctypes.c_char_p, []),
+    'stk_version': (ctypes.c_int, []),
+    'stk_device_info': (ctypes.c_int, [c_p, c_p, c_p]),
+    'stk_axpby': (ctypes.c_int, [c_p, c_i64, c_f64, c_p, c_f64, c_p]),
+    'stk_axpbyz': (ctypes.c_int, [c_p, c_i64, c_f64, c_p, c_f64, c_p, c_p]),
+    'stk_dot_work_size': (c_i64, []),
+    'stk_dot': (ctypes.c_int, [c_p, c_i64, c_p, c_p, c_p, c_p]),
+    'stk_pcg_update': (ctypes.c_int,
+                       [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'stk_kron_sum_apply': (ctypes.c_int, [
+        c_p, c_i32, c_i32, c_i32, c_p, c_p, c_i32,
+        ctypes.POINTER(KronTerm), c_f64, c_p
+    ]),
+    'stk_csr_spmm': (ctypes.c_int, [
+        c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_f64, c_p, c_p, c_p, c_f64,
+        c_f64, c_p, c_p
+    ]),
+    'stk_time_csr_apply': (ctypes.c_int, [
+        c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p, c_p, c_i32, c_p
+    ]),
+    'stk_wavelet_apply': (ctypes.c_int,
+                          [c_p, c_i32, c_i32, c_i32, c_i32, c_p, c_p]),
+    'stk_mg_create': (ctypes.c_int, [
+        c_i32,
+        ctypes.POINTER(MGLevel), c_i32, c_i32, c_i32, c_p, c_i32,
+        ctypes.POINTER(c_p)
+    ]),
+    'stk_mg_destroy': (ctypes.c_int, [c_p]),
+    'stk_mg_apply': (ctypes.c_int,
+                     [c_p, c_p, c_i32, c_i32, c_f64, c_p, c_p, c_p, c_p]),
+    'stk_mg_smooth': (ctypes.c_int, [
+        c_p, c_p, c_i32, c_i32, c_i32, c_f64, c_p, c_i32, c_i32, c_p, c_p
+    ]),
+}
+
+EXPORTED_SYMBOLS = sorted(_PROTOTYPES)
+
+_lib = None
+
+
+class StkError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise StkError(
+                'libstk.so not found at %s: build it with '
+                '`python -c "import __graft_entry__ as g; g.build()"` or '
+                '`make -C spacetime-fullgrid-parallel_amd/csrc`. '
+                'There is no CPU fallback.' % LIB_PATH)
+        _lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOTYPES.items():
+            fn = getattr(_lib, name)
+            fn.restype = res
+            fn.argtypes = args
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise StkError(lib().stk_last_error().decode())
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Refuses host tensors."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise StkError('libstk kernels need device tensors; got a %s tensor '
+                       '(no GPU visible? there is no CPU fallback)' % t.device)
+    return t.data_ptr()
+
+
+def compute_device():
+    """Device the slab of this process lives on."""
+    if torch.cuda.is_available():
+        return torch.device('cuda', torch.cuda.current_device())
+    return torch.device('cpu')
+
+
+def to_dev(array, dtype=None):
+    """Uploads a NumPy array (used for CSR arrays and small tables)."""
+    t = torch.from_numpy(np.ascontiguousarray(array))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(compute_device())
+
+
+class DeviceCSR:
+    """A CSR matrix resident on the device: int32 pattern + float64 values
+    (reference source/mpi_shared_mem.py:46-48 fixes the same dtypes)."""
+    def __init__(self, mat):
+        import scipy.sparse as sp
+        mat = sp.csr_matrix(mat)
+        mat.sort_indices()
+        self.shape = mat.shape
+        self.nnz = mat.nnz
+        self.indptr = to_dev(mat.indptr.astype(np.int32))
+        self.indices = to_dev(mat.indices.astype(np.int32))
+        self.data = to_dev(mat.data.astype(np.float64))

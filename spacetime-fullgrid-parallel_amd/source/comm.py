@@ -1,0 +1,131 @@
+"""A small MPI-like facade over torch.distributed.
+
+The reference talks to mpi4py (``from mpi4py import MPI``; every call site is
+listed in SURVEY.md section 2.2).  Here one process drives one GPU and the
+transport is torch.distributed: backend "nccl" (= RCCL over xGMI) on GPUs,
+"gloo" on CPU for the world_size-2 tests.  Only what the hot path uses exists:
+rank/size, scalar allreduce, neighbour / partner point-to-point exchange,
+barrier, and object bcast/gather for driver bookkeeping.
+
+Usage mirrors the reference:  ``from source.comm import MPI`` then
+``MPI.COMM_WORLD``, ``MPI.Wtime()``.
+"""
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+
+class Comm:
+    """Communicator over a torch.distributed process group (None = a single
+    process without torch.distributed)."""
+    def __init__(self, group=None, distributed=None):
+        self.group = group
+        self.distributed = dist.is_initialized() if distributed is None else distributed
+        if self.distributed:
+            self.rank = dist.get_rank(group)
+            self.size = dist.get_world_size(group)
+        else:
+            self.rank, self.size = 0, 1
+
+    def Get_rank(self):
+        return self.rank
+
+    def Get_size(self):
+        return self.size
+
+    # -- collectives ---------------------------------------------------------
+    def allreduce(self, value):
+        """Sum of a Python float over the ranks (reference mpi_vector.py:209)."""
+        if self.size == 1:
+            return value
+        t = torch.tensor([value], dtype=torch.float64, device=self._device())
+        dist.all_reduce(t, group=self.group)
+        return float(t.item())
+
+    def allreduce_tensor_(self, t):
+        """In-place sum of a small tensor that already lives on the compute
+        device (keeps the dot result on the GPU until the single D2H read)."""
+        if self.size > 1:
+            dist.all_reduce(t, group=self.group)
+        return t
+
+    def bcast(self, obj, root=0):
+        if self.size == 1:
+            return obj
+        box = [obj]
+        dist.broadcast_object_list(box, src=root, group=self.group)
+        return box[0]
+
+    def gather(self, obj, root=0):
+        if self.size == 1:
+            return [obj]
+        out = [None] * self.size if self.rank == root else None
+        dist.gather_object(obj, out, dst=root, group=self.group)
+        return out
+
+    def Barrier(self):
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if self.size > 1:
+            dist.barrier(group=self.group)
+
+    # -- point to point --------------------------------------------------------
+    def exchange(self, sends, recvs):
+        """Posts all sends/recvs as one batch (one RCCL group call).
+        sends/recvs: lists of (tensor, peer_rank).  Returns the requests; call
+        ``wait_all`` on them.  Matching is by posting order per peer pair, so
+        both sides must post their transfers with a common ordering (the
+        callers order by global time index)."""
+        ops = [dist.P2POp(dist.isend, t, p, self.group) for t, p in sends]
+        ops += [dist.P2POp(dist.irecv, t, p, self.group) for t, p in recvs]
+        if not ops:
+            return []
+        return dist.batch_isend_irecv(ops)
+
+    @staticmethod
+    def wait_all(reqs):
+        for r in reqs:
+            r.wait()
+
+    def _device(self):
+        if dist.get_backend(self.group) == 'nccl':
+            return torch.device('cuda', torch.cuda.current_device())
+        return torch.device('cpu')
+
+
+def init_from_env():
+    """Joins the job torchrun started (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_*), one process per GPU.  A no-op for a plain single process."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        kw = {}
+        if backend == 'nccl':
+            kw['device_id'] = torch.device('cuda', torch.cuda.current_device())
+        dist.init_process_group(backend, **kw)
+    return Comm()
+
+
+class _MPI:
+    """Namespace with the two names the drivers use."""
+    _world = None
+
+    @property
+    def COMM_WORLD(self):
+        if self._world is None or (dist.is_initialized()
+                                   and not self._world.distributed):
+            self._world = init_from_env()
+        return self._world
+
+    @staticmethod
+    def Wtime():
+        return time.perf_counter()
+
+
+MPI = _MPI()

@@ -1,0 +1,164 @@
+"""Space operators on device slabs, and the serial operator helpers of the
+reference (counterpart of reference source/linop.py).
+
+In the reference a "space operator" is anything SciPy can apply to an (M, k)
+block with one right-hand side per column (``mat_space @ X_loc.T``,
+mpi_kron.py:149).  Here a space operator acts on a device slab ``x[i, t]`` of
+shape (M, ld) -- all time columns at once -- through ``apply(x, out)``.
+
+  SpaceMatrix     a CSR matrix in HBM (SciPy CSR matrices are wrapped
+                  automatically wherever the reference accepts them)
+  CompositeLinOp  x -> A B x (reference linop.py:68-79)
+  MultiGrid       see multigrid.py
+KronLinOp / BlockDiagLinOp are the serial (single-rank, flat NumPy vector in /
+out) operators of reference linop.py:6-15, 29-44, run on the device.
+"""
+import weakref
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+from scipy.sparse.linalg import LinearOperator
+
+from . import _lib
+
+
+class SpaceOp:
+    """Protocol: ``shape`` and ``apply(x, out=None, cm=None, kind=None)`` on
+    (M, ld) device slabs; must not alias x and out."""
+    shape = None
+
+    def apply(self, x, out=None, n_loc=None, **kw):
+        raise NotImplementedError
+
+    # reference-style use on host data: op @ array, one RHS per column
+    def __matmul__(self, X):
+        X = np.asarray(X, dtype=np.float64)
+        one_d = X.ndim == 1
+        Xc = X.reshape(self.shape[1], -1)
+        x = _lib.to_dev(Xc)
+        y = self.apply(x, n_loc=x.shape[1])
+        Y = y.cpu().numpy()
+        return Y.reshape(-1) if one_d else Y
+
+
+_space_cache = {}
+
+
+def as_space_op(mat):
+    """SciPy sparse / dense matrices -> SpaceMatrix (uploaded once per matrix
+    object); SpaceOps pass through."""
+    if isinstance(mat, SpaceOp):
+        return mat
+    key = id(mat)
+    hit = _space_cache.get(key)
+    if hit is not None and hit[0]() is mat:
+        return hit[1]
+    op = SpaceMatrix(mat)
+    try:
+        _space_cache[key] = (weakref.ref(mat), op)
+    except TypeError:
+        pass
+    return op
+
+
+class SpaceMatrix(SpaceOp):
+    def __init__(self, mat):
+        if not sp.issparse(mat):
+            mat = sp.csr_matrix(np.asarray(mat, dtype=np.float64))
+        self.mat = sp.csr_matrix(mat)
+        self.mat.sort_indices()
+        self.shape = self.mat.shape
+        self.dev = _lib.DeviceCSR(self.mat)
+
+    def apply(self, x, out=None, n_loc=None, alpha=1.0, beta=0.0, z=None,
+              **kw):
+        ld = x.shape[1]
+        n_loc = ld if n_loc is None else n_loc
+        if out is None:
+            out = torch.empty((self.shape[0], ld),
+                              dtype=torch.float64,
+                              device=x.device)
+        d = self.dev
+        _lib.check(_lib.lib().stk_csr_spmm(
+            _lib.stream(), self.shape[0], n_loc, ld, _lib.ptr(d.indptr),
+            _lib.ptr(d.indices), _lib.ptr(d.data), 1.0, None, None,
+            _lib.ptr(x), alpha, beta, _lib.ptr(z), _lib.ptr(out)))
+        return out
+
+
+class CompositeLinOp(SpaceOp):
+    """x -> A B x, applied right to left (reference linop.py:68-79)."""
+    def __init__(self, linops):
+        self.linops = [as_space_op(op) for op in linops]
+        self.shape = (self.linops[0].shape[0], self.linops[-1].shape[1])
+        self.dtype = np.float64
+
+    def apply(self, x, out=None, n_loc=None, **kw):
+        y = x
+        for k, op in enumerate(reversed(self.linops)):
+            last = k == len(self.linops) - 1
+            y = op.apply(y, out=out if last else None, n_loc=n_loc, **kw)
+        return y
+
+
+def union_pattern(mats):
+    """One CSR pattern containing the patterns of all `mats`, and every
+    matrix's values expanded onto it (zeros where it has no entry).  The fused
+    Kronecker kernel walks the pattern once for all terms."""
+    mats = [sp.csr_matrix(m) for m in mats]
+    pat = sp.csr_matrix(mats[0].shape)
+    for m in mats:
+        a = m.copy()
+        a.data = np.ones_like(a.data)
+        pat = pat + a
+    pat = sp.csr_matrix(pat)
+    pat.sort_indices()
+    pat.data[:] = 1.0
+    vals = []
+    for m in mats:
+        # expand through a sorted-key lookup so explicit zeros survive
+        full = sp.csr_matrix((np.zeros(pat.nnz), pat.indices, pat.indptr),
+                             shape=pat.shape)
+        m = m.tocsr()
+        m.sort_indices()
+        rows = np.repeat(np.arange(m.shape[0]), np.diff(m.indptr))
+        prow = np.repeat(np.arange(pat.shape[0]), np.diff(pat.indptr))
+        key_p = prow.astype(np.int64) * pat.shape[1] + pat.indices
+        key_m = rows.astype(np.int64) * m.shape[1] + m.indices
+        pos = np.searchsorted(key_p, key_m)
+        assert np.array_equal(key_p[pos], key_m)
+        full.data[pos] = m.data
+        vals.append(full.data)
+    return pat.indptr.astype(np.int32), pat.indices.astype(np.int32), vals
+
+
+# ----------------------------------------------------------------------------
+# Serial operators of the reference (flat NumPy vectors in and out).
+# ----------------------------------------------------------------------------
+def KronLinOp(mat_time, mat_space):
+    """x -> (A kron B) x on the device (reference linop.py:6-15)."""
+    from .mpi_kron import SerialKron
+    N, K = mat_time.shape
+    M, L = mat_space.shape
+    op = SerialKron(mat_time, mat_space)
+    return LinearOperator(matvec=op.matvec, shape=(N * M, K * L))
+
+
+def BlockDiagLinOp(linops):
+    """Block diagonal of space operators (reference linop.py:29-44)."""
+    linops = [as_space_op(op) for op in linops]
+    height = sum(op.shape[0] for op in linops)
+    width = sum(op.shape[1] for op in linops)
+
+    def matvec(x):
+        x = np.asarray(x, dtype=np.float64).reshape(-1)
+        y = np.zeros(height)
+        start_r = start_c = 0
+        for op in linops:
+            end_r, end_c = start_r + op.shape[0], start_c + op.shape[1]
+            y[start_r:end_r] += op @ x[start_c:end_c]
+            start_r, start_c = end_r, end_c
+        return y
+
+    return LinearOperator(matvec=matvec, shape=(height, width))

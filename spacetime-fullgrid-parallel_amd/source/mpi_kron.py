@@ -1,0 +1,498 @@
+"""Time-parallel space-time operators on the GPU (counterpart of reference
+source/mpi_kron.py; same class names, constructor arguments and
+``_matvec(vec_in, vec_out)`` / ``op @ vec`` protocol).
+
+What differs from the reference is where the arithmetic runs: each ``_matvec``
+enqueues hand-written HIP kernels of libstk on the slab in HBM.
+``TridiagKronMatMPI`` with a CSR space factor is ONE kernel (time stencil and
+CSR gather fused), and ``SumMPI`` over such terms fuses up to 4 of them in one
+pass over x and y (``stk_kron_sum_apply``) instead of a temporary and a ``+=``
+per term (reference mpi_kron.py:77-90).
+"""
+import ctypes
+
+import numpy as np
+import scipy.sparse
+import torch
+
+from . import _lib
+from .comm import MPI
+from .linop import SpaceMatrix, SpaceOp, as_space_op, union_pattern
+from .mpi_vector import DofDistributionMPI, KronVectorMPI
+
+
+def as_matrix(operator):
+    """Dense matrix of anything supporting ``@`` on NumPy blocks
+    (reference mpi_kron.py:8-10)."""
+    cols = operator.shape[1]
+    return operator @ np.eye(cols)
+
+
+class LinearOperatorMPI:
+    """Base class for linear space-time operators parallelized in time
+    (reference mpi_kron.py:13-59)."""
+
+    # The reference times every apply with MPI.Wtime.  Kernels are
+    # asynchronous; set this to True (the timing driver does) to bracket each
+    # apply with a device synchronisation so that time_applies is wall time.
+    sync_timing = False
+
+    def __init__(self, dofs_distr):
+        self.dofs_distr = dofs_distr
+        self.N = dofs_distr.N
+        self.M = dofs_distr.M
+        self.num_applies = 0
+        self.time_applies = 0
+        self.time_communication = 0
+
+    def __matmul__(self, x):
+        assert isinstance(x, KronVectorMPI)
+        if LinearOperatorMPI.sync_timing:
+            torch.cuda.synchronize()
+        start_time = MPI.Wtime()
+
+        y = self._matvec(x, x._like())
+
+        if LinearOperatorMPI.sync_timing:
+            torch.cuda.synchronize()
+        self.num_applies += 1
+        self.time_applies += MPI.Wtime() - start_time
+        return y
+
+    def time_per_apply(self):
+        assert (self.time_applies)
+        return (self.time_applies / self.num_applies,
+                self.time_communication / self.num_applies)
+
+    def as_global_matrix(self):
+        """Applies the operator to every unit vector (reference
+        mpi_kron.py:38-59).  Expensive: tests only."""
+        n = self.N * self.M
+        I = np.eye(n)
+        rank = self.dofs_distr.comm.Get_rank()
+        result = x_glob = None
+        if rank == 0:
+            x_glob = np.empty(n)
+            result = np.zeros((n, n))
+        for k in range(n):
+            x_mpi = KronVectorMPI(self.dofs_distr)
+            x_mpi.scatter(I[k, :] if rank == 0 else None)
+            x_mpi = self @ x_mpi
+            x_mpi.gather(x_glob)
+            if rank == 0:
+                result[:, k] = x_glob
+        return result
+
+
+class IdentityMPI(LinearOperatorMPI):
+    def __init__(self, dofs_distr):
+        super().__init__(dofs_distr)
+
+    def _matvec(self, vec_in, vec_out):
+        vec_out.buf.copy_(vec_in.buf)
+        return vec_out
+
+
+def _local_tridiag(dofs_distr, mat_time):
+    """(3, n_loc) coefficients [sub | diag | super] of the local rows of a
+    tridiagonal time matrix (the slicing of reference mpi_kron.py:165-183)."""
+    assert (scipy.sparse.isspmatrix_csr(mat_time))
+    N, K = mat_time.shape
+    assert (N == K)
+    coo = mat_time.tocoo()
+    assert np.all(np.abs(coo.row - coo.col) <= 1), 'time matrix not tridiagonal'
+    tb, te = dofs_distr.t_begin, dofs_distr.t_end
+    tri = np.zeros((3, te - tb))
+    for r, c, v in zip(coo.row, coo.col, coo.data):
+        if tb <= r < te:
+            tri[c - r + 1, r - tb] += v
+    return tri
+
+
+class SumMPI(LinearOperatorMPI):
+    """sum_k L_k (reference mpi_kron.py:71-90).  Consecutive
+    TridiagKronMatMPI terms whose space factor is a plain matrix are fused
+    into one kernel launch per group of 4."""
+    def __init__(self, dofs_distr, linops):
+        assert all(isinstance(linop, LinearOperatorMPI) for linop in linops)
+        self.linops = linops
+        super().__init__(dofs_distr)
+        self._groups = self._plan()
+
+    def _plan(self):
+        groups, run = [], []
+        for op in self.linops:
+            if isinstance(op, TridiagKronMatMPI) and op.fusable:
+                run.append(op)
+                if len(run) == 4:
+                    groups.append(_FusedKronSum(self.dofs_distr, run))
+                    run = []
+            else:
+                if run:
+                    groups.append(_FusedKronSum(self.dofs_distr, run))
+                    run = []
+                groups.append(op)
+        if run:
+            groups.append(_FusedKronSum(self.dofs_distr, run))
+        return groups
+
+    def _matvec(self, vec_in, vec_out):
+        assert (vec_in is not vec_out)
+        self.time_communication = 0
+        first = True
+        vec_tmp = None
+        for g in self._groups:
+            if isinstance(g, _FusedKronSum):
+                self.time_communication += g.apply(vec_in, vec_out,
+                                                   beta=0.0 if first else 1.0)
+            else:
+                if first:
+                    g._matvec(vec_in, vec_out)
+                else:
+                    if vec_tmp is None:
+                        vec_tmp = vec_in._like()
+                    g._matvec(vec_in, vec_tmp)
+                    vec_out += vec_tmp
+                self.time_communication += g.time_communication
+            first = False
+        vec_out.communicated_bdr = False
+        return vec_out
+
+
+class CompositeMPI(LinearOperatorMPI):
+    """L_1 L_2 ... x, right to left (reference mpi_kron.py:93-110)."""
+    def __init__(self, dofs_distr, linops):
+        assert all(isinstance(linop, LinearOperatorMPI) for linop in linops)
+        N, M = linops[0].N, linops[0].M
+        assert all(linop.N == N and linop.M == M for linop in linops)
+        self.linops = linops
+        super().__init__(dofs_distr)
+
+    def _matvec(self, vec_in, vec_out):
+        assert (vec_in is not vec_out)
+        self.time_communication = 0
+        Y = vec_in
+        for linop in reversed(self.linops):
+            Y = linop @ Y
+            self.time_communication += linop.time_communication
+        # hand the last result's storage over instead of copying it
+        vec_out._buf = Y.buf
+        vec_out.communicated_bdr = False
+        return vec_out
+
+
+class BlockDiagMPI(LinearOperatorMPI):
+    """y[t] = C_t x[t] for a list of space operators indexed by the GLOBAL
+    time index (reference mpi_kron.py:113-132).
+
+    Equal operator objects are applied to all their time slices in one batched
+    call.  When every block is ``CompositeLinOp([C, A, C])`` with the C's taken
+    from one MultiGrid family (multigrid.MultiGridFamily), all slices run
+    through a single batched V-cycle with per-slice matrix coefficients."""
+    def __init__(self, dofs_distr, matrices_space):
+        M = matrices_space[0].shape[0]
+        for mat in matrices_space:
+            assert mat.shape == (M, M)
+        self.matrices_space = [as_space_op(m) for m in matrices_space]
+        super().__init__(dofs_distr)
+        self._local = self.matrices_space[dofs_distr.t_begin:dofs_distr.t_end]
+        self._batched = self._try_batch()
+
+    def _try_batch(self):
+        from .linop import CompositeLinOp
+        from .multigrid import MultiGrid
+        ops = self._local
+        if all(op is ops[0] for op in ops):
+            return ('uniform', ops[0])
+        fam = None
+        mids = set()
+        for op in ops:
+            if not (isinstance(op, CompositeLinOp) and len(op.linops) == 3
+                    and op.linops[0] is op.linops[2]
+                    and isinstance(op.linops[0], MultiGrid)
+                    and op.linops[0].family is not None):
+                return None
+            if fam is None:
+                fam = op.linops[0].family
+            if op.linops[0].family is not fam:
+                return None
+            mids.add(id(op.linops[1]))
+        if len(mids) != 1:
+            return None
+        members = [op.linops[0].member for op in ops]
+        return ('family', fam, fam.slice_tables(members), ops[0].linops[1])
+
+    def _matvec(self, vec_in, vec_out):
+        assert (isinstance(vec_in, KronVectorMPI))
+        assert (self.N == vec_in.N and self.M == vec_in.M)
+        assert (vec_in.buf.shape == vec_out.buf.shape)
+        assert (vec_out is not vec_in)
+        n_loc = vec_in.n_loc
+        b = self._batched
+        if b is not None and b[0] == 'uniform':
+            b[1].apply(vec_in.buf, out=vec_out.buf, n_loc=n_loc)
+        elif b is not None and b[0] == 'family':
+            _, fam, (cm, kind), mid = b
+            t1 = fam.apply(vec_in.buf, n_loc=n_loc, cm=cm, kind=kind)
+            t2 = mid.apply(t1, n_loc=n_loc)
+            fam.apply(t2, out=vec_out.buf, n_loc=n_loc, cm=cm, kind=kind)
+        else:
+            # general case: one time slice at a time
+            for t_loc, linop in enumerate(self._local):
+                col = vec_in.buf[:, t_loc:t_loc + 1].contiguous()
+                res = linop.apply(col, n_loc=1)
+                vec_out.buf[:, t_loc:t_loc + 1].copy_(res)
+        vec_out.communicated_bdr = False
+        return vec_out
+
+
+class IdentityKronMatMPI(LinearOperatorMPI):
+    """I_t kron M_x (reference mpi_kron.py:135-150)."""
+    def __init__(self, dofs_distr, mat_space):
+        M, L = mat_space.shape
+        assert (M == L)
+        self.mat_space = mat_space
+        self.space_op = as_space_op(mat_space)
+        super().__init__(dofs_distr)
+
+    def _matvec(self, vec_in, vec_out):
+        assert (isinstance(vec_in, KronVectorMPI))
+        assert (self.N == vec_in.N and self.M == vec_in.M)
+        assert (vec_in.buf.shape == vec_out.buf.shape)
+        if vec_in is vec_out:  # allowed by the reference (mpi_kron.py:216)
+            vec_out._buf = self.space_op.apply(vec_in.buf, n_loc=vec_in.n_loc)
+        else:
+            self.space_op.apply(vec_in.buf, out=vec_out.buf,
+                                n_loc=vec_in.n_loc)
+        vec_out.communicated_bdr = False
+        return vec_out
+
+
+class _TimeCSR:
+    """Local rows of a sparse time matrix on the device; columns are local
+    time indices, or n_loc + slot for rows that live on other ranks."""
+    def __init__(self, n_loc, rows, cols, vals):
+        m = scipy.sparse.csr_matrix((vals, (rows, cols)),
+                                    shape=(n_loc, max(cols, default=0) + 1))
+        m.sort_indices()
+        self.indptr = _lib.to_dev(m.indptr.astype(np.int32))
+        self.cols = _lib.to_dev(m.indices.astype(np.int32))
+        self.vals = _lib.to_dev(m.data.astype(np.float64))
+
+    def apply(self, vec_in, recv, add_identity, vec_out):
+        _lib.check(_lib.lib().stk_time_csr_apply(
+            _lib.stream(), vec_in.M, vec_in.n_loc, vec_in.ld,
+            _lib.ptr(self.indptr), _lib.ptr(self.cols), _lib.ptr(self.vals),
+            _lib.ptr(vec_in.buf), _lib.ptr(recv), int(add_identity),
+            _lib.ptr(vec_out.buf)))
+
+
+class TridiagKronIdentityMPI(LinearOperatorMPI):
+    """T_t kron I_x for a tridiagonal T_t: one ghost time row from each
+    neighbour rank (reference mpi_kron.py:153-201)."""
+    def __init__(self, dofs_distr, mat_time):
+        self.tri = _local_tridiag(dofs_distr, mat_time)
+        super().__init__(dofs_distr)
+        n_loc = dofs_distr.t_end - dofs_distr.t_begin
+        rows, cols, vals = [], [], []
+        for t in range(n_loc):
+            for d in (0, 1, 2):
+                v = self.tri[d, t]
+                if v == 0.0:
+                    continue
+                c = t + d - 1
+                if c < 0:
+                    c = n_loc  # ghost slot 0 = X_lo
+                elif c >= n_loc:
+                    c = n_loc + 1  # ghost slot 1 = X_hi
+                rows.append(t), cols.append(c), vals.append(v)
+        self._csr = _TimeCSR(n_loc, rows, cols, vals)
+
+    def _matvec(self, vec_in, vec_out):
+        assert (isinstance(vec_in, KronVectorMPI))
+        assert (self.N == vec_in.N and self.M == vec_in.M)
+        assert (vec_in.buf.shape == vec_out.buf.shape)
+        assert (vec_in is not vec_out)
+        self.time_communication += vec_in.communicate_bdr()
+        ghost = None
+        if vec_in.X_lo is not None or vec_in.X_hi is not None:
+            ghost = vec_in.ghost_pair()
+        self._csr.apply(vec_in, ghost, False, vec_out)
+        vec_out.communicated_bdr = False
+        return vec_out
+
+
+class TridiagKronMatMPI(LinearOperatorMPI):
+    """T_t kron M_x (reference mpi_kron.py:204-222).  One fused kernel when
+    M_x is a plain matrix; otherwise the time factor, then the space operator
+    on the result, as the reference does."""
+    def __init__(self, dofs_distr, mat_time, mat_space):
+        super().__init__(dofs_distr)
+        self.mat_time = mat_time
+        self.mat_space = mat_space
+        self.space_op = as_space_op(mat_space)
+        self.fusable = isinstance(self.space_op, SpaceMatrix)
+        if self.fusable:
+            self._fused = _FusedKronSum(dofs_distr, [self])
+        else:
+            self.I_M = IdentityKronMatMPI(dofs_distr, self.space_op)
+            self.T_I = TridiagKronIdentityMPI(dofs_distr, mat_time)
+
+    def _matvec(self, vec_in, vec_out):
+        if self.fusable:
+            assert (vec_in is not vec_out)
+            self.time_communication = self._fused.apply(vec_in, vec_out, 0.0)
+        else:
+            self.T_I._matvec(vec_in, vec_out)
+            self.I_M._matvec(vec_out, vec_out)
+            self.time_communication = (self.I_M.time_communication +
+                                       self.T_I.time_communication)
+        vec_out.communicated_bdr = False
+        return vec_out
+
+    def as_matrix(self):
+        return np.kron(as_matrix(self.mat_time), as_matrix(self.mat_space))
+
+
+class _FusedKronSum:
+    """y = beta*y + sum_k (T_k kron X_k) x for up to 4 TridiagKronMatMPI terms
+    with plain CSR space factors: shared pattern, one launch."""
+    def __init__(self, dofs_distr, ops):
+        assert 1 <= len(ops) <= 4
+        self.dofs_distr = dofs_distr
+        mats = [op.space_op.mat for op in ops]
+        indptr, indices, vals = union_pattern(mats)
+        self.indptr = _lib.to_dev(indptr)
+        self.indices = _lib.to_dev(indices)
+        self.vals = [_lib.to_dev(v) for v in vals]
+        self.nnz = len(indices)
+        tris = [_local_tridiag(dofs_distr, op.mat_time) for op in ops]
+        self.needs_lo = any(t[0, 0] != 0.0 for t in tris)
+        self.needs_hi = any(t[2, -1] != 0.0 for t in tris)
+        self.tri = [_lib.to_dev(t) for t in tris]
+        self.terms = (_lib.KronTerm * len(ops))()
+
+    def apply(self, vec_in, vec_out, beta=0.0):
+        time_comm = 0.0
+        if self.dofs_distr.size > 1:
+            time_comm = vec_in.communicate_bdr()
+        lo = _lib.ptr(vec_in.X_lo) if (self.needs_lo
+                                       and vec_in.X_lo is not None) else None
+        hi = _lib.ptr(vec_in.X_hi) if (self.needs_hi
+                                       and vec_in.X_hi is not None) else None
+        x = _lib.ptr(vec_in.buf)
+        for k in range(len(self.terms)):
+            t = self.terms[k]
+            t.tri, t.vals = _lib.ptr(self.tri[k]), _lib.ptr(self.vals[k])
+            t.x, t.x_lo, t.x_hi = x, lo, hi
+        _lib.check(_lib.lib().stk_kron_sum_apply(
+            _lib.stream(), vec_in.M, vec_in.n_loc, vec_in.ld,
+            _lib.ptr(self.indptr), _lib.ptr(self.indices), len(self.terms),
+            self.terms, beta, _lib.ptr(vec_out.buf)))
+        return time_comm
+
+    def algorithmic_bytes(self, n_loc, M):
+        """Bytes one apply must move: x once, y once,
+        ghost rows, every CSR array once."""
+        h = int(self.needs_lo and self.dofs_distr.rank > 0) + int(
+            self.needs_hi and self.dofs_distr.rank + 1 < self.dofs_distr.size)
+        return (16 * n_loc * M + 8 * h * M +
+                (4 + 8 * len(self.vals)) * self.nnz + 4 * (M + 1))
+
+
+class SparseKronIdentityMPI(LinearOperatorMPI):
+    """M_t kron I_x for a sparse time matrix with symmetric sparsity pattern;
+    rows of other ranks are fetched point-to-point
+    (reference mpi_kron.py:259-317)."""
+    def __init__(self, dofs_distr, mat_time, add_identity=False):
+        super().__init__(dofs_distr)
+        assert scipy.sparse.isspmatrix_csr(mat_time)
+        N, K = mat_time.shape
+        assert (N == K)
+        assert (mat_time.nnz)
+        self.add_identity = add_identity
+        tb, te = dofs_distr.t_begin, dofs_distr.t_end
+        coo = mat_time.tocoo()
+        keep = (coo.row >= tb) & (coo.row < te)
+        self.row, self.col, self.data = (coo.row[keep], coo.col[keep],
+                                         coo.data[keep])
+        self.comm_dofs = sorted(
+            set((int(r), int(c)) for r, c in zip(self.row, self.col)
+                if c < tb or te <= c))
+        need = sorted(set(c for _, c in self.comm_dofs))
+        slot = {c: k for k, c in enumerate(need)}
+        n_loc = te - tb
+        cols = [
+            int(c - tb) if tb <= c < te else n_loc + slot[int(c)]
+            for c in self.col
+        ]
+        self._csr = _TimeCSR(n_loc, list(self.row - tb), cols,
+                             list(self.data))
+
+    def _matvec(self, vec_in, vec_out):
+        assert (isinstance(vec_in, KronVectorMPI))
+        assert (self.N == vec_in.N and self.M == vec_in.M)
+        assert (vec_in.buf.shape == vec_out.buf.shape)
+        assert vec_out is not vec_in
+        recv = None
+        if len(self.comm_dofs):
+            recv, _, reqs = vec_in.communicate_dofs(self.comm_dofs)
+            start_time = MPI.Wtime()
+            self.dofs_distr.comm.wait_all(reqs)
+            self.time_communication += MPI.Wtime() - start_time
+        self._csr.apply(vec_in, recv, self.add_identity, vec_out)
+        vec_out.communicated_bdr = False
+        return vec_out
+
+
+class MatKronIdentityMPI(LinearOperatorMPI):
+    """M_t kron I_x for a general (dense) time matrix through an all-to-all
+    transpose of the vector (reference mpi_kron.py:225-256)."""
+    def __init__(self, dofs_distr, mat_time):
+        N, K = mat_time.shape
+        assert (N == K)
+        self.mat_time = mat_time
+        if hasattr(mat_time, 'levels'):
+            self.levels = mat_time.levels
+        super().__init__(dofs_distr)
+        dense = mat_time if isinstance(mat_time, np.ndarray) else (
+            mat_time.toarray() if scipy.sparse.issparse(mat_time) else
+            as_matrix(mat_time))
+        self._time_op = SpaceMatrix(scipy.sparse.csr_matrix(dense))
+
+    def _matvec(self, vec_in, vec_out):
+        assert (isinstance(vec_in, KronVectorMPI))
+        assert (self.N == vec_in.N and self.M == vec_in.M)
+        assert (vec_in.buf.shape == vec_out.buf.shape)
+        vec_perm, comm_time = vec_in.permute()
+        self.time_communication += comm_time
+        # the permuted vector has the time index as its "space" index
+        vec_perm._buf = self._time_op.apply(vec_perm.buf,
+                                            n_loc=vec_perm.n_loc)
+        _, comm_time = vec_perm.permute(vec_out)
+        self.time_communication += comm_time
+        vec_out.communicated_bdr = False
+        return vec_out
+
+
+class SerialKron:
+    """(A kron B) on a flat host vector, run on the device (single rank);
+    backs linop.KronLinOp (reference linop.py:6-15)."""
+    def __init__(self, mat_time, mat_space):
+        N, K = mat_time.shape
+        assert N == K, 'square time factors only'
+        self.N, self.M = N, mat_space.shape[0]
+        assert mat_space.shape[0] == mat_space.shape[1]
+        mt = scipy.sparse.csr_matrix(mat_time).tocoo()
+        self._csr = _TimeCSR(N, list(mt.row), list(mt.col), list(mt.data))
+        self._space = as_space_op(mat_space)
+        from .comm import Comm
+        self._dd = DofDistributionMPI(Comm(distributed=False), N, self.M)
+
+    def matvec(self, x):
+        X = np.asarray(x, dtype=np.float64).reshape(self.N, self.M)
+        v = KronVectorMPI(self._dd, X)
+        z = v._like()
+        self._csr.apply(v, None, False, z)
+        y = self._space.apply(z.buf, n_loc=self.N)
+        return y[:, :self.N].t().contiguous().cpu().numpy().reshape(-1)

@@ -1,0 +1,415 @@
+"""Time-slab distributed vectors on the GPU (counterpart of reference
+source/mpi_vector.py).
+
+Same classes, attributes and call signatures as the reference; differences:
+* the slab lives in HBM, space-major: ``_buf[i, t]`` (shape (M, ld)), so that a
+  time column is contiguous (see include/stk.h).  ``X_loc`` is the reference's
+  (N_loc, M) view of it (a transposed torch view, writable);
+* arithmetic runs in libstk's BLAS-1 kernels; ``alpha * p`` is lazy so that the
+  reference's ``w += alpha * p`` (linalg.py:29) becomes one fused pass;
+* communication goes through torch.distributed (RCCL/xGMI) instead of mpi4py.
+"""
+import weakref
+
+import numpy as np
+import torch
+
+from . import _lib
+from .comm import MPI
+
+
+class DofDistributionMPI:
+    """Block partition of the N time dofs over the ranks: N // size each, the
+    last N % size ranks get one more (reference mpi_vector.py:5-38)."""
+    def __init__(self, comm, N, M):
+        self.N = N
+        self.M = M
+        self.comm = comm
+        self.rank = comm.Get_rank()
+        self.size = comm.Get_size()
+        assert (self.N >= self.size)
+
+        block_size, rest_size = divmod(self.N, self.size)
+        self.dof_distribution = []
+        self.displs = np.empty(self.size)
+        self.counts = np.empty(self.size)
+        start = 0
+        for p in range(self.size):
+            stop = start + block_size + (1 if self.size - p - 1 < rest_size
+                                         else 0)
+            self.dof_distribution.append([start, stop])
+            self.displs[p] = start * self.M
+            self.counts[p] = (stop - start) * self.M
+            start = stop
+        assert (start == self.N)
+        self.t_begin, self.t_end = self.dof_distribution[self.rank]
+
+        self.dof2proc = np.zeros(self.N)
+        for p, (t_begin, t_end) in enumerate(self.dof_distribution):
+            self.dof2proc[t_begin:t_end] = p
+
+
+_dot_ws = {}
+
+
+def _dot_workspace(device):
+    ws = _dot_ws.get(device)
+    if ws is None:
+        n = int(_lib.lib().stk_dot_work_size())
+        ws = (torch.empty(n, dtype=torch.float64, device=device),
+              torch.empty(2, dtype=torch.float64, device=device))
+        _dot_ws[device] = ws
+    return ws
+
+
+class KronVectorMPI:
+    """A vector distributed in its first (time) component
+    (reference mpi_vector.py:41-240)."""
+    # NumPy scalars must defer to __rmul__ instead of broadcasting over us
+    __array_ufunc__ = None
+
+    def __init__(self, dofs_distr, initial_data=None):
+        self.dofs_distr = dofs_distr
+
+        # Convenience
+        self.t_begin = dofs_distr.t_begin
+        self.t_end = dofs_distr.t_end
+        self.N = dofs_distr.N
+        self.M = dofs_distr.M
+        self.rank = dofs_distr.rank
+        self.n_loc = self.t_end - self.t_begin
+        self.ld = self.n_loc
+        self._pending = None
+
+        self.reset(initial_data)
+
+    # -- storage -------------------------------------------------------------
+    @property
+    def buf(self):
+        """Device slab, shape (M, ld), float64."""
+        return self._buf
+
+    @property
+    def X_loc(self):
+        """(N_loc, M) view in the reference's orientation."""
+        return self.buf[:, :self.n_loc].t()
+
+    def reset(self, initial_data=None):
+        self.communicated_bdr = False
+        # ghost time rows (the reference's X_loc_bdr[0] and X_loc_bdr[-1])
+        self.X_lo = self.X_hi = self._ghost = None
+        self._notify_pending()
+        dev = _lib.compute_device()
+        if initial_data is None:
+            self._buf = torch.zeros((self.M, self.ld),
+                                    dtype=torch.float64,
+                                    device=dev)
+        else:
+            assert tuple(initial_data.shape) == (self.n_loc, self.M)
+            self._buf = torch.zeros((self.M, self.ld),
+                                    dtype=torch.float64,
+                                    device=dev)
+            src = initial_data if torch.is_tensor(
+                initial_data) else torch.from_numpy(
+                    np.ascontiguousarray(initial_data, dtype=np.float64))
+            self._buf[:, :self.n_loc].copy_(src.to(dev).t())
+
+    def copy(self):
+        cpy = KronVectorMPI.__new__(KronVectorMPI)
+        cpy.__dict__.update(self.__dict__)
+        cpy._pending = None
+        cpy.communicated_bdr = False
+        cpy.X_lo = cpy.X_hi = cpy._ghost = None
+        cpy._buf = self.buf.clone()
+        return cpy
+
+    def _like(self):
+        out = KronVectorMPI.__new__(KronVectorMPI)
+        out.__dict__.update(self.__dict__)
+        out._pending = None
+        out.communicated_bdr = False
+        out.X_lo = out.X_hi = out._ghost = None
+        out._buf = torch.empty_like(self.buf)
+        return out
+
+    def _notify_pending(self):
+        # lazy `alpha * self` expressions must see the value from before the
+        # mutation that is about to happen
+        if getattr(self, '_pending', None):
+            for s in list(self._pending):
+                s._force()
+            self._pending = None
+
+    def _invalidate(self):
+        """Call before mutating: drops the cached ghost rows
+        (reference mpi_vector.py:77-82)."""
+        self.communicated_bdr = False
+        self._notify_pending()
+
+    # -- arithmetic (libstk BLAS-1) -------------------------------------------
+    def _axpby(self, a, x_buf, b):
+        n = self.buf.numel()
+        _lib.check(_lib.lib().stk_axpby(_lib.stream(), n, a, _lib.ptr(x_buf),
+                                        b, _lib.ptr(self.buf)))
+
+    def __iadd__(self, other):
+        self._invalidate()
+        if isinstance(other, _ScaledVector) and other._lazy:
+            self._axpby(other._alpha, other._src.buf, 1.0)
+        else:
+            self._axpby(1.0, other.buf, 1.0)
+        return self
+
+    def __isub__(self, other):
+        self._invalidate()
+        if isinstance(other, _ScaledVector) and other._lazy:
+            self._axpby(-other._alpha, other._src.buf, 1.0)
+        else:
+            self._axpby(-1.0, other.buf, 1.0)
+        return self
+
+    def __imul__(self, other):
+        self._invalidate()
+        self._axpby(float(other), self.buf, 0.0)
+        return self
+
+    def __itruediv__(self, other):
+        self._invalidate()
+        self._axpby(1.0 / float(other), self.buf, 0.0)
+        return self
+
+    def _combine(self, a, other, b):
+        """a * self + b * other as a new vector (one pass)."""
+        xa, xb = self, other
+        if isinstance(xa, _ScaledVector) and xa._lazy:
+            a, xa = a * xa._alpha, xa._src
+        if isinstance(xb, _ScaledVector) and xb._lazy:
+            b, xb = b * xb._alpha, xb._src
+        out = xa._like()
+        _lib.check(_lib.lib().stk_axpbyz(_lib.stream(), out.buf.numel(), a,
+                                         _lib.ptr(xa.buf), b,
+                                         _lib.ptr(xb.buf), _lib.ptr(out.buf)))
+        return out
+
+    def __add__(self, other):
+        return self._combine(1.0, other, 1.0)
+
+    def __sub__(self, other):
+        return self._combine(1.0, other, -1.0)
+
+    def __rmul__(self, other):
+        return _ScaledVector(float(other), self)
+
+    def __mul__(self, other):
+        return _ScaledVector(float(other), self)
+
+    def __neg__(self):
+        return _ScaledVector(-1.0, self)
+
+    def __truediv__(self, other):
+        return _ScaledVector(1.0 / float(other), self)
+
+    def dot(self, vec_other):
+        """Global inner product (reference mpi_vector.py:205-210): local
+        deterministic reduction on the device, sum over ranks, one D2H read."""
+        assert (isinstance(vec_other, KronVectorMPI))
+        assert (vec_other.buf.shape == self.buf.shape)
+        work, out = _dot_workspace(self.buf.device)
+        _lib.check(_lib.lib().stk_dot(_lib.stream(), self.buf.numel(),
+                                      _lib.ptr(self.buf),
+                                      _lib.ptr(vec_other.buf), _lib.ptr(work),
+                                      _lib.ptr(out)))
+        self.dofs_distr.comm.allreduce_tensor_(out[:1])
+        return float(out[0].item())
+
+    # -- I/O -------------------------------------------------------------------
+    def scatter(self, X_glob):
+        """Root's flat global array -> slabs (reference mpi_vector.py:124-132)."""
+        comm, dd = self.dofs_distr.comm, self.dofs_distr
+        self._invalidate()
+        dev = self.buf.device
+        if comm.size == 1:
+            slab = torch.from_numpy(
+                np.ascontiguousarray(X_glob, dtype=np.float64).reshape(
+                    self.N, self.M))
+        else:
+            slab = torch.empty((self.n_loc, self.M), dtype=torch.float64)
+            if comm.rank == 0:
+                X = torch.from_numpy(
+                    np.ascontiguousarray(X_glob, dtype=np.float64).reshape(
+                        self.N, self.M))
+                sends = [(X[b:e].contiguous().to(comm._device()), p)
+                         for p, (b, e) in enumerate(dd.dof_distribution)
+                         if p != 0]
+                reqs = comm.exchange(sends, [])
+                slab = X[dd.dof_distribution[0][0]:dd.dof_distribution[0][1]]
+                comm.wait_all(reqs)
+            else:
+                slab = slab.to(comm._device())
+                comm.wait_all(comm.exchange([], [(slab, 0)]))
+        self._buf[:, :self.n_loc].copy_(slab.to(dev).t())
+
+    def gather(self, X_glob):
+        """Slabs -> root's flat global array (reference mpi_vector.py:134-138)."""
+        comm, dd = self.dofs_distr.comm, self.dofs_distr
+        mine = self.X_loc.contiguous()
+        if comm.size == 1:
+            X_glob[...] = mine.cpu().numpy().reshape(X_glob.shape)
+            return
+        if comm.rank == 0:
+            out = np.asarray(X_glob).reshape(self.N, self.M)
+            bufs = {
+                p: torch.empty((e - b, self.M),
+                               dtype=torch.float64,
+                               device=comm._device())
+                for p, (b, e) in enumerate(dd.dof_distribution) if p != 0
+            }
+            reqs = comm.exchange([], [(t, p) for p, t in bufs.items()])
+            out[self.t_begin:self.t_end] = mine.cpu().numpy()
+            comm.wait_all(reqs)
+            for p, t in bufs.items():
+                b, e = dd.dof_distribution[p]
+                out[b:e] = t.cpu().numpy()
+        else:
+            comm.wait_all(comm.exchange([(mine.to(comm._device()), 0)], []))
+
+    # -- communication -----------------------------------------------------------
+    def communicate_bdr(self, callback=None):
+        """Fetches the ghost time rows t_begin-1 and t_end from the neighbour
+        ranks into X_lo / X_hi while `callback` computes what does not need
+        them; cached until the vector is mutated
+        (reference mpi_vector.py:140-187)."""
+        if self.communicated_bdr:
+            if callback is not None:
+                callback()
+            return 0.0
+        comm = self.dofs_distr.comm
+        rank, size = self.rank, self.dofs_distr.size
+        sends, recvs = [], []
+        if size > 1 and getattr(self, '_ghost', None) is None:
+            # row 0 = X_lo (time row t_begin - 1), row 1 = X_hi (row t_end)
+            self._ghost = torch.zeros((2, self.M),
+                                      dtype=torch.float64,
+                                      device=self.buf.device)
+        if rank > 0:
+            self.X_lo = self._ghost[0]
+            sends.append((self.buf[:, 0].contiguous(), rank - 1))
+            recvs.append((self.X_lo, rank - 1))
+        if rank + 1 < size:
+            self.X_hi = self._ghost[1]
+            sends.append((self.buf[:, self.n_loc - 1].contiguous(), rank + 1))
+            recvs.append((self.X_hi, rank + 1))
+        reqs = comm.exchange(sends, recvs)
+
+        # Do computation that doesn't require the bdr to be present.
+        if callback is not None:
+            callback()
+
+        start_time = MPI.Wtime()
+        comm.wait_all(reqs)
+        time_communication = MPI.Wtime() - start_time
+        self.communicated_bdr = True
+        return time_communication
+
+    def ghost_pair(self):
+        """(2, M) buffer [X_lo; X_hi] filled by communicate_bdr."""
+        return self._ghost
+
+    def communicate_dofs(self, comm_dofs):
+        """Fetches arbitrary remote time rows.  `comm_dofs` = (local row,
+        remote row) pairs of a time matrix with symmetric sparsity pattern
+        (reference mpi_vector.py:189-203).  Each needed row travels once per
+        destination; messages between a pair of ranks are ordered by
+        (row sent, rank) on both sides, which replaces MPI tags.
+        Returns (recv buffer (n_recv, M), {remote row: slot}, requests)."""
+        dd = self.dofs_distr
+        need = sorted(set(int(r) for _, r in comm_dofs))
+        slot = {r: k for k, r in enumerate(need)}
+        recv_buf = torch.empty((len(need), self.M),
+                               dtype=torch.float64,
+                               device=self.buf.device)
+        send_set = sorted(
+            set((int(s), int(dd.dof2proc[int(r)])) for s, r in comm_dofs))
+        sends = [(self.buf[:, s - self.t_begin].contiguous(), p)
+                 for s, p in send_set]
+        recvs = [(recv_buf[slot[r]], int(dd.dof2proc[r])) for r in need]
+        reqs = dd.comm.exchange(sends, recvs)
+        return recv_buf, slot, reqs
+
+    def permute(self, vec_perm=None):
+        """Swaps the roles of time and space: all-to-all transpose
+        (reference mpi_vector.py:212-240).  Returns (vector distributed over
+        the M space dofs with N as second component, communication time)."""
+        start_time = MPI.Wtime()
+        comm = self.dofs_distr.comm
+        if vec_perm is None:
+            vec_perm = KronVectorMPI(DofDistributionMPI(comm, self.M, self.N))
+        else:
+            assert (vec_perm.N == self.M and vec_perm.M == self.N)
+            vec_perm._invalidate()
+        pd = vec_perm.dofs_distr
+        x_begin, x_end = vec_perm.t_begin, vec_perm.t_end
+        # own block needs no transfer
+        if comm.size == 1:
+            # vec_perm.buf[tglob, x - x_begin] = self.buf[x, t]
+            vec_perm._buf[:, :vec_perm.n_loc].copy_(
+                self.buf[x_begin:x_end, :self.n_loc].t())
+            return vec_perm, MPI.Wtime() - start_time
+        sends, recvs, staged = [], [], []
+        for p in range(comm.size):
+            xb, xe = pd.dof_distribution[p]
+            tb, te = self.dofs_distr.dof_distribution[p]
+            if p == comm.rank:
+                vec_perm._buf[tb:te, :vec_perm.n_loc].copy_(
+                    self.buf[xb:xe, :self.n_loc].t())
+                continue
+            sends.append((self.buf[xb:xe, :self.n_loc].contiguous(), p))
+            rbuf = torch.empty((x_end - x_begin, te - tb),
+                               dtype=torch.float64,
+                               device=self.buf.device)
+            recvs.append((rbuf, p))
+            staged.append((tb, te, rbuf))
+        comm.wait_all(comm.exchange(sends, recvs))
+        for tb, te, rbuf in staged:
+            vec_perm._buf[tb:te, :vec_perm.n_loc].copy_(rbuf.t())
+        return vec_perm, MPI.Wtime() - start_time
+
+
+class _ScaledVector(KronVectorMPI):
+    """`alpha * x`, evaluated lazily: consumed by += / -= / + / - as a fused
+    axpy, or materialised on first use as an ordinary vector."""
+    def __init__(self, alpha, src):
+        if isinstance(src, _ScaledVector) and src._lazy:
+            alpha, src = alpha * src._alpha, src._src
+        self.__dict__.update(src.__dict__)
+        self._pending = None
+        self.communicated_bdr = False
+        self.X_lo = self.X_hi = self._ghost = None
+        self._alpha, self._src, self._lazy = alpha, src, True
+        self.__dict__.pop('_buf', None)
+        if src._pending is None:
+            src._pending = weakref.WeakSet()
+        src._pending.add(self)
+
+    def _force(self):
+        if self._lazy:
+            src = self._src
+            buf = torch.empty_like(src.buf)
+            _lib.check(_lib.lib().stk_axpbyz(_lib.stream(), buf.numel(),
+                                             self._alpha, _lib.ptr(src.buf),
+                                             0.0, None, _lib.ptr(buf)))
+            self.__dict__['_buf'] = buf
+            self._lazy = False
+            if src._pending is not None:
+                src._pending.discard(self)
+            self._src = None
+
+    @property
+    def _buf(self):
+        self._force()
+        return self.__dict__['_buf']
+
+    @_buf.setter
+    def _buf(self, value):
+        self._lazy = False
+        self.__dict__['_buf'] = value

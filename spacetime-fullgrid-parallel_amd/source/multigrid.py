@@ -1,0 +1,262 @@
+"""Spatial multigrid with Gauss-Seidel smoothing on the GPU (counterpart of
+reference source/multigrid.py).
+
+``MeshHierarchy`` and ``MultiGrid`` keep the reference's constructor
+signatures.  Setup (Galerkin products, reference multigrid.py:142-145) is done
+once on the host with SciPy, as in the reference; every V-cycle then runs in
+libstk (``stk_mg_apply``) on all time slices of the slab at once.
+
+The smoother is the reference's sequential Gauss-Seidel sweep in dof order
+(multigrid.py:83-97, which is what it asks of PETSc MatSOR, :116-127).  It is
+run in parallel without changing its result by scheduling rows along the
+dependency DAG of the sweep; see csrc/mg.hip and mesh.py.
+
+``MultiGridFamily`` is an addition: the preconditioner needs one multigrid per
+wavelet level for the matrices 2^j M_x + alpha A_x (reference
+heateq_mpi.py:97-98, 147-153).  A family stores A and M hierarchies once and
+applies all members in one batched V-cycle with a per-time-slice coefficient.
+"""
+import ctypes
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from . import _lib
+from .assembly import prolongation_matrices
+from .linop import SpaceOp, union_pattern
+
+
+class MeshHierarchy:
+    """Prolongation / restriction matrices between the free dofs of the levels
+    of a hierarchically numbered mesh (reference multigrid.py:14-80).  Takes a
+    mesh.TriangleMesh (the reference takes an NGSolve H1 space), or a ready
+    list of prolongation matrices."""
+    def __init__(self, fes=None, shared_comm=None, P_mats=None):
+        if P_mats is None:
+            mesh = getattr(fes, 'mesh', fes)
+            P_mats = prolongation_matrices(mesh)
+        self.shared_comm = shared_comm
+        self.P_mats = [sp.csr_matrix(P) for P in P_mats]
+        self.R_mats = [P.T.tocsr() for P in self.P_mats]
+        self.J = len(self.P_mats)
+
+
+def gauss_seidel_schedule(indptr, indices, backward=False):
+    """Groups the rows of a CSR pattern by their depth in the dependency DAG
+    of a Gauss-Seidel sweep in dof order: row i must wait for its neighbours
+    j < i (forward) or j > i (backward).  Returns (ptr, rows): rows of group g
+    are rows[ptr[g]:ptr[g+1]], ascending (descending for backward), and are
+    mutually independent."""
+    n = len(indptr) - 1
+    rows_of = np.repeat(np.arange(n), np.diff(indptr))
+    dep = indices > rows_of if backward else indices < rows_of
+    depth = np.zeros(n, dtype=np.int64)
+    nonempty = np.flatnonzero(np.diff(indptr) > 0)
+    starts = indptr[:-1][nonempty]
+    while True:
+        cand = np.where(dep, depth[indices] + 1, 0)
+        new = np.zeros(n, dtype=np.int64)
+        if len(cand):
+            new[nonempty] = np.maximum.reduceat(cand, starts)
+        if np.array_equal(new, depth):
+            break
+        depth = new
+    order = np.argsort(depth, kind='stable')
+    if backward:
+        # descending row index inside a group, like the sequential sweep
+        order = np.lexsort((-np.arange(n), depth))
+    counts = np.bincount(depth, minlength=int(depth.max()) + 1 if n else 1)
+    ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    return ptr, order.astype(np.int32)
+
+
+class _DeviceHierarchy:
+    """Everything one libstk multigrid plan needs, resident on the device."""
+    def __init__(self, mat_a, mat_m, hierarchy, smoothsteps, vcycles,
+                 coarse_mats):
+        self.J = hierarchy.J
+        self.smoothsteps, self.vcycles = smoothsteps, vcycles
+        self.has_m = mat_m is not None
+        # Galerkin hierarchies, coarse to fine (reference multigrid.py:142-145)
+        A = [sp.csr_matrix(mat_a)]
+        Mm = [sp.csr_matrix(mat_m)] if self.has_m else None
+        for j in reversed(range(self.J)):
+            R, P = hierarchy.R_mats[j], hierarchy.P_mats[j]
+            A.insert(0, sp.csr_matrix(R @ A[0] @ P))
+            if self.has_m:
+                Mm.insert(0, sp.csr_matrix(R @ Mm[0] @ P))
+        self.mats_a, self.mats_m = A, Mm
+        self.shape = A[-1].shape
+        self._keep = []  # device tensors / host arrays the plan points into
+        self.levels = (_lib.MGLevel * (self.J + 1))()
+        for j in range(self.J + 1):
+            self._fill_level(j, hierarchy)
+        inv = np.stack([np.linalg.inv(np.asarray(m.todense()))
+                        for m in coarse_mats(A[0], Mm[0] if Mm else None)])
+        self.coarse_inv = _lib.to_dev(np.ascontiguousarray(inv))
+        self.n_kinds = inv.shape[0]
+        self.plan = None
+        self.plan_ld = 0
+
+    def _fill_level(self, j, hierarchy):
+        L = self.levels[j]
+        mats = [self.mats_a[j]] + ([self.mats_m[j]] if self.has_m else [])
+        indptr, indices, vals = union_pattern(mats)
+        n = len(indptr) - 1
+        rows_of = np.repeat(np.arange(n), np.diff(indptr))
+        diag = np.full(n, -1, dtype=np.int64)
+        on_diag = np.flatnonzero(indices == rows_of)
+        diag[rows_of[on_diag]] = on_diag
+        assert (diag >= 0).all(), 'matrix lacks a diagonal entry'
+        dev = {
+            'indptr': _lib.to_dev(indptr),
+            'indices': _lib.to_dev(indices),
+            'vals_a': _lib.to_dev(vals[0]),
+            'diag': _lib.to_dev(diag.astype(np.int32)),
+        }
+        if self.has_m:
+            dev['vals_m'] = _lib.to_dev(vals[1])
+        L.n = n
+        host = {}
+        if j > 0:
+            for name, bw in (('fwd', False), ('bwd', True)):
+                ptr, rows = gauss_seidel_schedule(indptr, indices, bw)
+                host[name + '_ptr'] = ptr
+                dev[name + '_rows'] = _lib.to_dev(rows)
+                setattr(L, 'n_' + name, len(ptr) - 1)
+                setattr(L, name + '_ptr_host',
+                        ptr.ctypes.data_as(ctypes.c_void_p))
+            P = sp.csr_matrix(hierarchy.P_mats[j - 1])
+            R = sp.csr_matrix(hierarchy.R_mats[j - 1])
+            for name, m in (('p', P), ('r', R)):
+                m.sort_indices()
+                dev[name + '_indptr'] = _lib.to_dev(m.indptr.astype(np.int32))
+                dev[name + '_indices'] = _lib.to_dev(
+                    m.indices.astype(np.int32))
+                dev[name + '_vals'] = _lib.to_dev(m.data.astype(np.float64))
+        for name, t in dev.items():
+            setattr(L, name, _lib.ptr(t))
+        self._keep.append((dev, host))
+        if j == self.J:
+            self.groups_fwd = len(host['fwd_ptr']) - 1 if j > 0 else 0
+
+    def ensure_plan(self, ld):
+        if self.plan is not None and ld <= self.plan_ld:
+            return self.plan
+        if self.plan is not None:
+            _lib.check(_lib.lib().stk_mg_destroy(self.plan))
+        handle = ctypes.c_void_p()
+        _lib.check(_lib.lib().stk_mg_create(
+            self.J + 1, self.levels, self.smoothsteps, self.vcycles,
+            self.n_kinds, _lib.ptr(self.coarse_inv), ld,
+            ctypes.byref(handle)))
+        self.plan, self.plan_ld = handle, ld
+        return self.plan
+
+    def apply(self, x, out, n_loc, ca, cm, kind):
+        ld = x.shape[1]
+        n_loc = ld if n_loc is None else n_loc
+        if out is None:
+            out = torch.empty_like(x)
+        plan = self.ensure_plan(ld)
+        _lib.check(_lib.lib().stk_mg_apply(plan, _lib.stream(), n_loc, ld, ca,
+                                           _lib.ptr(cm), _lib.ptr(kind),
+                                           _lib.ptr(x), _lib.ptr(out)))
+        return out
+
+    def __del__(self):
+        try:
+            if self.plan is not None:
+                _lib.lib().stk_mg_destroy(self.plan)
+        except Exception:
+            pass
+
+
+class MultiGrid(SpaceOp):
+    """`vcycles` V-cycles from a zero initial guess, `smoothsteps` forward
+    Gauss-Seidel sweeps before and backward sweeps after the coarse-grid
+    correction, exact solve on level 0 (reference multigrid.py:130-197)."""
+    family = None
+    member = None
+
+    def __init__(self, mat, hierarchy, smoothsteps=2, vcycles=1):
+        self.num_applies = 0
+        self.time_applies = 0
+        self.hierarchy = hierarchy
+        self.smoothsteps = smoothsteps
+        self.vcycles = vcycles
+        self._dev = _DeviceHierarchy(mat, None, hierarchy, smoothsteps,
+                                     vcycles, lambda a0, m0: [a0])
+        self.mats = self._dev.mats_a
+        self.shape = self.mats[-1].shape
+        self.dtype = np.float64
+
+    def apply(self, x, out=None, n_loc=None, **kw):
+        self.num_applies += 1
+        return self._dev.apply(x, out, n_loc, 1.0, None, None)
+
+    def smooth(self, level, u, f, its, backward, n_loc=None):
+        """`its` Gauss-Seidel sweeps on one level, in place on the slab u
+        (PETScSMoother.PreSmooth / PostSmooth, reference multigrid.py:112-127)."""
+        ld = u.shape[1]
+        n_loc = ld if n_loc is None else n_loc
+        plan = self._dev.ensure_plan(ld)
+        _lib.check(_lib.lib().stk_mg_smooth(plan, _lib.stream(), level, n_loc,
+                                            ld, 1.0, None, its, int(backward),
+                                            _lib.ptr(f), _lib.ptr(u)))
+        return u
+
+
+class MultiGridFamily:
+    """MultiGrid operators for the matrices ca * A + cm_k * M, k = 0..K-1,
+    sharing one device hierarchy.  ``members[k]`` is a MultiGrid for matrix k;
+    BlockDiagMPI recognises members of one family and runs all time slices in
+    one batched V-cycle."""
+    def __init__(self, mat_a, mat_m, hierarchy, ca, cms, smoothsteps=2,
+                 vcycles=1):
+        self.ca = float(ca)
+        self.cms = [float(c) for c in cms]
+        self.hierarchy = hierarchy
+
+        def coarse(a0, m0):
+            # kind 0: A alone (unused by members); kind 1+k: member k
+            return [a0] + [self.ca * a0 + c * m0 for c in self.cms]
+
+        self._dev = _DeviceHierarchy(mat_a, mat_m, hierarchy, smoothsteps,
+                                     vcycles, coarse)
+        self.shape = self._dev.shape
+        self.members = [_FamilyMember(self, k) for k in range(len(self.cms))]
+        self._uniform = {}
+
+    def slice_tables(self, members):
+        """Per-time-slice coefficient and coarse-inverse index for a list of
+        member indices (one per local time slice)."""
+        cm = _lib.to_dev(np.array([self.cms[k] for k in members]))
+        kind = _lib.to_dev(np.array([k + 1 for k in members], dtype=np.int32))
+        return cm, kind
+
+    def apply(self, x, out=None, n_loc=None, cm=None, kind=None):
+        return self._dev.apply(x, out, n_loc, self.ca, cm, kind)
+
+    def apply_member(self, k, x, out=None, n_loc=None):
+        n = x.shape[1] if n_loc is None else n_loc
+        key = (k, n)
+        if key not in self._uniform:
+            self._uniform[key] = self.slice_tables([k] * n)
+        cm, kind = self._uniform[key]
+        return self._dev.apply(x, out, n_loc, self.ca, cm, kind)
+
+
+class _FamilyMember(MultiGrid):
+    def __init__(self, family, k):
+        self.family, self.member = family, k
+        self.hierarchy = family.hierarchy
+        self.shape = family.shape
+        self.dtype = np.float64
+        self.num_applies = 0
+        self.time_applies = 0
+
+    def apply(self, x, out=None, n_loc=None, **kw):
+        self.num_applies += 1
+        return self.family.apply_member(self.member, x, out, n_loc)

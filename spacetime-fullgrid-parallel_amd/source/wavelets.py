@@ -1,0 +1,182 @@
+"""Wavelet-in-time transform (counterpart of reference source/wavelets.py).
+
+W maps 3-point wavelet coordinates to hat-function coordinates in time.  On a
+single rank the whole transform is one fused HIP kernel
+(``stk_wavelet_apply``: all J levels in LDS, one read and one write of the
+vector); across ranks it is the reference's composite of per-level
+``SparseKronIdentityMPI(split(j), add_identity=True)`` factors
+(reference wavelets.py:172-198), whose strided partner exchange runs over
+torch.distributed.
+"""
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from . import _lib
+from .mpi_kron import CompositeMPI, SparseKronIdentityMPI
+from .mpi_vector import KronVectorMPI
+
+
+def _level_matrix(J, j):
+    """I + split(j): the level-j step on the stride-2^(J-j) nodes of the
+    interleaved numbering, as a sparse (2^J+1)^2 matrix.
+    odd k:  y = 1/2 (x[k-1] + x[k+1]) + s x[k];
+    even k: y = x[k] - 1/2 s (x[k-1] + x[k+1]), -s at the two end nodes
+    (reference wavelets.py:81-104, 136-169)."""
+    n = 2**J + 1
+    S, s, nk = 2**(J - j), 2**(j / 2), 2**j
+    rows, cols, vals = [], [], []
+    for k in range(nk + 1):
+        r = k * S
+        if k % 2:
+            rows += [r, r, r]
+            cols += [r - S, r, r + S]
+            vals += [0.5, s, 0.5]
+        else:
+            rows.append(r), cols.append(r), vals.append(1.0)
+            for nb in (k - 1, k + 1):
+                if 0 <= nb <= nk:
+                    end = k == 0 or k == nk
+                    rows.append(r), cols.append(nb * S)
+                    vals.append(-s if end else -0.5 * s)
+    other = np.setdiff1d(np.arange(n), np.arange(0, n, S))
+    rows += list(other)
+    cols += list(other)
+    vals += [1.0] * len(other)
+    return sp.csr_matrix((vals, (rows, cols)), shape=(n, n))
+
+
+class WaveletTransformOp(sp.linalg.LinearOperator):
+    """Matrix-free W_t, applied on the device (reference wavelets.py:45-169).
+
+    interleaved=False: wavelets ordered level by level [d_0, d_1, ..., d_J];
+    interleaved=True: numbered by their node on the finest mesh."""
+    def __init__(self, J, interleaved=False):
+        super().__init__(dtype=np.float64, shape=(2**J + 1, 2**J + 1))
+        self.J = J
+        self.interleaved = interleaved
+        n = 2**J + 1
+        lv = np.zeros(n, dtype=int)
+        for j in reversed(range(0, J + 1)):
+            lv[::2**(J - j)] = j
+        if interleaved:
+            self.levels = lv
+            self._pos = None
+        else:
+            # position in the interleaved numbering of the k-th level-ordered
+            # wavelet: level 0 -> the two end nodes, level j -> odd multiples
+            # of 2^(J-j)
+            pos = [0, n - 1]
+            for j in range(1, J + 1):
+                S = 2**(J - j)
+                pos += [(2 * m + 1) * S for m in range(2**(j - 1))]
+            self._pos = np.array(pos)
+            self.levels = [int(lv[p]) for p in pos]
+
+    def _device_apply(self, X, transposed):
+        X = np.asarray(X, dtype=np.float64)
+        n = self.shape[0]
+        X2 = X.reshape(n, -1)
+        x = _lib.to_dev(np.ascontiguousarray(X2.T))  # (k, n): time contiguous
+        y = torch.empty_like(x)
+        _lib.check(_lib.lib().stk_wavelet_apply(_lib.stream(), x.shape[0],
+                                                self.J, n, int(transposed),
+                                                _lib.ptr(x), _lib.ptr(y)))
+        return y.cpu().numpy().T.reshape(X.shape)
+
+    def _matmat(self, X):
+        X = np.asarray(X, dtype=np.float64)
+        if self._pos is not None:
+            Xi = np.empty_like(X)
+            Xi[self._pos] = X
+            X = Xi
+        return self._device_apply(X, False)
+
+    def _rmatmat(self, X):
+        Y = self._device_apply(X, True)
+        if self._pos is not None:
+            Y = Y[self._pos]
+        return Y
+
+    def _matvec(self, x):
+        return self._matmat(np.asarray(x).reshape(-1, 1)).reshape(-1)
+
+    def _rmatvec(self, x):
+        return self._rmatmat(np.asarray(x).reshape(-1, 1)).reshape(-1)
+
+    def split(self, j):
+        """The level-j step minus the identity, [p(j) q(j)] - I on the level-j
+        nodes, such that W = prod_j (I + split(j)) (reference
+        wavelets.py:136-169)."""
+        n = 2**self.J + 1
+        if j == 0:
+            return sp.csr_matrix((n, n))
+        S = 2**(self.J - j)
+        full = _level_matrix(self.J, j) - sp.identity(n, format='csr')
+        # keep the explicit -1 + 1 = 0 free structure of the reference: entries
+        # only on the level-j nodes, including the (zero-sum) diagonal there
+        full = sp.csr_matrix(full)
+        keep = np.zeros(n, dtype=bool)
+        keep[::S] = True
+        coo = full.tocoo()
+        m = keep[coo.row]
+        out = sp.csr_matrix((coo.data[m], (coo.row[m], coo.col[m])),
+                            shape=(n, n))
+        return out
+
+
+class _FusedWavelet:
+    def __init__(self, J, transposed):
+        self.J, self.transposed = J, transposed
+
+    def apply(self, vec_in, vec_out):
+        _lib.check(_lib.lib().stk_wavelet_apply(
+            _lib.stream(), vec_in.M, self.J, vec_in.ld, int(self.transposed),
+            _lib.ptr(vec_in.buf), _lib.ptr(vec_out.buf)))
+
+
+class WaveletTransformKronIdentityMPI(CompositeMPI):
+    """W := W_t kron Id_x (reference wavelets.py:172-183)."""
+    def __init__(self, dofs_distr, J):
+        wavelet_transform = WaveletTransformOp(J, interleaved=True)
+        self.levels = wavelet_transform.levels
+        linops = []
+        for j in reversed(range(1, J + 1)):
+            split_mat = wavelet_transform.split(j)
+            linops.append(
+                SparseKronIdentityMPI(dofs_distr, split_mat,
+                                      add_identity=True))
+        super().__init__(dofs_distr, linops)
+        self._fused = _FusedWavelet(J, False) if dofs_distr.size == 1 else None
+
+    def _matvec(self, vec_in, vec_out):
+        if self._fused is None:
+            return super()._matvec(vec_in, vec_out)
+        self.time_communication = 0
+        self._fused.apply(vec_in, vec_out)
+        vec_out.communicated_bdr = False
+        return vec_out
+
+
+class TransposedWaveletTransformKronIdentityMPI(CompositeMPI):
+    """W.T := W_t.T kron Id_x (reference wavelets.py:186-198)."""
+    def __init__(self, dofs_distr, J):
+        wavelet_transform = WaveletTransformOp(J, interleaved=True)
+        self.levels = wavelet_transform.levels
+        linops = []
+        for j in range(1, J + 1):
+            split_mat = wavelet_transform.split(j)
+            linops.append(
+                SparseKronIdentityMPI(dofs_distr,
+                                      split_mat.T.tocsr(),
+                                      add_identity=True))
+        super().__init__(dofs_distr, linops)
+        self._fused = _FusedWavelet(J, True) if dofs_distr.size == 1 else None
+
+    def _matvec(self, vec_in, vec_out):
+        if self._fused is None:
+            return super()._matvec(vec_in, vec_out)
+        self.time_communication = 0
+        self._fused.apply(vec_in, vec_out)
+        vec_out.communicated_bdr = False
+        return vec_out
