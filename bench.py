@@ -160,7 +160,7 @@ def main():
         return
     achieved = my_bytes / (dev_ms * 1e-3) / 1e9
     out = {
-        'metric': 'Kronecker-matvec GB/s (algorithmic bytes; % of 8 TB/s HBM '
+        'metric': 'Kronecker-matvec GB/s (algorithmic bytes; share of 8 TB/s HBM '
                   'peak in roofline.frac) + PCG iters/s, J_time=%d J_space=%d %s'
                   % (args.J_time, args.J_space, args.problem),
         'value': value,
