@@ -43,6 +43,9 @@ const char *stk_last_error(void);
 int stk_version(void);
 /* Device properties the host side sizes launches with (CUs, wavefront). */
 int stk_device_info(int32_t *n_cu, int32_t *wave_size, int64_t *hbm_bytes);
+/* Launch-geometry knobs for benchmarking sweeps ("kron_block": 0 = automatic,
+ * or 256 / 512 / 1024 threads per workgroup).  Results never depend on them. */
+int stk_set_tuning(const char *key, int32_t value);
 
 /* ---- BLAS-1 on flat arrays (KronVectorMPI arithmetic, mpi_vector.py:84-122,
  *      and dot, mpi_vector.py:205-210, local part) -------------------------- */
@@ -78,10 +81,42 @@ typedef struct {
     const double *x_hi; /* ghost time row t = n_loc (length M) or NULL */
 } stk_kron_term;
 
+/* CSR row `pos` produces output row row_ids[pos] (row_ids == NULL: pos itself).
+ * The host lists the rows in the order it wants them processed (a mesh-tile or
+ * RCM order keeps the gathers of one XCD inside its L2); the result does not
+ * depend on that order.  Requires ld even and 16-byte aligned x, y. */
 int stk_kron_sum_apply(void *stream, int32_t M, int32_t n_loc, int32_t ld,
                        const int32_t *indptr, const int32_t *indices,
-                       int32_t n_terms, const stk_kron_term *terms_host,
-                       double beta, double *y);
+                       const int32_t *row_ids, int32_t n_terms,
+                       const stk_kron_term *terms_host, double beta,
+                       double *y);
+
+/* The same operator on a sliced-ELL copy of the pattern, the fast path.
+ * Every row owns K slots (K <= 16): ell_idx[pos*K + e] / ell_vals[pos*K + e];
+ * unused slots hold the row's own column and the value 0.  Rows are listed in
+ * processing order, row pos writes output row row_ids[pos].  Entries beyond K
+ * of longer rows are kept in an overflow CSR indexed by pos (NULL if none). */
+typedef struct {
+    int32_t M, K;
+    const int32_t *ell_idx;     /* M*K */
+    const int32_t *row_ids;     /* M or NULL */
+    const int32_t *ovf_indptr;  /* M+1 or NULL */
+    const int32_t *ovf_indices;
+} stk_ell_pattern;
+
+typedef struct {
+    const double *tri;      /* as in stk_kron_term */
+    const double *ell_vals; /* M*K values of X_k */
+    const double *ovf_vals; /* overflow values or NULL */
+    const double *x, *x_lo, *x_hi;
+} stk_kron_ell_term;
+
+/* Tuning key (stk_set_tuning): "ell_wg_per_cu" (persistent workgroups per CU,
+ * 0 = default).  K must be one of 5, 7, 9, 12, 16; at most 3 terms. */
+int stk_kron_ell_apply(void *stream, const stk_ell_pattern *pattern_host,
+                       int32_t n_loc, int32_t ld, int32_t n_terms,
+                       const stk_kron_ell_term *terms_host, double beta,
+                       double *y);
 
 /* ---- (I_t kron A) for a general, possibly rectangular CSR A ---------------
  * y = alpha * A x + beta * z  on `rows` x n_loc outputs (IdentityKronMatMPI,

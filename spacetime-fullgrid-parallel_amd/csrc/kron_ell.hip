@@ -1,0 +1,419 @@
+// Kronecker-sum apply, ELL form:  y = beta*y + sum_k (T_k kron X_k) x_k.
+//
+// Same operator as stk_kron_sum_apply (reference source/mpi_kron.py:77-90,
+// 186-201, 214-219) on a sliced-ELL copy of the shared sparsity pattern:
+// every row owns K entry slots (short rows are padded with a zero value and
+// their own column), rows are listed in the order they are processed, and
+// entries beyond K of very long rows live in an overflow CSR.
+//
+// The kernel is persistent: a workgroup walks a strided sequence of row groups
+// (R rows each, one lane per pair of time steps).  While it gathers and reduces
+// group g it already has the ELL entries of its next group in flight (register
+// prefetch), so the only memory round trip on the critical path of a group is
+// the gather of the x time columns themselves, and all K gathers of a lane are
+// issued back to back.  K is a compile-time constant, so the inner loops carry
+// no branches.  Workgroups that share an XCD (blockIdx % 8) take interleaved
+// groups of one contiguous chunk of the row order, which keeps their gathers
+// in that XCD's L2.  HBM-bound by design: x, y and the matrix arrays are each
+// read or written once.
+#include <cstring>
+
+#include "stk_common.h"
+
+namespace {
+
+constexpr int BS = 512;
+
+template <int NT>
+struct EllArgs {
+    const int32_t *ell_idx;     // [M][K] column of every slot
+    const int32_t *row_ids;     // output row of ELL row pos (NULL: identity)
+    const int32_t *ovf_indptr;  // overflow CSR (NULL: none)
+    const int32_t *ovf_indices;
+    const double *ell_vals[NT];  // [M][K]
+    const double *ovf_vals[NT];
+    const double *tri[NT];
+    const double *x[NT];
+    const double *lo[NT];
+    const double *hi[NT];
+    double *y;
+    double beta;
+    int32_t M, n_loc, ld;
+    int32_t has_lo, has_hi, any_tri;
+    int32_t P, W, R;
+    int32_t ngroups, chunk;  // groups in total / per XCD
+};
+
+// K: slots per row (compile time).  NPF: ELL elements each thread prefetches
+// per array and group, NPF * BS >= R * K.
+template <int NT, bool SHARED_IN, int K, int NPF>
+__global__ __launch_bounds__(BS) void kron_ell_kernel(const EllArgs<NT> a)
+{
+    constexpr int KS = (K + 3) & ~3;  // LDS stride of a row's slots (16-byte vectors)
+    extern __shared__ double sm[];
+    const int W = a.W, R = a.R, SW = a.n_loc + 3;
+    double *s_w = sm;                                                    // [NT][R][SW]
+    double *s_val = s_w + (a.any_tri ? NT * R * SW : 0);                 // [NT][R][KS]
+    uint32_t *s_off = reinterpret_cast<uint32_t *>(s_val + NT * R * KS); // [R][KS] column * ld
+    int32_t *s_idx = reinterpret_cast<int32_t *>(s_off + R * KS);        // [R][KS] ghost lanes only
+    uint32_t *s_row = reinterpret_cast<uint32_t *>(s_idx + R * KS);      // [R] output row * ld
+    // time-stencil coefficients [NT][3][LT], staged once (16-byte aligned rows)
+    const int LT = (a.n_loc + 2) & ~1;
+    double *s_tri = reinterpret_cast<double *>(s_row + ((R + 3) & ~3));
+
+    const int tid = threadIdx.x;
+    const int r = tid / W;
+    const int l = tid - r * W;
+    const int p = l - a.has_lo;  // pair index; < 0: lo ghost lane, >= P: hi ghost lane
+    const bool is_pair = (p >= 0) && (p < a.P) && (r < R);
+    const bool is_ghost = (r < R) && !is_pair;
+    const int t0 = 2 * p;
+    const bool has1 = t0 + 1 < a.n_loc;
+    const bool ghosts = a.has_lo || a.has_hi;
+
+    if (a.any_tri) {
+        for (int i = threadIdx.x; i < NT * 3 * LT; i += BS) {
+            const int k = i / (3 * LT), rem = i - k * 3 * LT;
+            const int d = rem / LT, t = rem - d * LT;
+            s_tri[i] = (a.tri[k] != nullptr && t < a.n_loc) ? a.tri[k][d * a.n_loc + t] : 0.0;
+        }
+    }
+
+    // staging role: element i of the group's flat [rows][K] chunk -> LDS [row][KS]
+    int st_lds[NPF];
+#pragma unroll
+    for (int q = 0; q < NPF; ++q) {
+        const int i = tid + q * BS;
+        st_lds[q] = (i / K) * KS + (i % K);
+    }
+
+    // groups of this workgroup: interleaved with the other workgroups of its XCD
+    const int xcd = blockIdx.x & 7;
+    const int step = gridDim.x >> 3;
+    const int gend = min((xcd + 1) * a.chunk, a.ngroups);
+    int g = xcd * a.chunk + (int)(blockIdx.x >> 3);
+
+    int32_t pidx[NPF];
+    double pval[NT][NPF];
+    int32_t prow = 0;
+#pragma unroll
+    for (int q = 0; q < NPF; ++q) {
+        pidx[q] = 0;
+#pragma unroll
+        for (int k = 0; k < NT; ++k) pval[k][q] = 0.0;
+    }
+    if (g < gend) {
+        const int rows = min(R, a.M - g * R);
+        const size_t base = (size_t)g * R * K;
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) {
+            const int i = tid + q * BS;
+            if (i < rows * K) {
+                pidx[q] = a.ell_idx[base + i];
+#pragma unroll
+                for (int k = 0; k < NT; ++k) pval[k][q] = a.ell_vals[k][base + i];
+            }
+        }
+        if (tid < rows) prow = a.row_ids ? a.row_ids[g * R + tid] : g * R + tid;
+    }
+
+    for (; g < gend; g += step) {
+        const int rows = min(R, a.M - g * R);
+        // ---- publish this group's ELL entries -------------------------------
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) {
+            const int i = tid + q * BS;
+            if (i < rows * K) {
+                s_off[st_lds[q]] = (uint32_t)pidx[q] * (uint32_t)a.ld;
+                if (ghosts) s_idx[st_lds[q]] = pidx[q];
+#pragma unroll
+                for (int k = 0; k < NT; ++k) s_val[k * R * KS + st_lds[q]] = pval[k][q];
+            }
+        }
+        if (tid < rows) s_row[tid] = (uint32_t)prow * (uint32_t)a.ld;
+        __syncthreads();
+
+        // ---- prefetch the next group (in flight behind the gathers) ----------
+        {
+            const int gn = g + step;
+            if (gn < gend) {
+                const int nrows = min(R, a.M - gn * R);
+                const size_t base = (size_t)gn * R * K;
+#pragma unroll
+                for (int q = 0; q < NPF; ++q) {
+                    const int i = tid + q * BS;
+                    if (i < nrows * K) {
+                        pidx[q] = a.ell_idx[base + i];
+#pragma unroll
+                        for (int k = 0; k < NT; ++k) pval[k][q] = a.ell_vals[k][base + i];
+                    }
+                }
+                if (tid < nrows) prow = a.row_ids ? a.row_ids[gn * R + tid] : gn * R + tid;
+            }
+        }
+
+        const bool rowok = r < rows;
+        const int pos = g * R + r;
+        double acc0[NT], acc1[NT];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) acc0[k] = acc1[k] = 0.0;
+
+        if (rowok && is_pair) {
+            const uint32_t *so = s_off + r * KS;
+            uint32_t off[K];
+#pragma unroll
+            for (int u = 0; u < K; ++u) off[u] = so[u];
+            if (SHARED_IN) {
+                const double *xb = a.x[0] + t0;
+                double2 xv[K];
+#pragma unroll
+                for (int u = 0; u < K; ++u) xv[u] = *reinterpret_cast<const double2 *>(xb + off[u]);
+#pragma unroll
+                for (int k = 0; k < NT; ++k) {
+                    const double *sv = s_val + (k * R + r) * KS;
+#pragma unroll
+                    for (int u = 0; u < K; ++u) {
+                        const double v = sv[u];
+                        acc0[k] = fma(v, xv[u].x, acc0[k]);
+                        acc1[k] = fma(v, xv[u].y, acc1[k]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NT; ++k) {
+                    const double *xb = a.x[k] + t0;
+                    const double *sv = s_val + (k * R + r) * KS;
+                    double2 xv[K];
+#pragma unroll
+                    for (int u = 0; u < K; ++u) xv[u] = *reinterpret_cast<const double2 *>(xb + off[u]);
+#pragma unroll
+                    for (int u = 0; u < K; ++u) {
+                        const double v = sv[u];
+                        acc0[k] = fma(v, xv[u].x, acc0[k]);
+                        acc1[k] = fma(v, xv[u].y, acc1[k]);
+                    }
+                }
+            }
+            if (a.ovf_indptr != nullptr) {  // entries beyond K of very long rows
+                for (int e = a.ovf_indptr[pos]; e < a.ovf_indptr[pos + 1]; ++e) {
+                    const size_t o = (size_t)a.ovf_indices[e] * a.ld + t0;
+#pragma unroll
+                    for (int k = 0; k < NT; ++k) {
+                        const double2 xv = *reinterpret_cast<const double2 *>(a.x[k] + o);
+                        const double v = a.ovf_vals[k][e];
+                        acc0[k] = fma(v, xv.x, acc0[k]);
+                        acc1[k] = fma(v, xv.y, acc1[k]);
+                    }
+                }
+            }
+        } else if (rowok && is_ghost) {
+            // ghost lane: one value of the neighbour rank's boundary time row
+            const int32_t *si = s_idx + r * KS;
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                const double *gp = (p < 0) ? a.lo[k] : a.hi[k];
+                if (gp == nullptr) continue;
+                const double *sv = s_val + (k * R + r) * KS;
+                double gv[K];
+#pragma unroll
+                for (int u = 0; u < K; ++u) gv[u] = gp[si[u]];
+#pragma unroll
+                for (int u = 0; u < K; ++u) acc0[k] = fma(sv[u], gv[u], acc0[k]);
+                if (a.ovf_indptr != nullptr)
+                    for (int e = a.ovf_indptr[pos]; e < a.ovf_indptr[pos + 1]; ++e)
+                        acc0[k] = fma(a.ovf_vals[k][e], gp[a.ovf_indices[e]], acc0[k]);
+            }
+        }
+
+        // ---- time stencil through LDS, store ---------------------------------
+        double y0 = 0.0, y1 = 0.0;
+        if (a.any_tri) {
+            // s_w[k][r][q]: q = t + 1; q = 0 is the lo ghost, q = n_loc + 1 the hi ghost
+            if (rowok) {
+#pragma unroll
+                for (int k = 0; k < NT; ++k) {
+                    double *w = s_w + (k * R + r) * SW;
+                    if (is_pair) {
+                        w[t0 + 1] = acc0[k];
+                        if (has1) w[t0 + 2] = acc1[k];
+                    } else {
+                        w[p < 0 ? 0 : a.n_loc + 1] = acc0[k];
+                    }
+                }
+            }
+            __syncthreads();
+            if (rowok && is_pair) {
+#pragma unroll
+                for (int k = 0; k < NT; ++k) {
+                    if (a.tri[k] != nullptr) {
+                        const double *w = s_w + (k * R + r) * SW + t0 + 1;  // w[0]: value at t0
+                        const double *c = s_tri + k * 3 * LT + t0;
+                        const double2 sub = *reinterpret_cast<const double2 *>(c);
+                        const double2 dia = *reinterpret_cast<const double2 *>(c + LT);
+                        const double2 sup = *reinterpret_cast<const double2 *>(c + 2 * LT);
+                        double v0 = dia.x * acc0[k];
+                        if (t0 > 0 || a.has_lo) v0 = fma(sub.x, w[-1], v0);
+                        if (has1 || a.has_hi) v0 = fma(sup.x, has1 ? acc1[k] : w[1], v0);
+                        y0 += v0;
+                        if (has1) {
+                            double v1 = dia.y * acc1[k];
+                            v1 = fma(sub.y, acc0[k], v1);
+                            if (t0 + 2 < a.n_loc || a.has_hi) v1 = fma(sup.y, w[2], v1);
+                            y1 += v1;
+                        }
+                    } else {
+                        y0 += acc0[k];
+                        y1 += acc1[k];
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                y0 += acc0[k];
+                y1 += acc1[k];
+            }
+            __syncthreads();  // the LDS entries are rewritten at the top of the loop
+        }
+        if (rowok && is_pair) {
+            if (!has1) y1 = 0.0;  // padding slot stays zero
+            double2 *yp = reinterpret_cast<double2 *>(a.y + s_row[r] + t0);
+            if (a.beta != 0.0) {
+                const double2 old = *yp;
+                y0 = fma(a.beta, old.x, y0);
+                if (has1) y1 = fma(a.beta, old.y, y1);
+            }
+            *yp = make_double2(y0, y1);
+        }
+    }
+}
+
+int g_ell_wg_per_cu = 0;
+
+template <int NT, bool SHARED_IN, int K>
+int launch3(hipStream_t st, const EllArgs<NT> &a, unsigned grid, size_t lds)
+{
+    const int npf = (a.R * K + BS - 1) / BS;
+    if (npf <= 1)
+        hipLaunchKernelGGL((kron_ell_kernel<NT, SHARED_IN, K, 1>), dim3(grid), dim3(BS), lds, st, a);
+    else if (npf <= 2)
+        hipLaunchKernelGGL((kron_ell_kernel<NT, SHARED_IN, K, 2>), dim3(grid), dim3(BS), lds, st, a);
+    else if (npf <= 4)
+        hipLaunchKernelGGL((kron_ell_kernel<NT, SHARED_IN, K, 4>), dim3(grid), dim3(BS), lds, st, a);
+    else {
+        stk_set_error("stk_kron_ell_apply: %d slots per row with %d lanes per row not supported", K, a.W);
+        return 2;
+    }
+    STK_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int NT, bool SHARED_IN>
+int launch2(hipStream_t st, const EllArgs<NT> &a_in, int K)
+{
+    EllArgs<NT> a = a_in;
+    a.R = BS / a.W;
+    a.ngroups = (a.M + a.R - 1) / a.R;
+    a.chunk = (a.ngroups + 7) / 8;
+    const int KS = (K + 3) & ~3;
+    const size_t lds = sizeof(double) * ((a.any_tri ? (size_t)NT * a.R * (a.n_loc + 3) : 0) +
+                                          (size_t)NT * a.R * KS) +
+                       sizeof(int32_t) * (2 * (size_t)a.R * KS + a.R + 4) +
+                       sizeof(double) * (size_t)NT * 3 * (a.n_loc + 2) + 32;
+    int n_cu = 256;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            n_cu = prop.multiProcessorCount;
+    }
+    int per_cu = g_ell_wg_per_cu > 0 ? g_ell_wg_per_cu : 2;
+    const int by_lds = (int)(160 * 1024 / (lds + 256));
+    if (per_cu > by_lds) per_cu = by_lds > 0 ? by_lds : 1;
+    int per_xcd = (n_cu / 8) * per_cu;
+    if (per_xcd > a.chunk) per_xcd = a.chunk;
+    if (per_xcd < 1) per_xcd = 1;
+    const unsigned grid = (unsigned)per_xcd * 8;
+    switch (K) {
+        case 5: return launch3<NT, SHARED_IN, 5>(st, a, grid, lds);
+        case 7: return launch3<NT, SHARED_IN, 7>(st, a, grid, lds);
+        case 9: return launch3<NT, SHARED_IN, 9>(st, a, grid, lds);
+        case 12: return launch3<NT, SHARED_IN, 12>(st, a, grid, lds);
+        case 16: return launch3<NT, SHARED_IN, 16>(st, a, grid, lds);
+    }
+    stk_set_error("stk_kron_ell_apply: K=%d is not one of 5, 7, 9, 12, 16", K);
+    return 2;
+}
+
+template <int NT>
+int dispatch(hipStream_t st, const stk_ell_pattern *pat, int32_t n_loc, int32_t ld, const stk_kron_ell_term *t,
+             double beta, double *y)
+{
+    EllArgs<NT> a;
+    a.ell_idx = pat->ell_idx;
+    a.row_ids = pat->row_ids;
+    a.ovf_indptr = pat->ovf_indptr;
+    a.ovf_indices = pat->ovf_indices;
+    a.y = y;
+    a.beta = beta;
+    a.M = pat->M;
+    a.n_loc = n_loc;
+    a.ld = ld;
+    a.has_lo = a.has_hi = a.any_tri = 0;
+    bool shared = true;
+    for (int k = 0; k < NT; ++k) {
+        a.ell_vals[k] = t[k].ell_vals;
+        a.ovf_vals[k] = t[k].ovf_vals;
+        a.tri[k] = t[k].tri;
+        a.x[k] = t[k].x;
+        a.lo[k] = t[k].x_lo;
+        a.hi[k] = t[k].x_hi;
+        if (t[k].x_lo) a.has_lo = 1;
+        if (t[k].x_hi) a.has_hi = 1;
+        if (t[k].tri) a.any_tri = 1;
+        if (t[k].x != t[0].x) shared = false;
+    }
+    a.P = (n_loc + 1) / 2;
+    a.W = a.P + a.has_lo + a.has_hi;
+    return shared ? launch2<NT, true>(st, a, pat->K) : launch2<NT, false>(st, a, pat->K);
+}
+
+}  // namespace
+
+int stk_kron_ell_set_tuning(const char *key, int32_t value)
+{
+    if (std::strcmp(key, "ell_wg_per_cu") == 0) {
+        g_ell_wg_per_cu = value;
+        return 0;
+    }
+    return 1;
+}
+
+extern "C" int stk_kron_ell_apply(void *stream, const stk_ell_pattern *pat, int32_t n_loc, int32_t ld,
+                                  int32_t n_terms, const stk_kron_ell_term *t, double beta, double *y)
+{
+    STK_REQUIRE(pat && t && y, "stk_kron_ell_apply: null pointer");
+    STK_REQUIRE(pat->M > 0 && pat->K >= 1, "stk_kron_ell_apply: bad pattern M=%d K=%d", pat->M, pat->K);
+    STK_REQUIRE(pat->ell_idx, "stk_kron_ell_apply: pattern has no ell_idx");
+    STK_REQUIRE((pat->ovf_indptr == nullptr) == (pat->ovf_indices == nullptr),
+                "stk_kron_ell_apply: overflow arrays go together");
+    STK_REQUIRE(n_loc > 0 && ld >= n_loc && (ld & 1) == 0,
+                "stk_kron_ell_apply: bad sizes n_loc=%d ld=%d (ld must be even)", n_loc, ld);
+    STK_REQUIRE(n_terms >= 1 && n_terms <= 3, "stk_kron_ell_apply: n_terms=%d not in 1..3", n_terms);
+    STK_REQUIRE((n_loc + 1) / 2 + 2 <= BS, "stk_kron_ell_apply: n_loc=%d too large", n_loc);
+    STK_REQUIRE((int64_t)pat->M * ld < ((int64_t)1 << 32), "stk_kron_ell_apply: M*ld exceeds 32-bit offsets");
+    STK_REQUIRE(((uintptr_t)y & 15) == 0, "stk_kron_ell_apply: y must be 16-byte aligned");
+    for (int k = 0; k < n_terms; ++k) {
+        STK_REQUIRE(t[k].ell_vals && t[k].x, "stk_kron_ell_apply: term %d has null vals/x", k);
+        STK_REQUIRE(t[k].x != y, "stk_kron_ell_apply: input aliases output");
+        STK_REQUIRE(((uintptr_t)t[k].x & 15) == 0, "stk_kron_ell_apply: x must be 16-byte aligned");
+        STK_REQUIRE(pat->ovf_indptr == nullptr || t[k].ovf_vals, "stk_kron_ell_apply: term %d lacks ovf_vals",
+                    k);
+    }
+    hipStream_t st = stk_stream(stream);
+    switch (n_terms) {
+        case 1: return dispatch<1>(st, pat, n_loc, ld, t, beta, y);
+        case 2: return dispatch<2>(st, pat, n_loc, ld, t, beta, y);
+        default: return dispatch<3>(st, pat, n_loc, ld, t, beta, y);
+    }
+}

@@ -43,19 +43,24 @@ __global__ __launch_bounds__(GBS) void gs_group_kernel(int64_t total, const int3
         const int i = rows[q];
         const int e0 = indptr[i], e1 = indptr[i + 1];
         const double *ut = u + t;
-        double ax = 0.0, d;
-        if (vm != nullptr) {
-            const double c = cm[t];
-#pragma unroll 4
-            for (int e = e0; e < e1; ++e)
-                ax = fma(fma(c, vm[e], ca * va[e]), ut[(size_t)indices[e] * ld], ax);
-            const int ed = diag[i];
-            d = fma(c, vm[ed], ca * va[ed]);
-        } else {
-#pragma unroll 4
-            for (int e = e0; e < e1; ++e) ax = fma(ca * va[e], ut[(size_t)indices[e] * ld], ax);
-            d = ca * va[diag[i]];
+        const double c = (vm != nullptr) ? cm[t] : 0.0;
+        double ax = 0.0;
+        // batches of independent gathers (clamped past the row end), summed in
+        // CSR order like the sequential sweep
+        for (int eb = e0; eb < e1; eb += 8) {
+            double uv[8], av[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int e = min(eb + q, e1 - 1);
+                uv[q] = ut[(size_t)indices[e] * ld];
+                av[q] = (vm != nullptr) ? fma(c, vm[e], ca * va[e]) : ca * va[e];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (eb + q < e1) ax = fma(av[q], uv[q], ax);
         }
+        const int ed = diag[i];
+        const double d = (vm != nullptr) ? fma(c, vm[ed], ca * va[ed]) : ca * va[ed];
         const size_t o = (size_t)i * ld + t;
         u[o] += (1.0 / d) * (f[o] - ax);
     }

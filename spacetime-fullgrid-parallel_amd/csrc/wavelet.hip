@@ -93,6 +93,11 @@ __global__ __launch_bounds__(WBS) void wavelet_kernel(int32_t M, int32_t J, int3
         const int r = k / N, t = k - r * N;
         y[(size_t)(row0 + r) * ld + t] = tile[k];
     }
+    const int npad = ld - N;  // padding columns stay zero
+    for (int k = tid; k < nrows * npad; k += WBS) {
+        const int r = k / npad, t = N + (k - r * npad);
+        y[(size_t)(row0 + r) * ld + t] = 0.0;
+    }
 }
 
 }  // namespace

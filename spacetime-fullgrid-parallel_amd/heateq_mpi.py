@@ -21,7 +21,7 @@ from source.assembly import (prolongation_matrices, space_load,
                              space_matrices, time_matrices)
 from source.comm import MPI
 from source.linalg import PCG
-from source.linop import CompositeLinOp, as_space_op, union_pattern
+from source.linop import CompositeLinOp, EllMatrices, as_space_op
 from source.mpi_kron import (BlockDiagMPI, CompositeMPI, LinearOperatorMPI,
                              MatKronIdentityMPI, SumMPI, TridiagKronMatMPI,
                              _local_tridiag)
@@ -55,24 +55,11 @@ class SchurMPI(LinearOperatorMPI):
     def __init__(self, dofs_distr, A_t, L_t, M_t, G_t, M_x, A_x, Kinv_x):
         super().__init__(dofs_distr)
         self.Kinv_x = as_space_op(Kinv_x)
-        indptr, indices, (vm, va) = union_pattern([M_x, A_x])
-        self.indptr, self.indices = _lib.to_dev(indptr), _lib.to_dev(indices)
-        self.vm, self.va = _lib.to_dev(vm), _lib.to_dev(va)
-        self.nnz = len(indices)
+        self.ell = EllMatrices([M_x, A_x])  # matrix 0 = M_x, 1 = A_x
         tri = lambda T: _lib.to_dev(_local_tridiag(dofs_distr, T))
         self.tA, self.tL, self.tM, self.tG = tri(A_t), tri(L_t), tri(
             M_t), tri(G_t)
         self.tLT = tri(L_t.T.tocsr())
-        self._t2 = (_lib.KronTerm * 2)()
-        self._t3 = (_lib.KronTerm * 3)()
-
-    def _kron(self, terms, specs, n_loc, ld, beta, out):
-        for t, (tri, vals, x, lo, hi) in zip(terms, specs):
-            t.tri, t.vals, t.x = _lib.ptr(tri), _lib.ptr(vals), _lib.ptr(x)
-            t.x_lo, t.x_hi = _lib.ptr(lo), _lib.ptr(hi)
-        _lib.check(_lib.lib().stk_kron_sum_apply(
-            _lib.stream(), self.M, n_loc, ld, _lib.ptr(self.indptr),
-            _lib.ptr(self.indices), len(terms), terms, beta, _lib.ptr(out)))
 
     def _matvec(self, vec_in, vec_out):
         assert (vec_in is not vec_out)
@@ -82,16 +69,15 @@ class SchurMPI(LinearOperatorMPI):
         x, lo, hi = vec_in.buf, vec_in.X_lo, vec_in.X_hi
         n_loc, ld = vec_in.n_loc, vec_in.ld
         u = torch.empty_like(x)
-        self._kron(self._t2, [(self.tA, self.vm, x, lo, hi),
-                              (self.tL, self.va, x, lo, hi)], n_loc, ld, 0.0, u)
+        kron = self.ell.apply
+        kron([(self.tA, 0, x, lo, hi), (self.tL, 1, x, lo, hi)], n_loc, ld,
+             0.0, u)
         v1 = self.Kinv_x.apply(u, n_loc=n_loc)
-        self._kron(self._t2, [(self.tLT, self.vm, x, lo, hi),
-                              (self.tM, self.va, x, lo, hi)], n_loc, ld, 0.0, u)
+        kron([(self.tLT, 0, x, lo, hi), (self.tM, 1, x, lo, hi)], n_loc, ld,
+             0.0, u)
         v2 = self.Kinv_x.apply(u, n_loc=n_loc)
-        self._kron(self._t3, [(None, self.vm, v1, None, None),
-                              (None, self.va, v2, None, None),
-                              (self.tG, self.vm, x, lo, hi)], n_loc, ld, 0.0,
-                   vec_out.buf)
+        kron([(None, 0, v1, None, None), (None, 1, v2, None, None),
+              (self.tG, 0, x, lo, hi)], n_loc, ld, 0.0, vec_out.buf)
         vec_out.communicated_bdr = False
         return vec_out
 

@@ -23,6 +23,16 @@ class KronTerm(ctypes.Structure):
                 ('x_hi', c_p)]
 
 
+class EllPattern(ctypes.Structure):
+    _fields_ = [('M', c_i32), ('K', c_i32), ('ell_idx', c_p),
+                ('row_ids', c_p), ('ovf_indptr', c_p), ('ovf_indices', c_p)]
+
+
+class KronEllTerm(ctypes.Structure):
+    _fields_ = [('tri', c_p), ('ell_vals', c_p), ('ovf_vals', c_p),
+                ('x', c_p), ('x_lo', c_p), ('x_hi', c_p)]
+
+
 class MGLevel(ctypes.Structure):
     _fields_ = [('n', c_i32), ('indptr', c_p), ('indices', c_p),
                 ('vals_a', c_p), ('vals_m', c_p), ('diag', c_p),
@@ -42,9 +52,14 @@ _PROTOTYPES = {
     'stk_dot': (ctypes.c_int, [c_p, c_i64, c_p, c_p, c_p, c_p]),
     'stk_pcg_update': (ctypes.c_int,
                        [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'stk_set_tuning': (ctypes.c_int, [ctypes.c_char_p, c_i32]),
     'stk_kron_sum_apply': (ctypes.c_int, [
-        c_p, c_i32, c_i32, c_i32, c_p, c_p, c_i32,
+        c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_i32,
         ctypes.POINTER(KronTerm), c_f64, c_p
+    ]),
+    'stk_kron_ell_apply': (ctypes.c_int, [
+        c_p, ctypes.POINTER(EllPattern), c_i32, c_i32, c_i32,
+        ctypes.POINTER(KronEllTerm), c_f64, c_p
     ]),
     'stk_csr_spmm': (ctypes.c_int, [
         c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_f64, c_p, c_p, c_p, c_f64,

@@ -82,6 +82,27 @@ def _restrict(mat, fd):
     return _finish(sp.csr_matrix(mat)[fd, :].tocsc()[:, fd].tocsr())
 
 
+def tile_row_order(mesh, rows_per_tile=2048):
+    """A processing order for the free dofs that follows the geometry: the
+    bounding box is cut into square tiles of about `rows_per_tile` vertices,
+    tiles are visited row by row and vertices inside a tile lexicographically.
+    The hierarchical dof numbering scatters the neighbours of a vertex over
+    the whole index range; visiting rows in this order instead keeps the
+    gathers of consecutive workgroups inside the same few hundred KB, i.e. in
+    the L2 of the XCD that runs them.  Purely a performance hint
+    (stk_kron_sum_apply's row_ids); results do not depend on it."""
+    fd = free_dofs(mesh)
+    p = mesh.points[fd]
+    lo, hi = p.min(axis=0), p.max(axis=0)
+    ext = np.maximum(hi - lo, 1e-300)
+    ntiles = max(1.0, len(fd) / float(rows_per_tile))
+    side = np.sqrt(ext[0] * ext[1] / ntiles)
+    tx = np.floor((p[:, 0] - lo[0]) / side).astype(np.int64)
+    ty = np.floor((p[:, 1] - lo[1]) / side).astype(np.int64)
+    order = np.lexsort((p[:, 0], p[:, 1], tx, ty))
+    return order.astype(np.int32)
+
+
 def space_matrices(mesh):
     """Mass M_x and stiffness A_x on the free dofs (heateq_mpi.py:91-96)."""
     area, g = _tri_geometry(mesh)
@@ -99,7 +120,9 @@ def space_matrices(mesh):
     # NGSolve's exactly integrated entries
     A.data[np.abs(A.data) < 1e-14 * np.abs(A.data).max()] = 0.0
     fd = free_dofs(mesh)
-    return _restrict(M, fd), _restrict(A, fd)
+    M, A = _restrict(M, fd), _restrict(A, fd)
+    M.stk_row_order = A.stk_row_order = tile_row_order(mesh)
+    return M, A
 
 
 # Dunavant degree-4 rule (6 points)

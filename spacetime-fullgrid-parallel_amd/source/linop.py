@@ -13,6 +13,7 @@ shape (M, ld) -- all time columns at once -- through ``apply(x, out)``.
 KronLinOp / BlockDiagLinOp are the serial (single-rank, flat NumPy vector in /
 out) operators of reference linop.py:6-15, 29-44, run on the device.
 """
+import ctypes
 import weakref
 
 import numpy as np
@@ -131,6 +132,98 @@ def union_pattern(mats):
         full.data[pos] = m.data
         vals.append(full.data)
     return pat.indptr.astype(np.int32), pat.indices.astype(np.int32), vals
+
+
+def row_order_for(mats, indptr, indices):
+    """Processing order of the rows for the gather kernels: the hint attached
+    by the assembly (`stk_row_order`, a mesh-tile order) if there is one,
+    reverse Cuthill-McKee of the pattern for large anonymous matrices, else
+    None (index order)."""
+    for m in mats:
+        order = getattr(m, 'stk_row_order', None)
+        if order is not None:
+            return np.asarray(order, dtype=np.int32)
+    n = len(indptr) - 1
+    if n < 8192:
+        return None
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    pat = sp.csr_matrix((np.ones(len(indices)), indices, indptr),
+                        shape=(n, int(indices.max()) + 1 if len(indices) else n))
+    if pat.shape[0] != pat.shape[1]:
+        return None
+    return reverse_cuthill_mckee(pat, symmetric_mode=True).astype(np.int32)
+
+
+def permute_rows(indptr, indices, vals, order):
+    """CSR rows listed in `order`: returns (indptr, indices, vals, row_ids)
+    such that CSR row k of the result is row order[k] of the input."""
+    if order is None:
+        return indptr, indices, vals, None
+    counts = np.diff(indptr)[order]
+    new_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    starts = indptr[:-1][order]
+    gather = np.repeat(starts - new_ptr[:-1], counts) + np.arange(new_ptr[-1])
+    return (new_ptr, indices[gather].astype(np.int32),
+            [v[gather] for v in vals], np.asarray(order, dtype=np.int32))
+
+
+class EllMatrices:
+    """Several matrices on one shared pattern in the sliced-ELL form of
+    ``stk_kron_ell_apply`` (include/stk.h), resident on the device: K slots per
+    row, rows in processing order, overflow CSR for rows longer than K."""
+    MAXK = 16
+    SLOTS = (5, 7, 9, 12, 16)  # instantiated in csrc/kron_ell.hip
+
+    def __init__(self, mats, order_hints=()):
+        indptr, indices, vals = union_pattern(mats)
+        order = row_order_for(list(order_hints) + list(mats), indptr, indices)
+        indptr, indices, vals, row_ids = permute_rows(indptr, indices, vals,
+                                                      order)
+        M = len(indptr) - 1
+        counts = np.diff(indptr)
+        kmax = int(counts.max()) if M else 1
+        K = next((k for k in self.SLOTS if k >= kmax), self.MAXK)
+        own = row_ids if row_ids is not None else np.arange(M, dtype=np.int32)
+        pos = np.repeat(np.arange(M), counts)
+        slot = np.arange(len(indices)) - np.repeat(indptr[:-1], counts)
+        main = slot < K
+        ell_idx = np.repeat(own.astype(np.int32)[:, None], K, axis=1)
+        ell_idx[pos[main], slot[main]] = indices[main]
+        ell_vals = []
+        for v in vals:
+            e = np.zeros((M, K))
+            e[pos[main], slot[main]] = v[main]
+            ell_vals.append(e)
+        self.M, self.K = M, K
+        self.nnz = len(indices)
+        self.nnz_terms = [int(sp.csr_matrix(m).nnz) for m in mats]
+        self.ell_idx = _lib.to_dev(ell_idx)
+        self.ell_vals = [_lib.to_dev(e) for e in ell_vals]
+        self.row_ids = None if row_ids is None else _lib.to_dev(row_ids)
+        self.ovf_indptr = self.ovf_indices = None
+        self.ovf_vals = [None] * len(vals)
+        if not main.all():
+            rest = ~main
+            oc = np.bincount(pos[rest], minlength=M)
+            self.ovf_indptr = _lib.to_dev(
+                np.concatenate([[0], np.cumsum(oc)]).astype(np.int32))
+            self.ovf_indices = _lib.to_dev(indices[rest].astype(np.int32))
+            self.ovf_vals = [_lib.to_dev(v[rest]) for v in vals]
+        self.pattern = _lib.EllPattern(M, K, _lib.ptr(self.ell_idx),
+                                       _lib.ptr(self.row_ids),
+                                       _lib.ptr(self.ovf_indptr),
+                                       _lib.ptr(self.ovf_indices))
+
+    def apply(self, specs, n_loc, ld, beta, out):
+        """y = beta*y + sum over specs (tri, matrix index, x, x_lo, x_hi)."""
+        terms = (_lib.KronEllTerm * len(specs))()
+        for t, (tri, k, x, lo, hi) in zip(terms, specs):
+            t.tri, t.ell_vals = _lib.ptr(tri), _lib.ptr(self.ell_vals[k])
+            t.ovf_vals = _lib.ptr(self.ovf_vals[k])
+            t.x, t.x_lo, t.x_hi = _lib.ptr(x), _lib.ptr(lo), _lib.ptr(hi)
+        _lib.check(_lib.lib().stk_kron_ell_apply(
+            _lib.stream(), ctypes.byref(self.pattern), n_loc, ld, len(specs),
+            terms, beta, _lib.ptr(out)))
 
 
 # ----------------------------------------------------------------------------

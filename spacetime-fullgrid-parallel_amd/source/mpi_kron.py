@@ -17,7 +17,8 @@ import torch
 
 from . import _lib
 from .comm import MPI
-from .linop import SpaceMatrix, SpaceOp, as_space_op, union_pattern
+from .linop import (SpaceMatrix, SpaceOp, as_space_op, permute_rows,
+                    row_order_for, union_pattern)
 from .mpi_vector import DofDistributionMPI, KronVectorMPI
 
 
@@ -112,7 +113,7 @@ def _local_tridiag(dofs_distr, mat_time):
 class SumMPI(LinearOperatorMPI):
     """sum_k L_k (reference mpi_kron.py:71-90).  Consecutive
     TridiagKronMatMPI terms whose space factor is a plain matrix are fused
-    into one kernel launch per group of 4."""
+    into one kernel launch per group of 3 (ELL kernel) or 4 (CSR kernel)."""
     def __init__(self, dofs_distr, linops):
         assert all(isinstance(linop, LinearOperatorMPI) for linop in linops)
         self.linops = linops
@@ -124,7 +125,7 @@ class SumMPI(LinearOperatorMPI):
         for op in self.linops:
             if isinstance(op, TridiagKronMatMPI) and op.fusable:
                 run.append(op)
-                if len(run) == 4:
+                if len(run) == _FusedKronSum.max_terms():
                     groups.append(_FusedKronSum(self.dofs_distr, run))
                     run = []
             else:
@@ -238,6 +239,7 @@ class BlockDiagMPI(LinearOperatorMPI):
             fam.apply(t2, out=vec_out.buf, n_loc=n_loc, cm=cm, kind=kind)
         else:
             # general case: one time slice at a time
+            vec_out.buf.zero_()
             for t_loc, linop in enumerate(self._local):
                 col = vec_in.buf[:, t_loc:t_loc + 1].contiguous()
                 res = linop.apply(col, n_loc=1)
@@ -356,39 +358,62 @@ class TridiagKronMatMPI(LinearOperatorMPI):
 
 class _FusedKronSum:
     """y = beta*y + sum_k (T_k kron X_k) x for up to 4 TridiagKronMatMPI terms
-    with plain CSR space factors: shared pattern, one launch."""
+    with plain CSR space factors: shared pattern, one launch.  use_ell selects
+    the persistent sliced-ELL kernel (default) or the plain CSR one."""
+    use_ell = True
+
+    @classmethod
+    def max_terms(cls):
+        return 3 if cls.use_ell else 4
+
     def __init__(self, dofs_distr, ops):
-        assert 1 <= len(ops) <= 4
+        assert 1 <= len(ops) <= self.max_terms()
+        self.use_ell = type(self).use_ell
         self.dofs_distr = dofs_distr
         mats = [op.space_op.mat for op in ops]
-        indptr, indices, vals = union_pattern(mats)
-        self.indptr = _lib.to_dev(indptr)
-        self.indices = _lib.to_dev(indices)
-        self.vals = [_lib.to_dev(v) for v in vals]
-        self.nnz = len(indices)
+        hints = [op.mat_space for op in ops]
+        self.nnz_terms = [int(m.nnz) for m in mats]
         tris = [_local_tridiag(dofs_distr, op.mat_time) for op in ops]
         self.needs_lo = any(t[0, 0] != 0.0 for t in tris)
         self.needs_hi = any(t[2, -1] != 0.0 for t in tris)
         self.tri = [_lib.to_dev(t) for t in tris]
-        self.terms = (_lib.KronTerm * len(ops))()
+        self.n_terms = len(ops)
+        if self.use_ell:
+            from .linop import EllMatrices
+            self.ell = EllMatrices(mats, hints)
+            self.row_ids = self.ell.row_ids
+        else:
+            indptr, indices, vals = union_pattern(mats)
+            order = row_order_for(hints + mats, indptr, indices)
+            indptr, indices, vals, row_ids = permute_rows(
+                indptr, indices, vals, order)
+            self.indptr = _lib.to_dev(indptr)
+            self.indices = _lib.to_dev(indices)
+            self.row_ids = None if row_ids is None else _lib.to_dev(row_ids)
+            self.vals = [_lib.to_dev(v) for v in vals]
+            self.terms = (_lib.KronTerm * len(ops))()
 
     def apply(self, vec_in, vec_out, beta=0.0):
         time_comm = 0.0
         if self.dofs_distr.size > 1:
             time_comm = vec_in.communicate_bdr()
-        lo = _lib.ptr(vec_in.X_lo) if (self.needs_lo
-                                       and vec_in.X_lo is not None) else None
-        hi = _lib.ptr(vec_in.X_hi) if (self.needs_hi
-                                       and vec_in.X_hi is not None) else None
+        lo = vec_in.X_lo if self.needs_lo else None
+        hi = vec_in.X_hi if self.needs_hi else None
+        if self.use_ell:
+            self.ell.apply([(self.tri[k], k, vec_in.buf, lo, hi)
+                            for k in range(self.n_terms)], vec_in.n_loc,
+                           vec_in.ld, beta, vec_out.buf)
+            return time_comm
         x = _lib.ptr(vec_in.buf)
-        for k in range(len(self.terms)):
+        for k in range(self.n_terms):
             t = self.terms[k]
             t.tri, t.vals = _lib.ptr(self.tri[k]), _lib.ptr(self.vals[k])
-            t.x, t.x_lo, t.x_hi = x, lo, hi
+            t.x, t.x_lo, t.x_hi = x, _lib.ptr(lo), _lib.ptr(hi)
         _lib.check(_lib.lib().stk_kron_sum_apply(
             _lib.stream(), vec_in.M, vec_in.n_loc, vec_in.ld,
-            _lib.ptr(self.indptr), _lib.ptr(self.indices), len(self.terms),
-            self.terms, beta, _lib.ptr(vec_out.buf)))
+            _lib.ptr(self.indptr), _lib.ptr(self.indices),
+            _lib.ptr(self.row_ids), self.n_terms, self.terms, beta,
+            _lib.ptr(vec_out.buf)))
         return time_comm
 
     def algorithmic_bytes(self, n_loc, M):
@@ -396,8 +421,8 @@ class _FusedKronSum:
         ghost rows, every CSR array once."""
         h = int(self.needs_lo and self.dofs_distr.rank > 0) + int(
             self.needs_hi and self.dofs_distr.rank + 1 < self.dofs_distr.size)
-        return (16 * n_loc * M + 8 * h * M +
-                (4 + 8 * len(self.vals)) * self.nnz + 4 * (M + 1))
+        return (16 * n_loc * M + 8 * h * M + 12 * sum(self.nnz_terms) +
+                4 * (M + 1) * len(self.nnz_terms))
 
 
 class SparseKronIdentityMPI(LinearOperatorMPI):

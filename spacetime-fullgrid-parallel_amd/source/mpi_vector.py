@@ -78,7 +78,8 @@ class KronVectorMPI:
         self.M = dofs_distr.M
         self.rank = dofs_distr.rank
         self.n_loc = self.t_end - self.t_begin
-        self.ld = self.n_loc
+        # even leading dimension: time pairs are 16-byte aligned (include/stk.h)
+        self.ld = self.n_loc + (self.n_loc & 1)
         self._pending = None
 
         self.reset(initial_data)

@@ -311,9 +311,73 @@ def test_full_size_properties(stk):
 
 def test_abi_error_reporting(stk):
     lib = stk.lib()
-    rc = lib.stk_kron_sum_apply(None, 10, 5, 3, None, None, 1, None, 0.0, None)
+    rc = lib.stk_kron_sum_apply(None, 10, 5, 3, None, None, None, 1, None, 0.0,
+                                None)
     assert rc != 0 and b'bad sizes' in lib.stk_last_error()
     rc = lib.stk_wavelet_apply(None, 10, 3, 4, 0, None, None)
     assert rc != 0 and b'ld' in lib.stk_last_error()
     with pytest.raises(stk.StkError):
         stk.ptr(torch.zeros(3, dtype=torch.float64))  # host tensor refused
+
+
+def test_row_orders_and_formats_do_not_change_results(stk):
+    """Tile order (assembly hint), reverse Cuthill-McKee (anonymous matrix);
+    sliced-ELL and CSR kernels; every workgroup size: same Kronecker apply."""
+    import scipy.sparse as sp
+    from oracle import kron as okron
+    from source import mpi_kron
+    from source.assembly import space_matrices, time_matrices
+    from source.mesh import construct_2d_lshape_mesh, construct_interval
+    from source.mpi_kron import SumMPI, TridiagKronMatMPI
+    mesh, _ = construct_2d_lshape_mesh(5)  # M = 12033 (> RCM threshold)
+    M_x, A_x = space_matrices(mesh)
+    A_t, L_t, M_t, G_t, _ = time_matrices(construct_interval(2**3))
+    N, M = A_t.shape[0], M_x.shape[0]
+    assert M > 8192
+    dd = _dd(N, M)
+    X = np.random.RandomState(3).rand(N, M)
+    x = _vec(dd, X)
+    want = okron.sum_apply([(A_t, M_x), (M_t, A_x), (L_t, A_x)], X)
+    plain = lambda m: sp.csr_matrix(m)  # drops the stk_row_order hint
+    try:
+        for use_ell in (True, False):
+            mpi_kron._FusedKronSum.use_ell = use_ell
+            key = b'ell_wg_per_cu' if use_ell else b'kron_block'
+            for mk in (lambda m: m, plain):
+                for bs in ((0, 1, 3) if use_ell else (0, 256, 512, 1024)):
+                    stk.check(stk.lib().stk_set_tuning(key, bs))
+                    op = SumMPI(dd, [TridiagKronMatMPI(dd, A_t, mk(M_x)),
+                                     TridiagKronMatMPI(dd, M_t, mk(A_x)),
+                                     TridiagKronMatMPI(dd, L_t, mk(A_x))])
+                    assert (op._groups[0].row_ids is not None)
+                    assert relerr(_np(op @ x), want) < TOL
+            stk.check(stk.lib().stk_set_tuning(key, 0))
+    finally:
+        mpi_kron._FusedKronSum.use_ell = True
+    with pytest.raises(stk.StkError):
+        stk.check(stk.lib().stk_set_tuning(b'nonsense', 1))
+
+
+def test_ell_overflow_rows_and_ragged_matrix(stk):
+    """Rows longer than the 16 ELL slots spill into the overflow CSR; empty
+    rows and a dense row must come out right (ragged input)."""
+    import scipy.sparse as sp
+    from oracle import kron as okron
+    from source.mpi_kron import SumMPI, TridiagKronMatMPI
+    rng = np.random.RandomState(11)
+    M, N = 300, 9
+    S = sp.random(M, M, density=0.02, random_state=rng, format='lil')
+    S[5, :] = rng.rand(M)          # dense row -> overflow
+    S[17, :40] = rng.rand(40)      # 40 entries -> overflow
+    S[100, :] = 0.0                # empty row
+    S = sp.csr_matrix(S)
+    S.eliminate_zeros()
+    S2 = sp.csr_matrix(S.multiply(S > 0.5))
+    T = sp.diags([rng.rand(N - 1), rng.rand(N), rng.rand(N - 1)], [-1, 0, 1],
+                 format='csr')
+    dd = _dd(N, M)
+    X = rng.rand(N, M)
+    op = SumMPI(dd, [TridiagKronMatMPI(dd, T, S), TridiagKronMatMPI(dd, T.T.tocsr(), S2)])
+    assert op._groups[0].ell.ovf_indptr is not None
+    want = okron.sum_apply([(T, S), (T.T.tocsr(), S2)], X)
+    assert relerr(_np(op @ _vec(dd, X)), want) < TOL
