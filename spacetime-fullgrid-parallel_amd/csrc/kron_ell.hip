@@ -24,6 +24,30 @@ namespace {
 
 constexpr int BS = 512;
 
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// 128-bit buffer descriptor over a whole array: gathers and stores then take a
+// 32-bit byte offset per lane (no 64-bit address arithmetic, fewer VGPRs).
+__device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void *base, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
+
+__device__ inline double2 buf_load2(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off)
+{
+    const v4i v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0);
+    double2 out;
+    __builtin_memcpy(&out, &v, 16);
+    return out;
+}
+
+__device__ inline void buf_store2(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off, double2 val)
+{
+    v4i v;
+    __builtin_memcpy(&v, &val, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, 0);
+}
+
 template <int NT>
 struct EllArgs {
     const int32_t *ell_idx;     // [M][K] column of every slot
@@ -42,21 +66,22 @@ struct EllArgs {
     int32_t has_lo, has_hi, any_tri;
     int32_t P, W, R;
     int32_t ngroups, chunk;  // groups in total / per XCD
+    uint32_t vec_bytes;      // M * ld * 8
 };
 
 // K: slots per row (compile time).  NPF: ELL elements each thread prefetches
 // per array and group, NPF * BS >= R * K.
 template <int NT, bool SHARED_IN, int K, int NPF>
-__global__ __launch_bounds__(BS) void kron_ell_kernel(const EllArgs<NT> a)
+__global__ __launch_bounds__(BS, 6) void kron_ell_kernel(const EllArgs<NT> a)
 {
     constexpr int KS = (K + 3) & ~3;  // LDS stride of a row's slots (16-byte vectors)
     extern __shared__ double sm[];
     const int W = a.W, R = a.R, SW = a.n_loc + 3;
     double *s_w = sm;                                                    // [NT][R][SW]
     double *s_val = s_w + (a.any_tri ? NT * R * SW : 0);                 // [NT][R][KS]
-    uint32_t *s_off = reinterpret_cast<uint32_t *>(s_val + NT * R * KS); // [R][KS] column * ld
+    uint32_t *s_off = reinterpret_cast<uint32_t *>(s_val + NT * R * KS); // [R][KS] byte offset of the column
     int32_t *s_idx = reinterpret_cast<int32_t *>(s_off + R * KS);        // [R][KS] ghost lanes only
-    uint32_t *s_row = reinterpret_cast<uint32_t *>(s_idx + R * KS);      // [R] output row * ld
+    uint32_t *s_row = reinterpret_cast<uint32_t *>(s_idx + R * KS);      // [R] byte offset of the output row
     // time-stencil coefficients [NT][3][LT], staged once (16-byte aligned rows)
     const int LT = (a.n_loc + 2) & ~1;
     double *s_tri = reinterpret_cast<double *>(s_row + ((R + 3) & ~3));
@@ -70,6 +95,12 @@ __global__ __launch_bounds__(BS) void kron_ell_kernel(const EllArgs<NT> a)
     const int t0 = 2 * p;
     const bool has1 = t0 + 1 < a.n_loc;
     const bool ghosts = a.has_lo || a.has_hi;
+    const uint32_t ld_bytes = (uint32_t)a.ld * 8u;
+    const uint32_t t0_bytes = (uint32_t)t0 * 8u;
+    __amdgpu_buffer_rsrc_t rs_x[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) rs_x[k] = make_rsrc(a.x[k], a.vec_bytes);
+    const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(a.y, a.vec_bytes);
 
     if (a.any_tri) {
         for (int i = threadIdx.x; i < NT * 3 * LT; i += BS) {
@@ -124,13 +155,13 @@ __global__ __launch_bounds__(BS) void kron_ell_kernel(const EllArgs<NT> a)
         for (int q = 0; q < NPF; ++q) {
             const int i = tid + q * BS;
             if (i < rows * K) {
-                s_off[st_lds[q]] = (uint32_t)pidx[q] * (uint32_t)a.ld;
+                s_off[st_lds[q]] = (uint32_t)pidx[q] * ld_bytes;
                 if (ghosts) s_idx[st_lds[q]] = pidx[q];
 #pragma unroll
                 for (int k = 0; k < NT; ++k) s_val[k * R * KS + st_lds[q]] = pval[k][q];
             }
         }
-        if (tid < rows) s_row[tid] = (uint32_t)prow * (uint32_t)a.ld;
+        if (tid < rows) s_row[tid] = (uint32_t)prow * ld_bytes;
         __syncthreads();
 
         // ---- prefetch the next group (in flight behind the gathers) ----------
@@ -154,6 +185,9 @@ __global__ __launch_bounds__(BS) void kron_ell_kernel(const EllArgs<NT> a)
 
         const bool rowok = r < rows;
         const int pos = g * R + r;
+        // read now: s_row is rewritten at the top of the next iteration, which a
+        // fast wave reaches while a slow one is still storing
+        const uint32_t yo = (rowok ? s_row[r] : 0u) + t0_bytes;
         double acc0[NT], acc1[NT];
 #pragma unroll
         for (int k = 0; k < NT; ++k) acc0[k] = acc1[k] = 0.0;
@@ -162,12 +196,11 @@ __global__ __launch_bounds__(BS) void kron_ell_kernel(const EllArgs<NT> a)
             const uint32_t *so = s_off + r * KS;
             uint32_t off[K];
 #pragma unroll
-            for (int u = 0; u < K; ++u) off[u] = so[u];
+            for (int u = 0; u < K; ++u) off[u] = so[u] + t0_bytes;
             if (SHARED_IN) {
-                const double *xb = a.x[0] + t0;
                 double2 xv[K];
 #pragma unroll
-                for (int u = 0; u < K; ++u) xv[u] = *reinterpret_cast<const double2 *>(xb + off[u]);
+                for (int u = 0; u < K; ++u) xv[u] = buf_load2(rs_x[0], off[u]);
 #pragma unroll
                 for (int k = 0; k < NT; ++k) {
                     const double *sv = s_val + (k * R + r) * KS;
@@ -181,11 +214,10 @@ __global__ __launch_bounds__(BS) void kron_ell_kernel(const EllArgs<NT> a)
             } else {
 #pragma unroll
                 for (int k = 0; k < NT; ++k) {
-                    const double *xb = a.x[k] + t0;
                     const double *sv = s_val + (k * R + r) * KS;
                     double2 xv[K];
 #pragma unroll
-                    for (int u = 0; u < K; ++u) xv[u] = *reinterpret_cast<const double2 *>(xb + off[u]);
+                    for (int u = 0; u < K; ++u) xv[u] = buf_load2(rs_x[k], off[u]);
 #pragma unroll
                     for (int u = 0; u < K; ++u) {
                         const double v = sv[u];
@@ -277,13 +309,12 @@ __global__ __launch_bounds__(BS) void kron_ell_kernel(const EllArgs<NT> a)
         }
         if (rowok && is_pair) {
             if (!has1) y1 = 0.0;  // padding slot stays zero
-            double2 *yp = reinterpret_cast<double2 *>(a.y + s_row[r] + t0);
             if (a.beta != 0.0) {
-                const double2 old = *yp;
+                const double2 old = buf_load2(rs_y, yo);
                 y0 = fma(a.beta, old.x, y0);
                 if (has1) y1 = fma(a.beta, old.y, y1);
             }
-            *yp = make_double2(y0, y1);
+            buf_store2(rs_y, yo, make_double2(y0, y1));
         }
     }
 }
@@ -315,6 +346,7 @@ int launch2(hipStream_t st, const EllArgs<NT> &a_in, int K)
     a.R = BS / a.W;
     a.ngroups = (a.M + a.R - 1) / a.R;
     a.chunk = (a.ngroups + 7) / 8;
+    a.vec_bytes = (uint32_t)((int64_t)a.M * a.ld * 8);
     const int KS = (K + 3) & ~3;
     const size_t lds = sizeof(double) * ((a.any_tri ? (size_t)NT * a.R * (a.n_loc + 3) : 0) +
                                           (size_t)NT * a.R * KS) +
@@ -327,7 +359,7 @@ int launch2(hipStream_t st, const EllArgs<NT> &a_in, int K)
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
             n_cu = prop.multiProcessorCount;
     }
-    int per_cu = g_ell_wg_per_cu > 0 ? g_ell_wg_per_cu : 2;
+    int per_cu = g_ell_wg_per_cu > 0 ? g_ell_wg_per_cu : 3;
     const int by_lds = (int)(160 * 1024 / (lds + 256));
     if (per_cu > by_lds) per_cu = by_lds > 0 ? by_lds : 1;
     int per_xcd = (n_cu / 8) * per_cu;
@@ -401,7 +433,9 @@ extern "C" int stk_kron_ell_apply(void *stream, const stk_ell_pattern *pat, int3
                 "stk_kron_ell_apply: bad sizes n_loc=%d ld=%d (ld must be even)", n_loc, ld);
     STK_REQUIRE(n_terms >= 1 && n_terms <= 3, "stk_kron_ell_apply: n_terms=%d not in 1..3", n_terms);
     STK_REQUIRE((n_loc + 1) / 2 + 2 <= BS, "stk_kron_ell_apply: n_loc=%d too large", n_loc);
-    STK_REQUIRE((int64_t)pat->M * ld < ((int64_t)1 << 32), "stk_kron_ell_apply: M*ld exceeds 32-bit offsets");
+    STK_REQUIRE((int64_t)pat->M * ld * 8 < ((int64_t)1 << 32),
+                "stk_kron_ell_apply: slab of %lld bytes exceeds the 4 GiB buffer-descriptor range; use "
+                "stk_kron_sum_apply", (long long)pat->M * ld * 8);
     STK_REQUIRE(((uintptr_t)y & 15) == 0, "stk_kron_ell_apply: y must be 16-byte aligned");
     for (int k = 0; k < n_terms; ++k) {
         STK_REQUIRE(t[k].ell_vals && t[k].x, "stk_kron_ell_apply: term %d has null vals/x", k);
