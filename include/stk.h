@@ -130,6 +130,27 @@ int stk_csr_spmm(void *stream, int32_t rows, int32_t n_loc, int32_t ld,
                  const double *cm, const double *x, double alpha, double beta,
                  const double *z, double *y);
 
+/* The same on a sliced-ELL copy (fast path; slot count K one of 2, 5, 7, 9,
+ * 12, 16; padding slots: any valid column, value 0).  ELL row `pos` produces
+ * output row row_ids[pos]; dia_a / dia_m hold the diagonal entry of that row
+ * (Gauss-Seidel only). */
+typedef struct {
+    int32_t n_pos;  /* ELL rows */
+    int32_t n_rows; /* rows of the output slab */
+    int32_t K;
+    const int32_t *idx;     /* n_pos*K columns */
+    const double *va, *vm;  /* n_pos*K values; vm may be NULL */
+    const int32_t *row_ids; /* n_pos or NULL */
+    const double *dia_a, *dia_m; /* n_pos each or NULL */
+} stk_ell_rows;
+
+/* y = alpha * A(t) x + beta * z; x has x_rows rows, y and z have ell->n_rows.
+ * Tuning key "rows_wg_per_cu". */
+int stk_ell_spmm(void *stream, const stk_ell_rows *ell_host, int32_t n_loc,
+                 int32_t ld, int32_t x_rows, double ca, const double *cm,
+                 const double *x, double alpha, double beta, const double *z,
+                 double *y);
+
 /* ---- (A_t kron I) for a small sparse time matrix ---------------------------
  * y[., t] = (add_identity ? x[., t] : 0) + sum_e val[e] * src(col[e]) over the
  * CSR row t of the LOCAL rows of the time matrix; col < n_loc addresses the
@@ -173,6 +194,14 @@ typedef struct {
     const double *p_vals;
     const int32_t *r_indptr, *r_indices;
     const double *r_vals;
+    /* Optional sliced-ELL copies (host structs, copied by stk_mg_create); when
+     * present the V-cycle runs on them.  ell_a: the level matrix in a
+     * locality order, for the residual.  ell_fwd / ell_bwd: the level matrix
+     * with its rows listed group by group of the forward / backward
+     * Gauss-Seidel schedule; *_pos_host[g] .. [g+1] is the position range of
+     * group g (n_fwd+1 / n_bwd+1 entries).  ell_p / ell_r: the transfers. */
+    const stk_ell_rows *ell_a, *ell_fwd, *ell_bwd, *ell_p, *ell_r;
+    const int32_t *fwd_pos_host, *bwd_pos_host;
 } stk_mg_level;
 
 typedef struct stk_mg stk_mg;

@@ -19,6 +19,7 @@
 #include "stk_common.h"
 
 int stk_kron_ell_set_tuning(const char *key, int32_t value);  // kron_ell.hip
+int stk_rows_ell_set_tuning(const char *key, int32_t value);  // rows_ell.hip
 
 namespace {
 
@@ -402,6 +403,7 @@ extern "C" int stk_set_tuning(const char *key, int32_t value)
         return 0;
     }
     if (stk_kron_ell_set_tuning(key, value) == 0) return 0;
+    if (stk_rows_ell_set_tuning(key, value) == 0) return 0;
     stk_set_error("stk_set_tuning: unknown key '%s'", key);
     return 2;
 }

@@ -22,7 +22,10 @@
 
 namespace {
 
-constexpr int BS = 512;
+#ifndef STK_ELL_BS
+#define STK_ELL_BS 512
+#endif
+constexpr int BS = STK_ELL_BS;
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
@@ -72,7 +75,7 @@ struct EllArgs {
 // K: slots per row (compile time).  NPF: ELL elements each thread prefetches
 // per array and group, NPF * BS >= R * K.
 template <int NT, bool SHARED_IN, int K, int NPF>
-__global__ __launch_bounds__(BS, 6) void kron_ell_kernel(const EllArgs<NT> a)
+__global__ __launch_bounds__(BS, 6 * 512 / BS > 8 ? 8 : 6) void kron_ell_kernel(const EllArgs<NT> a)
 {
     constexpr int KS = (K + 3) & ~3;  // LDS stride of a row's slots (16-byte vectors)
     extern __shared__ double sm[];

@@ -84,8 +84,20 @@ __global__ __launch_bounds__(GBS) void coarse_kernel(int32_t n0, int32_t n_loc, 
 
 }  // namespace
 
+// rows_ell.hip
+int stk_rows_ell_launch(hipStream_t st, int mode, const stk_ell_rows *e, int32_t pos_begin, int32_t pos_end,
+                        int32_t n_loc, int32_t ld, int64_t x_rows, int64_t y_rows, double ca, const double *cm,
+                        const double *x, double alpha, double beta, const double *z, double *y);
+
+struct EllLevel {
+    bool has_a = false, has_gs = false, has_p = false, has_r = false;
+    stk_ell_rows a, fwd, bwd, p, r;
+    std::vector<int32_t> fwd_pos, bwd_pos;
+};
+
 struct stk_mg {
     std::vector<stk_mg_level> lv;
+    std::vector<EllLevel> ell;
     std::vector<std::vector<int32_t>> fwd_ptr, bwd_ptr;
     int smoothsteps, vcycles, n_kinds, max_ld;
     const double *coarse_inv;
@@ -97,6 +109,18 @@ static int smooth_level(stk_mg *mg, hipStream_t st, int level, int n_loc, int ld
                         int its, bool backward, const double *f, double *u)
 {
     const stk_mg_level &L = mg->lv[level];
+    const EllLevel &E = mg->ell[level];
+    if (E.has_gs && (ld & 1) == 0) {
+        const stk_ell_rows &e = backward ? E.bwd : E.fwd;
+        const std::vector<int32_t> &pos = backward ? E.bwd_pos : E.fwd_pos;
+        for (int it = 0; it < its; ++it)
+            for (size_t g = 0; g + 1 < pos.size(); ++g) {
+                int rc = stk_rows_ell_launch(st, 1, &e, pos[g], pos[g + 1], n_loc, ld, L.n, L.n, ca, cm, u, 0.0, 0.0,
+                                             f, u);
+                if (rc) return rc;
+            }
+        return 0;
+    }
     const std::vector<int32_t> &ptr = backward ? mg->bwd_ptr[level] : mg->fwd_ptr[level];
     const int32_t *rows = backward ? L.bwd_rows : L.fwd_rows;
     const int ngroups = (int)ptr.size() - 1;
@@ -132,20 +156,33 @@ static int mgm(stk_mg *mg, hipStream_t st, int j, int n_loc, int ld, double ca, 
     if (rc) return rc;
     const stk_mg_level &C = mg->lv[j - 1];
     double *r_j = mg->r[j], *d_c = mg->f[j - 1], *u_c = mg->u[j - 1];
+    const EllLevel &E = mg->ell[j];
+    const bool even = (ld & 1) == 0;
     // r_j = A_j u_j - f_j
-    rc = stk_csr_spmm(st, L.n, n_loc, ld, L.indptr, L.indices, L.vals_a, ca, cm ? L.vals_m : nullptr, cm, u_j,
-                      1.0, -1.0, f_j, r_j);
+    if (E.has_a && even)
+        rc = stk_rows_ell_launch(st, 0, &E.a, 0, E.a.n_pos, n_loc, ld, L.n, L.n, ca, cm, u_j, 1.0, -1.0, f_j, r_j);
+    else
+        rc = stk_csr_spmm(st, L.n, n_loc, ld, L.indptr, L.indices, L.vals_a, ca, cm ? L.vals_m : nullptr, cm, u_j,
+                          1.0, -1.0, f_j, r_j);
     if (rc) return rc;
     // d_c = R r_j
-    rc = stk_csr_spmm(st, C.n, n_loc, ld, L.r_indptr, L.r_indices, L.r_vals, 1.0, nullptr, nullptr, r_j, 1.0,
-                      0.0, nullptr, d_c);
+    if (E.has_r && even)
+        rc = stk_rows_ell_launch(st, 0, &E.r, 0, E.r.n_pos, n_loc, ld, L.n, C.n, 1.0, nullptr, r_j, 1.0, 0.0,
+                                 nullptr, d_c);
+    else
+        rc = stk_csr_spmm(st, C.n, n_loc, ld, L.r_indptr, L.r_indices, L.r_vals, 1.0, nullptr, nullptr, r_j, 1.0,
+                          0.0, nullptr, d_c);
     if (rc) return rc;
     STK_HIP(hipMemsetAsync(u_c, 0, sizeof(double) * (size_t)C.n * ld, st));
     rc = mgm(mg, st, j - 1, n_loc, ld, ca, cm, kind, d_c, u_c);
     if (rc) return rc;
     // u_j -= P u_c
-    rc = stk_csr_spmm(st, L.n, n_loc, ld, L.p_indptr, L.p_indices, L.p_vals, 1.0, nullptr, nullptr, u_c, -1.0,
-                      1.0, u_j, u_j);
+    if (E.has_p && even)
+        rc = stk_rows_ell_launch(st, 0, &E.p, 0, E.p.n_pos, n_loc, ld, C.n, L.n, 1.0, nullptr, u_c, -1.0, 1.0, u_j,
+                                 u_j);
+    else
+        rc = stk_csr_spmm(st, L.n, n_loc, ld, L.p_indptr, L.p_indices, L.p_vals, 1.0, nullptr, nullptr, u_c, -1.0,
+                          1.0, u_j, u_j);
     if (rc) return rc;
     return smooth_level(mg, st, j, n_loc, ld, ca, cm, mg->smoothsteps, true, f_j, u_j);
 }
@@ -165,6 +202,22 @@ extern "C" int stk_mg_create(int32_t n_levels, const stk_mg_level *levels, int32
     mg->lv.assign(levels, levels + n_levels);
     mg->fwd_ptr.resize(n_levels);
     mg->bwd_ptr.resize(n_levels);
+    mg->ell.resize(n_levels);
+    for (int j = 1; j < n_levels; ++j) {
+        const stk_mg_level &L = mg->lv[j];
+        EllLevel &E = mg->ell[j];
+        if (L.ell_a) { E.a = *L.ell_a; E.has_a = true; }
+        if (L.ell_p) { E.p = *L.ell_p; E.has_p = true; }
+        if (L.ell_r) { E.r = *L.ell_r; E.has_r = true; }
+        if (L.ell_fwd && L.ell_bwd && L.fwd_pos_host && L.bwd_pos_host) {
+            E.fwd = *L.ell_fwd;
+            E.bwd = *L.ell_bwd;
+            E.fwd_pos.assign(L.fwd_pos_host, L.fwd_pos_host + L.n_fwd + 1);
+            E.bwd_pos.assign(L.bwd_pos_host, L.bwd_pos_host + L.n_bwd + 1);
+            E.has_gs = true;
+        }
+        mg->lv[j].ell_a = mg->lv[j].ell_fwd = mg->lv[j].ell_bwd = mg->lv[j].ell_p = mg->lv[j].ell_r = nullptr;
+    }
     mg->u.assign(n_levels, nullptr);
     mg->f.assign(n_levels, nullptr);
     mg->r.assign(n_levels, nullptr);

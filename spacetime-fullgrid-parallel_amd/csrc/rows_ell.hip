@@ -1,0 +1,330 @@
+// Row-gather engine on sliced-ELL matrices for the multigrid building blocks:
+//
+//   SPMM : y = alpha * A(t) x + beta * z          (residual, restriction,
+//                                                  prolongation-correction,
+//                                                  I kron A applies)
+//   GS   : u_i += (f_i - sum_j a_ij(t) u_j) / a_ii(t)   for the rows of one
+//          dependency group of a Gauss-Seidel sweep (reference
+//          source/multigrid.py:83-97, 116-127; see mg.hip for the schedule)
+//
+// with a(t) = ca * va + cm[t] * vm (vm optional).  Same structure as
+// kron_ell.hip: persistent workgroups, one lane per pair of time steps,
+// compile-time slot count K, all K gathers of a lane issued back to back
+// through a buffer descriptor, ELL entries of the next row group prefetched
+// into registers and handed over through double-buffered LDS (one barrier per
+// group).  HBM-bound: every slab row and matrix entry is read once per pass.
+#include <cstring>
+
+#include "stk_common.h"
+
+namespace {
+
+constexpr int BS = 512;
+enum { MODE_SPMM = 0, MODE_GS = 1 };
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+__device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void *base, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
+
+__device__ inline double2 buf_load2(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off)
+{
+    const v4i v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0);
+    double2 out;
+    __builtin_memcpy(&out, &v, 16);
+    return out;
+}
+
+__device__ inline void buf_store2(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off, double2 val)
+{
+    v4i v;
+    __builtin_memcpy(&v, &val, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, 0);
+}
+
+struct RowsArgs {
+    const int32_t *idx;      // [n_pos][K]
+    const double *va, *vm;   // [n_pos][K]
+    const int32_t *row_ids;  // [n_pos] or NULL
+    const double *dia_a, *dia_m;  // [n_pos] (GS)
+    const double *cm;        // [n_loc] or NULL
+    const double *x;         // gather source slab (GS: u)
+    const double *z;         // SPMM: beta operand; GS: right-hand side f
+    double *y;               // output slab (GS: u)
+    double ca, alpha, beta;
+    int32_t pos_begin, pos_end;
+    int32_t n_loc, ld, P, R;
+    int32_t ngroups, chunk;
+    uint32_t x_bytes, y_bytes;
+};
+
+template <int MODE, int K, int NPF, bool HAS_M>
+__global__ __launch_bounds__(BS, 6) void rows_ell_kernel(const RowsArgs a)
+{
+    constexpr int KS = (K + 3) & ~3;
+    extern __shared__ double sm[];
+    const int R = a.R, W = a.P;
+    // two LDS buffers of {va[R][KS], vm[R][KS], off[R][KS], row[R], dia_a[R], dia_m[R]}
+    const int buf_doubles = ((HAS_M ? 2 : 1) * R * KS + 2 * R + (R * KS + R + 1) / 2 + 2) & ~1;
+    const int tid = threadIdx.x;
+    const int r = tid / W;
+    const int p = tid - r * W;
+    const bool lane_ok = r < R;
+    const int t0 = 2 * p;
+    const bool has1 = t0 + 1 < a.n_loc;
+    const uint32_t ld_bytes = (uint32_t)a.ld * 8u;
+    const uint32_t t0_bytes = (uint32_t)t0 * 8u;
+    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(a.x, a.x_bytes);
+    const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(a.y, a.y_bytes);
+    const __amdgpu_buffer_rsrc_t rs_z = make_rsrc(a.z, a.y_bytes);
+
+    double cm0 = 0.0, cm1 = 0.0;
+    if (HAS_M && lane_ok) {
+        cm0 = a.cm[t0];
+        if (has1) cm1 = a.cm[t0 + 1];
+    }
+
+    int st_lds[NPF];
+#pragma unroll
+    for (int q = 0; q < NPF; ++q) {
+        const int i = tid + q * BS;
+        st_lds[q] = (i / K) * KS + (i % K);
+    }
+
+    const int xcd = blockIdx.x & 7;
+    const int step = gridDim.x >> 3;
+    const int gend = min((xcd + 1) * a.chunk, a.ngroups);
+    int g = xcd * a.chunk + (int)(blockIdx.x >> 3);
+
+    int32_t pidx[NPF];
+    double pva[NPF], pvm[NPF];
+    int32_t prow = 0;
+    double pda = 1.0, pdm = 0.0;
+#pragma unroll
+    for (int q = 0; q < NPF; ++q) {
+        pidx[q] = 0;
+        pva[q] = pvm[q] = 0.0;
+    }
+    auto load_group = [&](int gg) {
+        const int first = a.pos_begin + gg * R;
+        const int rows = min(R, a.pos_end - first);
+        const size_t base = (size_t)first * K;
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) {
+            const int i = tid + q * BS;
+            if (i < rows * K) {
+                pidx[q] = a.idx[base + i];
+                pva[q] = a.va[base + i];
+                if (HAS_M) pvm[q] = a.vm[base + i];
+            }
+        }
+        if (tid < rows) {
+            prow = a.row_ids ? a.row_ids[first + tid] : first + tid;
+            if (MODE == MODE_GS) {
+                pda = a.dia_a[first + tid];
+                if (HAS_M) pdm = a.dia_m[first + tid];
+            }
+        }
+    };
+    if (g < gend) load_group(g);
+
+    int flip = 0;
+    for (; g < gend; g += step, flip ^= 1) {
+        double *b_va = sm + flip * buf_doubles;
+        double *b_vm = b_va + R * KS;
+        double *b_da = b_va + (HAS_M ? 2 : 1) * R * KS;
+        double *b_dm = b_da + R;
+        uint32_t *b_off = reinterpret_cast<uint32_t *>(b_dm + R);
+        uint32_t *b_row = b_off + R * KS;
+
+        const int first = a.pos_begin + g * R;
+        const int rows = min(R, a.pos_end - first);
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) {
+            const int i = tid + q * BS;
+            if (i < rows * K) {
+                b_off[st_lds[q]] = (uint32_t)pidx[q] * ld_bytes;
+                b_va[st_lds[q]] = a.ca * pva[q];
+                if (HAS_M) b_vm[st_lds[q]] = pvm[q];
+            }
+        }
+        if (tid < rows) {
+            b_row[tid] = (uint32_t)prow * ld_bytes;
+            if (MODE == MODE_GS) {
+                b_da[tid] = a.ca * pda;
+                if (HAS_M) b_dm[tid] = pdm;
+            }
+        }
+        __syncthreads();
+        if (g + step < gend) load_group(g + step);  // in flight behind the gathers
+
+        if (lane_ok && r < rows) {
+            const uint32_t *so = b_off + r * KS;
+            const double *sva = b_va + r * KS;
+            const double *svm = b_vm + r * KS;
+            const uint32_t yo = b_row[r] + t0_bytes;
+            double2 xv[K];
+#pragma unroll
+            for (int u = 0; u < K; ++u) xv[u] = buf_load2(rs_x, so[u] + t0_bytes);
+            double2 zv = make_double2(0.0, 0.0), own = make_double2(0.0, 0.0);
+            if (MODE == MODE_GS) {
+                zv = buf_load2(rs_z, yo);
+                own = buf_load2(rs_x, yo);
+            } else if (a.beta != 0.0) {
+                zv = buf_load2(rs_z, yo);
+            }
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int u = 0; u < K; ++u) {
+                double v0 = sva[u], v1 = v0;
+                if (HAS_M) {
+                    const double m = svm[u];
+                    v0 = fma(cm0, m, v0);
+                    v1 = fma(cm1, m, v1);
+                }
+                s0 = fma(v0, xv[u].x, s0);
+                s1 = fma(v1, xv[u].y, s1);
+            }
+            double o0, o1;
+            if (MODE == MODE_GS) {
+                double d0 = b_da[r], d1 = d0;
+                if (HAS_M) {
+                    const double m = b_dm[r];
+                    d0 = fma(cm0, m, d0);
+                    d1 = fma(cm1, m, d1);
+                }
+                o0 = own.x + (1.0 / d0) * (zv.x - s0);
+                o1 = own.y + (1.0 / d1) * (zv.y - s1);
+            } else {
+                o0 = a.alpha * s0;
+                o1 = a.alpha * s1;
+                if (a.beta != 0.0) {
+                    o0 = fma(a.beta, zv.x, o0);
+                    o1 = fma(a.beta, zv.y, o1);
+                }
+            }
+            if (!has1) o1 = 0.0;  // padding slot stays zero
+            buf_store2(rs_y, yo, make_double2(o0, o1));
+        }
+    }
+}
+
+int g_rows_wg_per_cu = 0;
+
+template <int MODE, int K, bool HAS_M>
+int launch_npf(hipStream_t st, const RowsArgs &a, unsigned grid, size_t lds)
+{
+    const int npf = (a.R * K + BS - 1) / BS;
+    if (npf <= 1)
+        hipLaunchKernelGGL((rows_ell_kernel<MODE, K, 1, HAS_M>), dim3(grid), dim3(BS), lds, st, a);
+    else if (npf <= 2)
+        hipLaunchKernelGGL((rows_ell_kernel<MODE, K, 2, HAS_M>), dim3(grid), dim3(BS), lds, st, a);
+    else if (npf <= 4)
+        hipLaunchKernelGGL((rows_ell_kernel<MODE, K, 4, HAS_M>), dim3(grid), dim3(BS), lds, st, a);
+    else {
+        stk_set_error("rows_ell: %d slots per row with %d lanes per row not supported", K, a.P);
+        return 2;
+    }
+    STK_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int MODE, bool HAS_M>
+int launch_k(hipStream_t st, const RowsArgs &a, int K, unsigned grid, size_t lds)
+{
+    switch (K) {
+        case 2: return launch_npf<MODE, 2, HAS_M>(st, a, grid, lds);
+        case 5: return launch_npf<MODE, 5, HAS_M>(st, a, grid, lds);
+        case 7: return launch_npf<MODE, 7, HAS_M>(st, a, grid, lds);
+        case 9: return launch_npf<MODE, 9, HAS_M>(st, a, grid, lds);
+        case 12: return launch_npf<MODE, 12, HAS_M>(st, a, grid, lds);
+        case 16: return launch_npf<MODE, 16, HAS_M>(st, a, grid, lds);
+    }
+    stk_set_error("rows_ell: K=%d is not one of 2, 5, 7, 9, 12, 16", K);
+    return 2;
+}
+
+}  // namespace
+
+int stk_rows_ell_set_tuning(const char *key, int32_t value)
+{
+    if (std::strcmp(key, "rows_wg_per_cu") == 0) {
+        g_rows_wg_per_cu = value;
+        return 0;
+    }
+    return 1;
+}
+
+// Shared launcher (also used by mg.hip).  mode: 0 = SPMM, 1 = GS.
+int stk_rows_ell_launch(hipStream_t st, int mode, const stk_ell_rows *e, int32_t pos_begin, int32_t pos_end,
+                        int32_t n_loc, int32_t ld, int64_t x_rows, int64_t y_rows, double ca, const double *cm,
+                        const double *x, double alpha, double beta, const double *z, double *y)
+{
+    if (pos_end <= pos_begin) return 0;
+    STK_REQUIRE(e && e->idx && e->va, "rows_ell: incomplete matrix");
+    STK_REQUIRE((cm == nullptr) || e->vm, "rows_ell: cm given but the matrix has no vm");
+    STK_REQUIRE(n_loc > 0 && ld >= n_loc && (ld & 1) == 0, "rows_ell: bad n_loc=%d ld=%d (ld must be even)", n_loc,
+                ld);
+    STK_REQUIRE(x_rows * ld * 8 < ((int64_t)1 << 32) && y_rows * ld * 8 < ((int64_t)1 << 32),
+                "rows_ell: slab exceeds the 4 GiB buffer-descriptor range");
+    STK_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)z) & 15) == 0, "rows_ell: slabs must be 16-byte aligned");
+    STK_REQUIRE((n_loc + 1) / 2 <= BS, "rows_ell: n_loc too large");
+    RowsArgs a;
+    a.idx = e->idx;
+    a.va = e->va;
+    a.vm = cm ? e->vm : nullptr;
+    a.row_ids = e->row_ids;
+    a.dia_a = e->dia_a;
+    a.dia_m = e->dia_m;
+    a.cm = cm;
+    a.x = x;
+    a.z = z ? z : y;
+    a.y = y;
+    a.ca = ca;
+    a.alpha = alpha;
+    a.beta = z ? beta : 0.0;
+    a.pos_begin = pos_begin;
+    a.pos_end = pos_end;
+    a.n_loc = n_loc;
+    a.ld = ld;
+    a.P = (n_loc + 1) / 2;
+    a.R = BS / a.P;
+    a.ngroups = (pos_end - pos_begin + a.R - 1) / a.R;
+    a.chunk = (a.ngroups + 7) / 8;
+    a.x_bytes = (uint32_t)(x_rows * ld * 8);
+    a.y_bytes = (uint32_t)(y_rows * ld * 8);
+    if (mode == MODE_GS) STK_REQUIRE(e->dia_a && (!cm || e->dia_m), "rows_ell: GS needs the diagonal arrays");
+    const int K = e->K;
+    const int KS = (K + 3) & ~3;
+    const bool has_m = cm != nullptr;
+    const size_t buf_doubles =
+        ((size_t)(has_m ? 2 : 1) * a.R * KS + 2 * a.R + ((size_t)a.R * KS + a.R + 1) / 2 + 2) & ~(size_t)1;
+    const size_t lds = 2 * buf_doubles * sizeof(double) + 16;
+    int n_cu = 256;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            n_cu = prop.multiProcessorCount;
+    }
+    int per_cu = g_rows_wg_per_cu > 0 ? g_rows_wg_per_cu : 3;
+    int per_xcd = (n_cu / 8) * per_cu;
+    if (per_xcd > a.chunk) per_xcd = a.chunk;
+    if (per_xcd < 1) per_xcd = 1;
+    const unsigned grid = (unsigned)per_xcd * 8;
+    if (mode == MODE_GS)
+        return has_m ? launch_k<MODE_GS, true>(st, a, K, grid, lds) : launch_k<MODE_GS, false>(st, a, K, grid, lds);
+    return has_m ? launch_k<MODE_SPMM, true>(st, a, K, grid, lds) : launch_k<MODE_SPMM, false>(st, a, K, grid, lds);
+}
+
+extern "C" int stk_ell_spmm(void *stream, const stk_ell_rows *ell, int32_t n_loc, int32_t ld, int32_t x_rows,
+                            double ca, const double *cm, const double *x, double alpha, double beta,
+                            const double *z, double *y)
+{
+    STK_REQUIRE(ell && x && y && x != y, "stk_ell_spmm: bad pointers");
+    STK_REQUIRE(beta == 0.0 || z, "stk_ell_spmm: beta != 0 needs z");
+    return stk_rows_ell_launch(stk_stream(stream), MODE_SPMM, ell, 0, ell->n_pos, n_loc, ld, x_rows, ell->n_rows, ca,
+                               cm, x, alpha, beta, beta != 0.0 ? z : nullptr, y);
+}

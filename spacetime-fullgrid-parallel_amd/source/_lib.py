@@ -33,13 +33,25 @@ class KronEllTerm(ctypes.Structure):
                 ('x', c_p), ('x_lo', c_p), ('x_hi', c_p)]
 
 
+class EllRows(ctypes.Structure):
+    _fields_ = [('n_pos', c_i32), ('n_rows', c_i32), ('K', c_i32),
+                ('idx', c_p), ('va', c_p), ('vm', c_p), ('row_ids', c_p),
+                ('dia_a', c_p), ('dia_m', c_p)]
+
+
 class MGLevel(ctypes.Structure):
     _fields_ = [('n', c_i32), ('indptr', c_p), ('indices', c_p),
                 ('vals_a', c_p), ('vals_m', c_p), ('diag', c_p),
                 ('n_fwd', c_i32), ('fwd_ptr_host', c_p), ('fwd_rows', c_p),
                 ('n_bwd', c_i32), ('bwd_ptr_host', c_p), ('bwd_rows', c_p),
                 ('p_indptr', c_p), ('p_indices', c_p), ('p_vals', c_p),
-                ('r_indptr', c_p), ('r_indices', c_p), ('r_vals', c_p)]
+                ('r_indptr', c_p), ('r_indices', c_p), ('r_vals', c_p),
+                ('ell_a', ctypes.POINTER(EllRows)),
+                ('ell_fwd', ctypes.POINTER(EllRows)),
+                ('ell_bwd', ctypes.POINTER(EllRows)),
+                ('ell_p', ctypes.POINTER(EllRows)),
+                ('ell_r', ctypes.POINTER(EllRows)),
+                ('fwd_pos_host', c_p), ('bwd_pos_host', c_p)]
 
 
 _PROTOTYPES = {
@@ -60,6 +72,10 @@ _PROTOTYPES = {
     'stk_kron_ell_apply': (ctypes.c_int, [
         c_p, ctypes.POINTER(EllPattern), c_i32, c_i32, c_i32,
         ctypes.POINTER(KronEllTerm), c_f64, c_p
+    ]),
+    'stk_ell_spmm': (ctypes.c_int, [
+        c_p, ctypes.POINTER(EllRows), c_i32, c_i32, c_i32, c_f64, c_p, c_p,
+        c_f64, c_f64, c_p, c_p
     ]),
     'stk_csr_spmm': (ctypes.c_int, [
         c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_f64, c_p, c_p, c_p, c_f64,

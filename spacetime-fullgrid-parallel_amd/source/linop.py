@@ -167,6 +167,76 @@ def permute_rows(indptr, indices, vals, order):
             [v[gather] for v in vals], np.asarray(order, dtype=np.int32))
 
 
+class EllRowsMatrix:
+    """One matrix (values va, optionally a second value array vm on the same
+    pattern) in the sliced-ELL form of the row-gather engine (stk_ell_rows,
+    include/stk.h).  `order` lists the rows in processing order; `diag` adds
+    the diagonal arrays the Gauss-Seidel mode needs.  `ok` is False when a row
+    has more entries than the largest instantiated slot count."""
+    SLOTS = (2, 5, 7, 9, 12, 16)
+
+    def __init__(self, indptr, indices, va, vm=None, order=None, n_cols=None,
+                 diag=False):
+        n = len(indptr) - 1
+        counts_all = np.diff(indptr)
+        kmax = int(counts_all.max()) if n else 1
+        self.ok = kmax <= self.SLOTS[-1]
+        if not self.ok:
+            return
+        K = next(k for k in self.SLOTS if k >= kmax)
+        order = np.arange(n, dtype=np.int64) if order is None else np.asarray(
+            order, dtype=np.int64)
+        counts = counts_all[order]
+        npos = len(order)
+        pos = np.repeat(np.arange(npos), counts)
+        src = np.repeat(indptr[:-1][order], counts) + (
+            np.arange(counts.sum()) - np.repeat(
+                np.concatenate([[0], np.cumsum(counts)[:-1]]), counts))
+        slot = np.arange(counts.sum()) - np.repeat(
+            np.concatenate([[0], np.cumsum(counts)[:-1]]), counts)
+        idx = np.zeros((npos, K), dtype=np.int32)
+        idx[pos, slot] = indices[src]
+        ea = np.zeros((npos, K))
+        ea[pos, slot] = va[src]
+        self.K, self.n_pos, self.n_rows = K, npos, n
+        self.idx = _lib.to_dev(idx)
+        self.va = _lib.to_dev(ea)
+        self.vm = None
+        if vm is not None:
+            em = np.zeros((npos, K))
+            em[pos, slot] = vm[src]
+            self.vm = _lib.to_dev(em)
+        self.row_ids = _lib.to_dev(order.astype(np.int32))
+        self.dia_a = self.dia_m = None
+        if diag:
+            rows_of = np.repeat(np.arange(n), counts_all)
+            on = np.flatnonzero(indices == rows_of)
+            dpos = np.full(n, -1, dtype=np.int64)
+            dpos[rows_of[on]] = on
+            assert (dpos[order] >= 0).all(), 'matrix lacks a diagonal entry'
+            self.dia_a = _lib.to_dev(va[dpos[order]])
+            if vm is not None:
+                self.dia_m = _lib.to_dev(vm[dpos[order]])
+        self.struct = _lib.EllRows(npos, n, K, _lib.ptr(self.idx),
+                                   _lib.ptr(self.va), _lib.ptr(self.vm),
+                                   _lib.ptr(self.row_ids),
+                                   _lib.ptr(self.dia_a), _lib.ptr(self.dia_m))
+
+
+def tile_order_from_coords(coords, rows_per_tile=2048):
+    """Same as assembly.tile_row_order but from a coordinate array."""
+    p = np.asarray(coords)
+    if len(p) <= rows_per_tile:
+        return np.lexsort((p[:, 0], p[:, 1])).astype(np.int32)
+    lo, hi = p.min(axis=0), p.max(axis=0)
+    ext = np.maximum(hi - lo, 1e-300)
+    ntiles = max(1.0, len(p) / float(rows_per_tile))
+    side = np.sqrt(ext[0] * ext[1] / ntiles)
+    tx = np.floor((p[:, 0] - lo[0]) / side).astype(np.int64)
+    ty = np.floor((p[:, 1] - lo[1]) / side).astype(np.int64)
+    return np.lexsort((p[:, 0], p[:, 1], tx, ty)).astype(np.int32)
+
+
 class EllMatrices:
     """Several matrices on one shared pattern in the sliced-ELL form of
     ``stk_kron_ell_apply`` (include/stk.h), resident on the device: K slots per

@@ -24,7 +24,8 @@ import torch
 
 from . import _lib
 from .assembly import prolongation_matrices
-from .linop import SpaceOp, union_pattern
+from .linop import (EllRowsMatrix, SpaceOp, tile_order_from_coords,
+                    union_pattern)
 
 
 class MeshHierarchy:
@@ -33,9 +34,13 @@ class MeshHierarchy:
     mesh.TriangleMesh (the reference takes an NGSolve H1 space), or a ready
     list of prolongation matrices."""
     def __init__(self, fes=None, shared_comm=None, P_mats=None):
+        self.coords = None
         if P_mats is None:
             mesh = getattr(fes, 'mesh', fes)
             P_mats = prolongation_matrices(mesh)
+            # coordinates of the free dofs (level l = the first n_l of them):
+            # only used to pick cache-friendly row orders on the device
+            self.coords = mesh.points[~mesh.boundary]
         self.shared_comm = shared_comm
         self.P_mats = [sp.csr_matrix(P) for P in P_mats]
         self.R_mats = [P.T.tocsr() for P in self.P_mats]
@@ -120,6 +125,15 @@ class _DeviceHierarchy:
         L.n = n
         host = {}
         if j > 0:
+            # processing order: mesh tiles if coordinates are known
+            if hierarchy.coords is not None:
+                tile = tile_order_from_coords(hierarchy.coords[:n])
+            else:
+                tile = np.arange(n, dtype=np.int32)
+            rank = np.empty(n, dtype=np.int64)
+            rank[tile] = np.arange(n)
+            vm = vals[1] if self.has_m else None
+            ells = {'a': EllRowsMatrix(indptr, indices, vals[0], vm, tile)}
             for name, bw in (('fwd', False), ('bwd', True)):
                 ptr, rows = gauss_seidel_schedule(indptr, indices, bw)
                 host[name + '_ptr'] = ptr
@@ -127,14 +141,35 @@ class _DeviceHierarchy:
                 setattr(L, 'n_' + name, len(ptr) - 1)
                 setattr(L, name + '_ptr_host',
                         ptr.ctypes.data_as(ctypes.c_void_p))
+                # the same groups, each in tile order, as one ELL matrix
+                order = np.concatenate([
+                    np.sort(rank[rows[ptr[g]:ptr[g + 1]]])
+                    for g in range(len(ptr) - 1)
+                ]) if n else np.zeros(0, dtype=np.int64)
+                ells[name] = EllRowsMatrix(indptr, indices, vals[0], vm,
+                                           tile[order], diag=True)
+                host[name + '_pos'] = ptr  # group g = positions ptr[g]:ptr[g+1]
+                setattr(L, name + '_pos_host',
+                        ptr.ctypes.data_as(ctypes.c_void_p))
             P = sp.csr_matrix(hierarchy.P_mats[j - 1])
             R = sp.csr_matrix(hierarchy.R_mats[j - 1])
-            for name, m in (('p', P), ('r', R)):
+            nc = P.shape[1]
+            if hierarchy.coords is not None:
+                tile_c = tile_order_from_coords(hierarchy.coords[:nc])
+            else:
+                tile_c = np.arange(nc, dtype=np.int32)
+            for name, m, order in (('p', P, tile), ('r', R, tile_c)):
                 m.sort_indices()
                 dev[name + '_indptr'] = _lib.to_dev(m.indptr.astype(np.int32))
                 dev[name + '_indices'] = _lib.to_dev(
                     m.indices.astype(np.int32))
                 dev[name + '_vals'] = _lib.to_dev(m.data.astype(np.float64))
+                ells[name] = EllRowsMatrix(m.indptr, m.indices, m.data, None,
+                                           order)
+            if all(e.ok for e in ells.values()):
+                for name, e in ells.items():
+                    setattr(L, 'ell_' + name, ctypes.pointer(e.struct))
+                host['ells'] = ells
         for name, t in dev.items():
             setattr(L, name, _lib.ptr(t))
         self._keep.append((dev, host))

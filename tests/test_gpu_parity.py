@@ -181,15 +181,17 @@ def test_gauss_seidel_and_multigrid_match_reference_golden(stk, g3):
     rng = np.random.RandomState(7)
     # smoother alone, 5 time slices at once, nonzero initial guess
     mg = MultiGrid(m['A_x'], hier, smoothsteps=3, vcycles=2)
-    F, U0 = rng.rand(5, M), rng.rand(5, M)
-    for backward in (False, True):
-        ref = U0.copy()
-        sm = Smoother(m['A_x'], its=2)
-        (sm.PostSmooth if backward else sm.PreSmooth)(ref, F)
-        u = stk.to_dev(np.ascontiguousarray(U0.T))
-        f = stk.to_dev(np.ascontiguousarray(F.T))
-        mg.smooth(hier.J, u, f, its=2, backward=backward)
-        assert relerr(u.cpu().numpy().T, ref) < TOL
+    # 5 slices: odd leading dimension -> flat CSR kernels; 6: ELL row engine
+    for nsl in (5, 6):
+        F, U0 = rng.rand(nsl, M), rng.rand(nsl, M)
+        for backward in (False, True):
+            ref = U0.copy()
+            sm = Smoother(m['A_x'], its=2)
+            (sm.PostSmooth if backward else sm.PreSmooth)(ref, F)
+            u = stk.to_dev(np.ascontiguousarray(U0.T))
+            f = stk.to_dev(np.ascontiguousarray(F.T))
+            mg.smooth(hier.J, u, f, its=2, backward=backward)
+            assert relerr(u.cpu().numpy().T, ref) < TOL
     for ss in (1, 3):
         for vc in (1, 2):
             mg = MultiGrid(m['A_x'], hier, smoothsteps=ss, vcycles=vc)
