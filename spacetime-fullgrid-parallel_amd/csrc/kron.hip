@@ -20,6 +20,7 @@
 
 int stk_kron_ell_set_tuning(const char *key, int32_t value);  // kron_ell.hip
 int stk_rows_ell_set_tuning(const char *key, int32_t value);  // rows_ell.hip
+int stk_wavelet_set_tuning(const char *key, int32_t value);   // wavelet.hip
 
 namespace {
 
@@ -404,6 +405,7 @@ extern "C" int stk_set_tuning(const char *key, int32_t value)
     }
     if (stk_kron_ell_set_tuning(key, value) == 0) return 0;
     if (stk_rows_ell_set_tuning(key, value) == 0) return 0;
+    if (stk_wavelet_set_tuning(key, value) == 0) return 0;
     stk_set_error("stk_set_tuning: unknown key '%s'", key);
     return 2;
 }

@@ -71,6 +71,18 @@ class SpaceMatrix(SpaceOp):
         self.mat.sort_indices()
         self.shape = self.mat.shape
         self.dev = _lib.DeviceCSR(self.mat)
+        self._ell = None
+        self._hint = getattr(mat, 'stk_row_order', None)
+
+    def _ell_form(self):
+        """Sliced-ELL copy for the row-gather engine, built on first use."""
+        if self._ell is None:
+            m = self.mat
+            order = self._hint
+            if order is None:
+                order = row_order_for([m], m.indptr, m.indices)
+            self._ell = EllRowsMatrix(m.indptr, m.indices, m.data, None, order)
+        return self._ell if self._ell.ok else None
 
     def apply(self, x, out=None, n_loc=None, alpha=1.0, beta=0.0, z=None,
               **kw):
@@ -80,6 +92,13 @@ class SpaceMatrix(SpaceOp):
             out = torch.empty((self.shape[0], ld),
                               dtype=torch.float64,
                               device=x.device)
+        ell = self._ell_form() if (ld % 2 == 0 and ld > 1) else None
+        if ell is not None:
+            _lib.check(_lib.lib().stk_ell_spmm(
+                _lib.stream(), ctypes.byref(ell.struct), n_loc, ld,
+                self.shape[1], 1.0, None, _lib.ptr(x), alpha, beta,
+                _lib.ptr(z), _lib.ptr(out)))
+            return out
         d = self.dev
         _lib.check(_lib.lib().stk_csr_spmm(
             _lib.stream(), self.shape[0], n_loc, ld, _lib.ptr(d.indptr),

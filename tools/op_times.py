@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Per-operator device times at the bench configuration (W, WT, S, P, kron,
+BLAS-1), the analogue of the reference's heateq_mpi_timing.py."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, 'spacetime-fullgrid-parallel_amd'))
+import heateq_mpi as hm  # noqa: E402
+from bench import seeded_slab  # noqa: E402
+from source.mpi_vector import KronVectorMPI  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--J_time', type=int, default=6)
+ap.add_argument('--J_space', type=int, default=9)
+ap.add_argument('--iters', type=int, default=5)
+ap.add_argument('--problem', default='square')
+args = ap.parse_args()
+h = hm.HeatEquationMPI(J_space=args.J_space, J_time=args.J_time, problem=args.problem)
+dd = h.dofs_distr
+x = KronVectorMPI(dd, seeded_slab(dd.t_begin, dd.t_end, h.M))
+y = x.copy()
+nb = 8.0 * h.N * h.M
+
+
+def timeit(fn, n=args.iters):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+rows = [('W', lambda: h.W @ x, 2), ('WT', lambda: h.WT @ x, 2), ('S', lambda: h.S @ x, None),
+        ('P', lambda: h.P @ x, None), ('Kinv', lambda: h.Kinv_x.apply(x.buf, n_loc=x.n_loc), None),
+        ('A_x', lambda: h.CAC_j[0].linops[1].apply(x.buf, n_loc=x.n_loc), 2),
+        ('axpy', lambda: y.__iadd__(0.5 * x), 3), ('dot', lambda: x.dot(y), 2)]
+for name, fn, passes in rows:
+    ms = timeit(fn)
+    extra = '' if passes is None else '  %.0f GB/s (%d vector passes)' % (passes * nb / ms / 1e6, passes)
+    print('%-5s %9.3f ms%s' % (name, ms, extra))
