@@ -48,7 +48,12 @@ class Comm:
         """In-place sum of a small tensor that already lives on the compute
         device (keeps the dot result on the GPU until the single D2H read)."""
         if self.size > 1:
-            dist.all_reduce(t, group=self.group)
+            if t.is_cuda and self._device().type == 'cpu':
+                host = t.cpu()  # gloo: stage through the host
+                dist.all_reduce(host, group=self.group)
+                t.copy_(host)
+            else:
+                dist.all_reduce(t, group=self.group)
         return t
 
     def bcast(self, obj, root=0):
@@ -78,11 +83,28 @@ class Comm:
         ``wait_all`` on them.  Matching is by posting order per peer pair, so
         both sides must post their transfers with a common ordering (the
         callers order by global time index)."""
+        if not sends and not recvs:
+            return []
+        staged = []
+        if self._device().type == 'cpu':
+            # gloo moves host memory: device tensors are staged through the
+            # host (CPU tests, and several ranks sharing one GPU)
+            sends = [(t.cpu() if t.is_cuda else t, p) for t, p in sends]
+            host_recvs = []
+            for t, p in recvs:
+                if t.is_cuda:
+                    h = torch.empty(t.shape, dtype=t.dtype)
+                    staged.append((t, h))
+                    host_recvs.append((h, p))
+                else:
+                    host_recvs.append((t, p))
+            recvs = host_recvs
         ops = [dist.P2POp(dist.isend, t, p, self.group) for t, p in sends]
         ops += [dist.P2POp(dist.irecv, t, p, self.group) for t, p in recvs]
-        if not ops:
-            return []
-        return dist.batch_isend_irecv(ops)
+        reqs = list(dist.batch_isend_irecv(ops))
+        if staged:
+            reqs.append(_CopyBack(staged))
+        return reqs
 
     @staticmethod
     def wait_all(reqs):
@@ -95,16 +117,30 @@ class Comm:
         return torch.device('cpu')
 
 
+class _CopyBack:
+    """Pseudo request: after the real receives have been waited for (it sits
+    last in the list), move the staged host buffers to their device tensors."""
+    def __init__(self, pairs):
+        self.pairs = pairs
+
+    def wait(self):
+        for dev, host in self.pairs:
+            dev.copy_(host)
+
+
 def init_from_env():
     """Joins the job torchrun started (RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_*), one process per GPU.  A no-op for a plain single process."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if torch.cuda.is_available():
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+        # several ranks may share one GPU in tests (STK_BACKEND=gloo)
+        torch.cuda.set_device(
+            int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count())
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        backend = os.environ.get(
+            'STK_BACKEND', 'nccl' if torch.cuda.is_available() else 'gloo')
         kw = {}
         if backend == 'nccl':
             kw['device_id'] = torch.device('cuda', torch.cuda.current_device())

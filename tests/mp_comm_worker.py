@@ -1,0 +1,85 @@
+"""Worker of tests/test_distributed.py: exercises the communication layer of
+KronVectorMPI over torch.distributed (gloo, host tensors).  Launched once per
+rank by torch.distributed.run.  No kernel runs here (there is no CPU compute
+path); what is checked is who sends which time row to whom."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, 'spacetime-fullgrid-parallel_amd'))
+
+from oracle import partition, wavelets  # noqa: E402
+from source.comm import MPI  # noqa: E402
+from source.mpi_vector import DofDistributionMPI, KronVectorMPI  # noqa: E402
+
+
+def main():
+    comm = MPI.COMM_WORLD
+    rank, size = comm.Get_rank(), comm.Get_size()
+    assert size == int(os.environ['WORLD_SIZE']) and size > 1
+    J, M = 4, 37
+    N = 2**J + 1
+    dd = DofDistributionMPI(comm, N, M)
+    # a1: partition equals the oracle's (pinned to the reference's tables)
+    dist = partition.dof_distribution(N, size)
+    assert [list(d) for d in dist] == dd.dof_distribution
+    assert (dd.t_begin, dd.t_end) == dist[rank]
+    assert np.array_equal(dd.dof2proc, partition.dof2proc(N, size))
+    c, d = partition.counts_displs(N, M, size)
+    assert np.array_equal(dd.counts, c) and np.array_equal(dd.displs, d)
+
+    X = np.random.RandomState(7).rand(N, M)  # same on every rank
+    v = KronVectorMPI(dd)
+    assert not v.buf.is_cuda or os.environ.get('STK_BACKEND') == 'gloo'
+    # a6: scatter / gather
+    v.scatter(X.reshape(-1) if rank == 0 else None)
+    assert np.array_equal(v.X_loc.cpu().numpy(), X[dd.t_begin:dd.t_end])
+    out = np.zeros(N * M) if rank == 0 else None
+    v.gather(out)
+    if rank == 0:
+        assert np.array_equal(out.reshape(N, M), X)
+    # a4: halo rows
+    t = v.communicate_bdr()
+    assert t >= 0.0 and v.communicated_bdr
+    if rank > 0:
+        assert np.array_equal(v.X_lo.cpu().numpy(), X[dd.t_begin - 1])
+    else:
+        assert v.X_lo is None
+    if rank + 1 < size:
+        assert np.array_equal(v.X_hi.cpu().numpy(), X[dd.t_end])
+    else:
+        assert v.X_hi is None
+    called = []
+    assert v.communicate_bdr(lambda: called.append(1)) == 0.0 and called  # cached
+    v._invalidate()
+    assert not v.communicated_bdr
+    # a5: arbitrary remote rows, pattern of every wavelet level
+    for j in range(1, J + 1):
+        S = wavelets.split(J, j).tocoo()
+        pairs = sorted(set((int(r), int(c)) for r, c in zip(S.row, S.col)
+                           if dd.t_begin <= r < dd.t_end and not
+                           (dd.t_begin <= c < dd.t_end)))
+        recv, slot, reqs = v.communicate_dofs(pairs)
+        comm.wait_all(reqs)
+        for row, k in slot.items():
+            assert np.array_equal(recv[k].cpu().numpy(), X[row]), (j, row)
+    # a3: scalar all-reduce
+    assert comm.allreduce(float(rank + 1)) == size * (size + 1) / 2
+    # permute: all-to-all transpose and back (reference mpi_vector_test.py:31-48)
+    vp, _ = v.permute()
+    assert vp.N == M and vp.M == N
+    assert np.array_equal(vp.X_loc.cpu().numpy(), X.T[vp.t_begin:vp.t_end])
+    back, _ = vp.permute()
+    assert np.array_equal(back.X_loc.cpu().numpy(), X[dd.t_begin:dd.t_end])
+    comm.Barrier()
+    if rank == 0:
+        print('mp_comm_worker ok, size', size)
+
+
+if __name__ == '__main__':
+    main()

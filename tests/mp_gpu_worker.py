@@ -1,0 +1,90 @@
+"""Worker of tests/test_distributed.py (gpu): the time-slab distributed solver
+on real kernels.  Several ranks share the one GPU of the test box and talk
+through gloo (STK_BACKEND=gloo, device buffers staged through the host); the
+data path -- ghost lanes of the Kronecker kernel, per-level wavelet exchange,
+scalar all-reduce -- is the one RCCL carries on an 8-GPU node.  Rank 0 checks
+everything against the CPU oracle."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, 'spacetime-fullgrid-parallel_amd'))
+
+import heateq_mpi as hm  # noqa: E402
+from oracle import kron as okron  # noqa: E402
+from oracle.heat import HeatEquationOracle  # noqa: E402
+from oracle.krylov import pcg  # noqa: E402
+from source.comm import MPI  # noqa: E402
+from source.linalg import PCG  # noqa: E402
+from source.mpi_kron import SumMPI, TridiagKronMatMPI  # noqa: E402
+from source.mpi_vector import KronVectorMPI  # noqa: E402
+
+
+def main():
+    comm = MPI.COMM_WORLD
+    rank, size = comm.Get_rank(), comm.Get_size()
+    J_time, J_space = 4, 3
+    h = hm.HeatEquationMPI(J_space=J_space, J_time=J_time)
+    dd = h.dofs_distr
+    N, M = h.N, h.M
+    X = np.random.RandomState(128).rand(N, M)
+
+    def scattered():
+        v = KronVectorMPI(dd)
+        v.scatter(X.reshape(-1) if rank == 0 else None)
+        return v
+
+    def gathered(v):
+        out = np.zeros(N * M) if rank == 0 else None
+        v.gather(out)
+        return out.reshape(N, M) if rank == 0 else None
+
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    o = None
+    if rank == 0:
+        mats = dict(A_t=h.A_t, L_t=h.L_t, M_t=h.M_t, G_t=h.G_t, M_x=h.M_x,
+                    A_x=h.A_x, P_mats=h.hierarchy.P_mats, u0_t=h.u0_t,
+                    u0_x=h.u0_x)
+        o = HeatEquationOracle(mats, J_time)
+
+    x = scattered()
+    metric = SumMPI(dd, [TridiagKronMatMPI(dd, h.A_t, h.M_x),
+                         TridiagKronMatMPI(dd, h.M_t, h.A_x)])
+    got = gathered(metric @ x)
+    if rank == 0:
+        want = okron.sum_apply([(h.A_t, h.M_x), (h.M_t, h.A_x)], X)
+        assert rel(got, want) < 1e-12, ('metric', rel(got, want))
+    for name, op, ref in [('W', h.W, 'W'), ('WT', h.WT, 'WT'), ('S', h.S, 'S'),
+                          ('P', h.P, 'P'), ('WTSW', h.WT_S_W, 'WT_S_W')]:
+        x._invalidate()
+        got = gathered(op @ x)
+        if rank == 0:
+            want = getattr(o, ref)(X)
+            assert rel(got, want) < 1e-11, (name, rel(got, want))
+    # the reference-structured S (5 terms, time factor then space operator)
+    h2 = hm.HeatEquationMPI(J_space=J_space, J_time=J_time, schur='reference')
+    got = gathered(h2.S @ scattered())
+    if rank == 0:
+        assert rel(got, o.S(X)) < 1e-11
+    # dot + solve
+    d = x.dot(x)
+    assert abs(d - np.vdot(X, X)) < 1e-12 * d
+    hist = []
+    w, its = PCG(h.WT_S_W, h.P, h.rhs, history=hist)
+    got = gathered(w)
+    if rank == 0:
+        wo, it_o, hist_o = pcg(o.WT_S_W, o.P, o.rhs())
+        assert its == it_o, (its, it_o)
+        assert np.allclose(hist, hist_o, rtol=1e-8, atol=1e-26)
+        assert rel(got, wo) < 1e-8
+        print('mp_gpu_worker ok: size %d, %d PCG iterations' % (size, its))
+    comm.Barrier()
+
+
+if __name__ == '__main__':
+    main()
