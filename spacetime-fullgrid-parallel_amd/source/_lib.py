@@ -132,6 +132,9 @@ def check(rc):
 
 
 def stream():
+    if not torch.cuda.is_available():
+        raise StkError('libstk kernels need a GPU (none visible); there is no '
+                       'CPU fallback')
     return torch.cuda.current_stream().cuda_stream
 
 

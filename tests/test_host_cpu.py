@@ -1,0 +1,291 @@
+"""Host-side logic and the C-ABI surface, without a GPU.
+
+Covers: the built library exports every symbol include/stk.h declares; the
+product path refuses host tensors (no CPU fallback); partition tables against
+the reference's; wavelet split matrices against the reference's; the
+Gauss-Seidel dependency schedule (its groups reproduce the sequential sweep);
+the sliced-ELL builders; the duck-typed PCG / Lanczos on NumPy operands
+against the oracle; the build-owned mesh / assembly identities the reference's
+own tests check on NGSolve matrices."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from conftest import PKG, REPO, csr_from, load_golden, problem_from, relerr
+
+
+# ---- C ABI -------------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+    from source import _lib
+    header = open(os.path.join(REPO, 'include', 'stk.h')).read()
+    declared = set(re.findall(r'\b(stk_[a-z0-9_]+)\s*\(', header))
+    declared -= {'stk_mg'}  # a type, not a function
+    assert os.path.exists(_lib.LIB_PATH), 'run __graft_entry__.build() first'
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    # and the Python binding covers the header
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(
+        _lib.EXPORTED_SYMBOLS)
+    assert _lib.lib().stk_version() >= 100
+    assert _lib.lib().stk_last_error() is not None
+
+
+def test_no_cpu_fallback():
+    from source import _lib
+    from source.comm import Comm
+    from source.mpi_vector import DofDistributionMPI, KronVectorMPI
+    with pytest.raises(_lib.StkError):
+        _lib.ptr(torch.zeros(4, dtype=torch.float64))
+    if not torch.cuda.is_available():
+        dd = DofDistributionMPI(Comm(distributed=False), 5, 3)
+        x = KronVectorMPI(dd, np.ones((5, 3)))
+        with pytest.raises(_lib.StkError):
+            x += x  # arithmetic needs the device kernels
+        with pytest.raises(_lib.StkError):
+            x.dot(x)
+
+
+# ---- a1: partition -------------------------------------------------------------
+class _FakeComm:
+    def __init__(self, rank, size):
+        self.rank, self.size = rank, size
+
+    def Get_rank(self):
+        return self.rank
+
+    def Get_size(self):
+        return self.size
+
+
+def test_dof_distribution_matches_reference_tables():
+    from source.mpi_vector import DofDistributionMPI
+    g = load_golden('g2_partition')
+    for N in (5, 9, 33, 65, 129):
+        for size in (1, 2, 3, 4, 8):
+            if size > N:
+                continue
+            tag = 'N%d_s%d' % (N, size)
+            for rank in (0, size - 1):
+                d = DofDistributionMPI(_FakeComm(rank, size), N, 7)
+                assert np.array_equal(np.array(d.dof_distribution),
+                                      g['dist_' + tag])
+                assert np.array_equal(d.counts, g['counts_' + tag])
+                assert np.array_equal(d.displs, g['displs_' + tag])
+                assert np.array_equal(d.dof2proc, g['dof2proc_' + tag])
+                assert (d.t_begin, d.t_end) == tuple(
+                    g['range_%s_r%d' % (tag, rank)])
+    with pytest.raises(AssertionError):
+        DofDistributionMPI(_FakeComm(0, 6), 5, 7)  # more ranks than time dofs
+
+
+# ---- a15: wavelet host objects ---------------------------------------------------
+def test_wavelet_split_and_levels_match_reference():
+    from source.wavelets import WaveletTransformOp
+    g = load_golden('g1_wavelets')
+    for J in range(1, 6):
+        op = WaveletTransformOp(J, interleaved=True)
+        assert np.array_equal(op.levels, g['levels_J%d_il' % J])
+        assert op.shape == (2**J + 1, 2**J + 1)
+        for j in range(J + 1):
+            assert np.allclose(op.split(j).toarray(),
+                               g['split_J%d_il_j%d' % (J, j)], rtol=0,
+                               atol=1e-15)
+        lv = WaveletTransformOp(J, interleaved=False)
+        assert np.array_equal(np.asarray(lv.levels), g['levels_J%d_lv' % J])
+
+
+# ---- a20: Gauss-Seidel schedule ------------------------------------------------
+def _scheduled_sweep(mat, u, f, ptr, rows):
+    """What the GPU does: groups in order, rows of a group from the same
+    (pre-group) state."""
+    invd = 1.0 / mat.diagonal()
+    for g in range(len(ptr) - 1):
+        idx = rows[ptr[g]:ptr[g + 1]]
+        ax = mat[idx] @ u
+        u[idx] += invd[idx] * (f[idx] - ax)
+    return u
+
+
+@pytest.mark.parametrize('fixture', ['g3_square3', 'g3_lshape'])
+def test_gauss_seidel_schedule_reproduces_sequential_sweep(fixture):
+    from oracle.multigrid import Smoother
+    from source.multigrid import gauss_seidel_schedule
+    g = load_golden(fixture)
+    A = csr_from(g, 'A_x') + 0.7 * csr_from(g, 'M_x')
+    A = sp.csr_matrix(A)
+    A.sort_indices()
+    n = A.shape[0]
+    rng = np.random.RandomState(2)
+    f, u0 = rng.rand(n), rng.rand(n)
+    for backward in (False, True):
+        ptr, rows = gauss_seidel_schedule(A.indptr, A.indices, backward)
+        assert sorted(rows) == list(range(n))
+        # rows of one group are mutually independent
+        for k in range(len(ptr) - 1):
+            grp = rows[ptr[k]:ptr[k + 1]]
+            sub = A[grp][:, grp]
+            assert (sub - sp.diags(sub.diagonal())).nnz == 0
+        ref = u0.copy()
+        sm = Smoother(A, its=1, use_c=False)
+        (sm.PostSmooth if backward else sm.PreSmooth)(ref, f)
+        got = _scheduled_sweep(A, u0.copy(), f, ptr, rows)
+        assert relerr(got, ref) < 1e-14
+    # the square numbering is built for 4 groups
+    if fixture == 'g3_square3':
+        assert len(gauss_seidel_schedule(A.indptr, A.indices)[0]) - 1 == 4
+
+
+def test_gauss_seidel_schedule_deep_chain():
+    from source.multigrid import gauss_seidel_schedule
+    n = 50
+    T = sp.diags([np.ones(n - 1), 2 * np.ones(n), np.ones(n - 1)], [-1, 0, 1],
+                 format='csr')
+    ptr, rows = gauss_seidel_schedule(T.indptr, T.indices)
+    assert len(ptr) - 1 == n and list(rows) == list(range(n))  # fully serial
+    ptr, rows = gauss_seidel_schedule(T.indptr, T.indices, backward=True)
+    assert list(rows) == list(range(n - 1, -1, -1))
+
+
+# ---- ELL builders (device upload replaced by host tensors) -------------------------
+@pytest.fixture
+def host_uploads(monkeypatch):
+    from source import _lib
+    monkeypatch.setattr(_lib, 'to_dev', lambda a, dtype=None: torch.from_numpy(
+        np.ascontiguousarray(a)))
+    monkeypatch.setattr(_lib, 'ptr', lambda t: None if t is None else
+                        t.data_ptr())
+
+
+def test_union_pattern_and_ell_formats(host_uploads):
+    from source.linop import (EllMatrices, EllRowsMatrix, permute_rows,
+                              union_pattern)
+    rng = np.random.RandomState(0)
+    A = sp.random(60, 60, density=0.08, random_state=rng, format='csr')
+    B = sp.random(60, 60, density=0.05, random_state=rng, format='csr')
+    A = sp.csr_matrix(A + sp.identity(60))
+    A[7, :30] = rng.rand(30)  # a long row -> overflow CSR in EllMatrices
+    A = sp.csr_matrix(A)
+    indptr, indices, (va, vb) = union_pattern([A, B])
+    U = lambda v: sp.csr_matrix((v, indices, indptr), shape=A.shape)
+    assert abs(U(va) - A).max() == 0 and abs(U(vb) - B).max() == 0
+    order = rng.permutation(60).astype(np.int32)
+    ip, ix, (pa,), rid = permute_rows(indptr, indices, [va], order)
+    assert abs(sp.csr_matrix((pa, ix, ip), shape=A.shape) - A[order]).max() == 0
+    assert np.array_equal(rid, order)
+
+    A.stk_row_order = order
+    ell = EllMatrices([A, B])
+    assert ell.K == 16 and ell.ovf_indptr is not None
+    idx = ell.ell_idx.numpy()
+    for k, mat in enumerate((A, B)):
+        D = np.zeros(A.shape)
+        v = ell.ell_vals[k].numpy()
+        for pos in range(60):
+            for s in range(ell.K):
+                D[order[pos], idx[pos, s]] += v[pos, s]
+        op, oi, ov = (ell.ovf_indptr.numpy(), ell.ovf_indices.numpy(),
+                      ell.ovf_vals[k].numpy())
+        for pos in range(60):
+            for e in range(op[pos], op[pos + 1]):
+                D[order[pos], oi[e]] += ov[e]
+        assert abs(D - mat.toarray()).max() == 0
+
+    C = sp.csr_matrix(sp.random(40, 25, density=0.15, random_state=rng))
+    C = sp.csr_matrix(C + sp.eye(40, 25))
+    C.sort_indices()
+    e = EllRowsMatrix(C.indptr, C.indices, C.data, None, rng.permutation(40))
+    assert e.ok and e.K in EllRowsMatrix.SLOTS
+    D = np.zeros(C.shape)
+    ridx = e.row_ids.numpy()
+    for pos in range(40):
+        for s in range(e.K):
+            D[ridx[pos], e.idx.numpy()[pos, s]] += e.va.numpy()[pos, s]
+    assert abs(D - C.toarray()).max() == 0
+    wide = sp.csr_matrix(np.ones((3, 20)))
+    assert not EllRowsMatrix(wide.indptr, wide.indices, wide.data).ok
+
+
+# ---- a22 / a23 on NumPy operands ---------------------------------------------------
+def test_pcg_and_lanczos_duck_typed_on_numpy():
+    from oracle.krylov import Lanczos as OLanczos
+    from oracle.krylov import pcg as opcg
+    from source.lanczos import Lanczos
+    from source.linalg import PCG
+    g = load_golden('g3_square')
+    A = csr_from(g, 'A_x')
+    Pm = sp.diags(1.0 / A.diagonal())
+    b = np.random.RandomState(5).rand(A.shape[0])
+    hist = []
+    w, it = PCG(A, Pm, b, history=hist)
+    wo, ito, ho = opcg(lambda v: A @ v, lambda v: Pm @ v, b)
+    assert it == ito and np.allclose(hist, ho, rtol=1e-12)
+    assert relerr(w, wo) < 1e-12
+    assert relerr(A @ w, b) < 1e-5
+    # early exits of reference linalg.py:17-18 and :24
+    w0, it0 = PCG(A, Pm, np.zeros_like(b))
+    assert it0 == 0 and not w0.any()
+    lz = Lanczos(A, Pm, w=b.copy())
+    lo = OLanczos(lambda v: A @ v, lambda v: Pm @ v, b.copy())
+    assert lz.iterations == lo.iterations
+    assert abs(lz.lmax - lo.lmax) < 1e-10 * lo.lmax
+    assert abs(lz.lmin - lo.lmin) < 1e-10 * lo.lmin
+    ev = np.linalg.eigvalsh((Pm @ A).toarray() if False else
+                            (sp.diags(A.diagonal()**-0.5) @ A @
+                             sp.diags(A.diagonal()**-0.5)).toarray())
+    assert abs(lz.lmax - ev[-1]) < 1e-3 * ev[-1]
+    assert abs(lz.lmin - ev[0]) < 1e-2 * ev[0]
+
+
+# ---- build-owned mesh and assembly -------------------------------------------------
+@pytest.mark.parametrize('name', ['square', 'lshape'])
+def test_mesh_assembly_identities(name):
+    from source.assembly import (prolongation_matrices, space_load,
+                                 space_matrices, tile_row_order, time_matrices)
+    from source.mesh import (construct_2d_lshape_mesh,
+                             construct_2d_square_mesh, construct_interval)
+    from source.multigrid import gauss_seidel_schedule
+    mk = construct_2d_square_mesh if name == 'square' else construct_2d_lshape_mesh
+    mesh, _ = mk(3)
+    M_x, A_x = space_matrices(mesh)
+    n = M_x.shape[0]
+    if name == 'square':
+        assert n == (2**4 - 1)**2  # (2^(J+1) - 1)^2
+    assert M_x.dtype == np.float64 and M_x.indices.dtype == np.int32
+    assert abs(M_x - M_x.T).max() < 1e-16 and abs(A_x - A_x.T).max() < 1e-13
+    # mass matrix integrates: sum over free dofs of int phi_i phi_j <= area
+    area = 1.0 if name == 'square' else 3.0
+    assert 0.5 * area < M_x.sum() < area
+    # stiffness of interior rows away from the boundary sums to zero
+    assert np.sort(np.abs(A_x @ np.ones(n)))[n // 2] < 1e-12
+    assert (np.linalg.eigvalsh(A_x.toarray())[0] > 0)
+    # Galerkin products equal assembly on the coarser mesh
+    # (reference multigrid_test.py:14-37)
+    P = prolongation_matrices(mesh)
+    assert len(P) == 3 and P[-1].shape[0] == n
+    Mc, Ac = space_matrices(mk(2)[0])
+    assert abs(P[-1].T @ A_x @ P[-1] - Ac).max() < 1e-13
+    assert abs(P[-1].T @ M_x @ P[-1] - Mc).max() < 1e-15
+    # numbering built for shallow Gauss-Seidel dependency DAGs
+    ptr, _ = gauss_seidel_schedule(M_x.indptr, M_x.indices)
+    assert len(ptr) - 1 <= 5
+    order = tile_row_order(mesh)
+    assert sorted(order) == list(range(n))
+    # time matrices: P1 on the uniform interval
+    A_t, L_t, M_t, G_t, u0_t = time_matrices(construct_interval(8))
+    assert np.allclose(A_t @ np.ones(9), 0) and abs(M_t.sum() - 1.0) < 1e-15
+    assert abs(L_t + L_t.T - sp.diags([-1.0] + [0.0] * 7 + [1.0])).max() < 1e-15
+    assert G_t.nnz == 1 and G_t[0, 0] == 1.0 and u0_t[0] == 1.0
+    tpts = np.linspace(0, 1, 9)
+    assert abs(tpts @ (A_t @ tpts) - 1.0) < 1e-13  # int (t')^2 = 1
+    # load vector of u0 = sin(pi x) sin(pi y) against the mass matrix
+    u0 = lambda x, y: np.sin(np.pi * x) * np.sin(np.pi * y)
+    if name == 'square':
+        b = space_load(mesh, u0)
+        pts = mesh.points[~mesh.boundary]
+        assert relerr(b, M_x @ u0(pts[:, 0], pts[:, 1])) < 2e-2
