@@ -82,7 +82,7 @@ def _restrict(mat, fd):
     return _finish(sp.csr_matrix(mat)[fd, :].tocsc()[:, fd].tocsr())
 
 
-def tile_row_order(mesh, rows_per_tile=2048):
+def tile_row_order(mesh, rows_per_tile=None):
     """A processing order for the free dofs that follows the geometry: the
     bounding box is cut into square tiles of about `rows_per_tile` vertices,
     tiles are visited row by row and vertices inside a tile lexicographically.
@@ -91,6 +91,9 @@ def tile_row_order(mesh, rows_per_tile=2048):
     gathers of consecutive workgroups inside the same few hundred KB, i.e. in
     the L2 of the XCD that runs them.  Purely a performance hint
     (stk_kron_sum_apply's row_ids); results do not depend on it."""
+    import os
+    if rows_per_tile is None:
+        rows_per_tile = int(os.environ.get('STK_ROWS_PER_TILE', '2048'))
     fd = free_dofs(mesh)
     p = mesh.points[fd]
     lo, hi = p.min(axis=0), p.max(axis=0)
