@@ -278,8 +278,12 @@ class _TimeCSR:
                                     shape=(n_loc, max(cols, default=0) + 1))
         m.sort_indices()
         self.indptr = _lib.to_dev(m.indptr.astype(np.int32))
-        self.cols = _lib.to_dev(m.indices.astype(np.int32))
-        self.vals = _lib.to_dev(m.data.astype(np.float64))
+        # a slab may own no entry at all (e.g. no node of a coarse wavelet
+        # level): keep the arrays non-empty so their pointers are valid
+        cols_ = m.indices.astype(np.int32) if m.nnz else np.zeros(1, np.int32)
+        vals_ = m.data.astype(np.float64) if m.nnz else np.zeros(1)
+        self.cols = _lib.to_dev(cols_)
+        self.vals = _lib.to_dev(vals_)
 
     def apply(self, vec_in, recv, add_identity, vec_out):
         _lib.check(_lib.lib().stk_time_csr_apply(

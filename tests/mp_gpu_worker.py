@@ -29,7 +29,8 @@ def main():
     comm = MPI.COMM_WORLD
     rank, size = comm.Get_rank(), comm.Get_size()
     J_time, J_space = 4, 3
-    h = hm.HeatEquationMPI(J_space=J_space, J_time=J_time)
+    problem = os.environ.get('STK_TEST_PROBLEM', 'square')
+    h = hm.HeatEquationMPI(J_space=J_space, J_time=J_time, problem=problem)
     dd = h.dofs_distr
     N, M = h.N, h.M
     X = np.random.RandomState(128).rand(N, M)
@@ -67,7 +68,8 @@ def main():
             want = getattr(o, ref)(X)
             assert rel(got, want) < 1e-11, (name, rel(got, want))
     # the reference-structured S (5 terms, time factor then space operator)
-    h2 = hm.HeatEquationMPI(J_space=J_space, J_time=J_time, schur='reference')
+    h2 = hm.HeatEquationMPI(J_space=J_space, J_time=J_time, schur='reference',
+                            problem=problem)
     got = gathered(h2.S @ scattered())
     if rank == 0:
         assert rel(got, o.S(X)) < 1e-11

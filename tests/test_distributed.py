@@ -43,7 +43,9 @@ def test_comm_layer_gloo_cpu(nproc):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('nproc', [2, 3])
-def test_distributed_solve_ranks_sharing_one_gpu(nproc):
-    out = _run('mp_gpu_worker.py', nproc, {'STK_BACKEND': 'gloo'})
+@pytest.mark.parametrize('nproc,problem', [(2, 'square'), (3, 'square'),
+                                           (4, 'lshape'), (5, 'square')])
+def test_distributed_solve_ranks_sharing_one_gpu(nproc, problem):
+    out = _run('mp_gpu_worker.py', nproc, {'STK_BACKEND': 'gloo',
+                                           'STK_TEST_PROBLEM': problem})
     assert 'mp_gpu_worker ok' in out
