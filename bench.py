@@ -65,6 +65,22 @@ def cpu_baseline(A_t, M_t, M_x, A_x, N, M, nbytes):
     }
 
 
+def pmc_traffic(args, size):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes
+    (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-byte-per-lane
+    streams, plus WRITE_SIZE, both KiB), collected by tools/pmc_kron.sh in
+    separate runs and committed under profiles/.  Only meaningful for the
+    configuration it was measured on."""
+    path = os.path.join(REPO, 'profiles', 'r01_pmc_traffic.json')
+    if not os.path.exists(path) or size != 1:
+        return None
+    rec = json.load(open(path))
+    if (rec.get('J_time'), rec.get('J_space'), rec.get('problem')) != (
+            args.J_time, args.J_space, args.problem):
+        return None
+    return rec['hbm_bytes_per_launch']
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -126,7 +142,8 @@ def main():
     dev_ms = ev0.elapsed_time(ev1) / args.steps
 
     import torch.distributed as dist
-    t = torch.tensor([dt, float(my_bytes)], dtype=torch.float64, device='cuda')
+    red_dev = comm._device() if size > 1 else 'cuda'  # nccl: device, gloo (tests): host
+    t = torch.tensor([dt, float(my_bytes)], dtype=torch.float64, device=red_dev)
     if size > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -161,7 +178,7 @@ def main():
         # consecutive stamps are exactly one PCG iteration apart
         n_it = len(stamps) - 1
         ds = torch.tensor([stamps[-1] - stamps[0]], dtype=torch.float64,
-                          device='cuda')
+                          device=red_dev)
         if size > 1:
             dist.all_reduce(ds, op=dist.ReduceOp.MAX)
         ds = float(ds[0])
@@ -202,8 +219,8 @@ def main():
             'peak': HBM_PEAK_GBS,
             'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS,
-            'traffic': None,
-            'kernel': 'kron_sum_kernel<2, shared input>',
+            'traffic': pmc_traffic(args, size),
+            'kernel': 'kron_ell_kernel<NT=2, shared input, K=7>',
             'bytes_per_launch': my_bytes,
             'avg_launch_ms': dev_ms,
         },
