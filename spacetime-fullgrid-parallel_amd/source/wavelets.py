@@ -135,6 +135,72 @@ class _FusedWavelet:
             _lib.ptr(vec_in.buf), _lib.ptr(vec_out.buf)))
 
 
+class _TransposedWavelet:
+    """W or W^T across ranks through two all-to-all transposes: every rank
+    collects ALL time steps of its share of the space dofs (rows
+    [x_begin, x_end) of every rank's slab), runs the fused single-rank kernel on
+    them, and sends the result back.  On a fully connected xGMI node an
+    all-to-all moves 1/size of the slab over each link at once, whereas the
+    per-level composite needs J dependent exchanges of whole time rows
+    (reference wavelets.py:172-198, mpi_vector.py:189-203)."""
+    def __init__(self, dofs_distr, J, transposed):
+        from .mpi_vector import DofDistributionMPI
+        self.dd = dofs_distr
+        self.J, self.transposed = J, transposed
+        self.space = DofDistributionMPI(dofs_distr.comm, dofs_distr.M, 1)
+
+    def apply(self, vec_in, vec_out):
+        from .comm import MPI
+        dd, comm = self.dd, self.dd.comm
+        rank, N = dd.rank, dd.N
+        xb, xe = self.space.dof_distribution[rank]
+        ldN = N + (N & 1)
+        full = torch.zeros((xe - xb, ldN), dtype=torch.float64,
+                           device=vec_in.buf.device)
+        t0 = MPI.Wtime()
+        sends, recvs, parts = [], [], []
+        for p in range(comm.size):
+            pb, pe = self.space.dof_distribution[p]
+            tb, te = dd.dof_distribution[p]
+            if p == rank:
+                full[:, tb:te] = vec_in.buf[xb:xe, :vec_in.n_loc]
+                continue
+            sends.append((vec_in.buf[pb:pe, :vec_in.n_loc].contiguous(), p))
+            r = torch.empty((xe - xb, te - tb), dtype=torch.float64,
+                            device=full.device)
+            recvs.append((r, p))
+            parts.append((tb, te, r))
+        comm.wait_all(comm.exchange(sends, recvs))
+        for tb, te, r in parts:
+            full[:, tb:te] = r
+        t_comm = MPI.Wtime() - t0
+        out = torch.empty_like(full)
+        if xe > xb:
+            _lib.check(_lib.lib().stk_wavelet_apply(
+                _lib.stream(), xe - xb, self.J, ldN, int(self.transposed),
+                _lib.ptr(full), _lib.ptr(out)))
+        t0 = MPI.Wtime()
+        sends, recvs, parts = [], [], []
+        tb_me, te_me = dd.dof_distribution[rank]
+        for p in range(comm.size):
+            pb, pe = self.space.dof_distribution[p]
+            tb, te = dd.dof_distribution[p]
+            if p == rank:
+                vec_out.buf[xb:xe, :vec_out.n_loc] = out[:, tb:te]
+                continue
+            sends.append((out[:, tb:te].contiguous(), p))
+            r = torch.empty((pe - pb, te_me - tb_me), dtype=torch.float64,
+                            device=full.device)
+            recvs.append((r, p))
+            parts.append((pb, pe, r))
+        comm.wait_all(comm.exchange(sends, recvs))
+        for pb, pe, r in parts:
+            vec_out.buf[pb:pe, :vec_out.n_loc] = r
+        if vec_out.ld > vec_out.n_loc:
+            vec_out.buf[:, vec_out.n_loc:] = 0.0
+        return t_comm + MPI.Wtime() - t0
+
+
 class WaveletTransformKronIdentityMPI(CompositeMPI):
     """W := W_t kron Id_x (reference wavelets.py:172-183)."""
     def __init__(self, dofs_distr, J):
@@ -148,12 +214,19 @@ class WaveletTransformKronIdentityMPI(CompositeMPI):
                                       add_identity=True))
         super().__init__(dofs_distr, linops)
         self._fused = _FusedWavelet(J, False) if dofs_distr.size == 1 else None
+        # across ranks: 'transpose' (default) or 'composite' (the reference's
+        # per-level exchange)
+        self.mode = 'transpose'
+        self._transposed = _TransposedWavelet(dofs_distr, J, False)
 
     def _matvec(self, vec_in, vec_out):
-        if self._fused is None:
+        if self._fused is None and self.mode == 'composite':
             return super()._matvec(vec_in, vec_out)
-        self.time_communication = 0
-        self._fused.apply(vec_in, vec_out)
+        if self._fused is None:
+            self.time_communication = self._transposed.apply(vec_in, vec_out)
+        else:
+            self.time_communication = 0
+            self._fused.apply(vec_in, vec_out)
         vec_out.communicated_bdr = False
         return vec_out
 
@@ -172,11 +245,16 @@ class TransposedWaveletTransformKronIdentityMPI(CompositeMPI):
                                       add_identity=True))
         super().__init__(dofs_distr, linops)
         self._fused = _FusedWavelet(J, True) if dofs_distr.size == 1 else None
+        self.mode = 'transpose'
+        self._transposed = _TransposedWavelet(dofs_distr, J, True)
 
     def _matvec(self, vec_in, vec_out):
-        if self._fused is None:
+        if self._fused is None and self.mode == 'composite':
             return super()._matvec(vec_in, vec_out)
-        self.time_communication = 0
-        self._fused.apply(vec_in, vec_out)
+        if self._fused is None:
+            self.time_communication = self._transposed.apply(vec_in, vec_out)
+        else:
+            self.time_communication = 0
+            self._fused.apply(vec_in, vec_out)
         vec_out.communicated_bdr = False
         return vec_out

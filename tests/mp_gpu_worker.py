@@ -67,6 +67,14 @@ def main():
         if rank == 0:
             want = getattr(o, ref)(X)
             assert rel(got, want) < 1e-11, (name, rel(got, want))
+    # the reference's per-level wavelet composite agrees with the transposes
+    for op, ref in ((h.W, 'W'), (h.WT, 'WT')):
+        op.mode = 'composite'
+        x._invalidate()
+        got = gathered(op @ x)
+        op.mode = 'transpose'
+        if rank == 0:
+            assert rel(got, getattr(o, ref)(X)) < 1e-11, ('composite', ref)
     # the reference-structured S (5 terms, time factor then space operator)
     h2 = hm.HeatEquationMPI(J_space=J_space, J_time=J_time, schur='reference',
                             problem=problem)
