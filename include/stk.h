@@ -60,12 +60,6 @@ int stk_axpbyz(void *stream, int64_t n, double a, const double *x, double b,
 int64_t stk_dot_work_size(void);
 int stk_dot(void *stream, int64_t n, const double *x, const double *y,
             double *work, double *out);
-/* PCG update pair of reference linalg.py:29-30 plus the next dot in one pass:
- * w += alpha p ; r -= alpha t ; out[0] = r . r   (alpha read from device) */
-int stk_pcg_update(void *stream, int64_t n, const double *alpha_dev,
-                   const double *p, const double *t, double *w, double *r,
-                   double *work, double *out);
-
 /* ---- sum of Kronecker terms  y = beta*y + sum_k (T_k kron X_k) x_k --------
  * Replaces TridiagKronMatMPI._matvec (mpi_kron.py:214-219), i.e.
  * TridiagKronIdentityMPI (:186-201) followed by IdentityKronMatMPI (:143-150),

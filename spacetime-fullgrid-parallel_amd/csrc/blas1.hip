@@ -83,25 +83,6 @@ __global__ __launch_bounds__(1024) void dot_final_kernel(int n_partial, const do
     if (threadIdx.x == 0) out[0] = r;
 }
 
-__global__ __launch_bounds__(BS) void pcg_update_kernel(int64_t n, const double *alpha_dev,
-                                                        const double *__restrict__ p,
-                                                        const double *__restrict__ t, double *w, double *r,
-                                                        double *partial)
-{
-    __shared__ double sm[BS / 64];
-    const double alpha = alpha_dev[0];
-    const int64_t stride = (int64_t)gridDim.x * BS;
-    double acc = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += stride) {
-        w[i] += alpha * p[i];
-        double rv = r[i] - alpha * t[i];
-        r[i] = rv;
-        acc += rv * rv;
-    }
-    double s = block_sum(acc, sm);
-    if (threadIdx.x == 0) partial[blockIdx.x] = s;
-}
-
 }  // namespace
 
 extern "C" int stk_axpbyz(void *stream, int64_t n, double a, const double *x, double b, const double *y,
@@ -132,20 +113,6 @@ extern "C" int stk_dot(void *stream, int64_t n, const double *x, const double *y
     unsigned grid = stk_flat_grid(n / 2 + 1, BS);
     if (grid > DOT_BLOCKS) grid = DOT_BLOCKS;
     hipLaunchKernelGGL(dot_partial_kernel, dim3(grid), dim3(BS), 0, stk_stream(stream), n, x, y, work);
-    STK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(1024), 0, stk_stream(stream), (int)grid, work, out);
-    STK_LAUNCH_CHECK();
-    return 0;
-}
-
-extern "C" int stk_pcg_update(void *stream, int64_t n, const double *alpha_dev, const double *p,
-                              const double *t, double *w, double *r, double *work, double *out)
-{
-    STK_REQUIRE(alpha_dev && p && t && w && r && work && out, "stk_pcg_update: null pointer");
-    unsigned grid = stk_flat_grid(n, BS);
-    if (grid > DOT_BLOCKS) grid = DOT_BLOCKS;
-    hipLaunchKernelGGL(pcg_update_kernel, dim3(grid), dim3(BS), 0, stk_stream(stream), n, alpha_dev, p, t, w,
-                       r, work);
     STK_LAUNCH_CHECK();
     hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(1024), 0, stk_stream(stream), (int)grid, work, out);
     STK_LAUNCH_CHECK();

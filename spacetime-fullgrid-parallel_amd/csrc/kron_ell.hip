@@ -347,6 +347,7 @@ int launch2(hipStream_t st, const EllArgs<NT> &a_in, int K)
 {
     EllArgs<NT> a = a_in;
     a.R = BS / a.W;
+    if (a.R * K > 4 * BS) a.R = 4 * BS / K;  // at most 4 prefetched entries per thread
     a.ngroups = (a.M + a.R - 1) / a.R;
     a.chunk = (a.ngroups + 7) / 8;
     a.vec_bytes = (uint32_t)((int64_t)a.M * a.ld * 8);

@@ -291,6 +291,7 @@ int stk_rows_ell_launch(hipStream_t st, int mode, const stk_ell_rows *e, int32_t
     a.ld = ld;
     a.P = (n_loc + 1) / 2;
     a.R = BS / a.P;
+    if (a.R * e->K > 4 * BS) a.R = 4 * BS / e->K;  // at most 4 prefetched entries per thread
     a.ngroups = (pos_end - pos_begin + a.R - 1) / a.R;
     a.chunk = (a.ngroups + 7) / 8;
     a.x_bytes = (uint32_t)(x_rows * ld * 8);

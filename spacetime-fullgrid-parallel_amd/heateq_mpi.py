@@ -21,7 +21,7 @@ from source.assembly import (prolongation_matrices, space_load,
                              space_matrices, time_matrices)
 from source.comm import MPI
 from source.linalg import PCG
-from source.linop import CompositeLinOp, EllMatrices, as_space_op
+from source.linop import CompositeLinOp, EllMatrices, InvLinOp, as_space_op
 from source.mpi_kron import (BlockDiagMPI, CompositeMPI, LinearOperatorMPI,
                              MatKronIdentityMPI, SumMPI, TridiagKronMatMPI,
                              _local_tridiag)
@@ -141,19 +141,24 @@ class HeatEquationMPI:
             raise ValueError(wavelettransform)
 
         # ---- Preconditioners in space ---- (heateq_mpi.py:141-162)
-        assert (precond == 'multigrid'), 'only multigrid runs on the device'
         hierarchy = MeshHierarchy(mesh_space)
         self.hierarchy = hierarchy
-        self.Kinv_x = MultiGrid(self.A_x, hierarchy, smoothsteps=smoothsteps,
-                                vcycles=vcycles)
-        # C_j = multigrid for 2^j M_x + alpha A_x, all in one family
-        self.C_family = MultiGridFamily(self.A_x, self.M_x, hierarchy,
-                                        ca=alpha,
-                                        cms=[2**j for j in
-                                             range(self.J_time + 1)],
-                                        smoothsteps=smoothsteps,
-                                        vcycles=vcycles)
-        self.C_j = self.C_family.members
+        if precond == 'multigrid':
+            self.Kinv_x = MultiGrid(self.A_x, hierarchy,
+                                    smoothsteps=smoothsteps, vcycles=vcycles)
+            # C_j = multigrid for 2^j M_x + alpha A_x, all in one family
+            self.C_family = MultiGridFamily(
+                self.A_x, self.M_x, hierarchy, ca=alpha,
+                cms=[2**j for j in range(self.J_time + 1)],
+                smoothsteps=smoothsteps, vcycles=vcycles)
+            self.C_j = self.C_family.members
+        else:
+            assert (precond == 'direct')
+            self.Kinv_x = InvLinOp(self.A_x)
+            self.C_j = [
+                InvLinOp(2**j * self.M_x + alpha * self.A_x)
+                for j in range(self.J_time + 1)
+            ]
         self.CAC_j = [
             CompositeLinOp([self.C_j[j], self.A_x, self.C_j[j]])
             for j in range(self.J_time + 1)

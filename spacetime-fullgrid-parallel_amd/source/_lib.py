@@ -62,8 +62,6 @@ _PROTOTYPES = {
     'stk_axpbyz': (ctypes.c_int, [c_p, c_i64, c_f64, c_p, c_f64, c_p, c_p]),
     'stk_dot_work_size': (c_i64, []),
     'stk_dot': (ctypes.c_int, [c_p, c_i64, c_p, c_p, c_p, c_p]),
-    'stk_pcg_update': (ctypes.c_int,
-                       [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     'stk_set_tuning': (ctypes.c_int, [ctypes.c_char_p, c_i32]),
     'stk_kron_sum_apply': (ctypes.c_int, [
         c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_i32,

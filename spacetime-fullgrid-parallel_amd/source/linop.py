@@ -107,6 +107,27 @@ class SpaceMatrix(SpaceOp):
         return out
 
 
+class InvLinOp(SpaceMatrix):
+    """Direct inverse as a space operator (reference linop.py:18-26, used by
+    precond='direct', heateq_mpi.py:154-157).  The factorisation is SuperLU on
+    the host at setup, as in the reference; the device then applies the
+    explicit inverse with the same row-gather kernels as any other matrix.
+    Meant for the small systems the reference's tests use it on: the dense
+    inverse needs M^2 doubles."""
+    MAX_ROWS = 8192
+
+    def __init__(self, mat):
+        mat = sp.csc_matrix(mat)
+        n = mat.shape[0]
+        if n > self.MAX_ROWS:
+            raise NotImplementedError(
+                'InvLinOp: a dense inverse of %d rows does not fit; use the '
+                'multigrid preconditioner' % n)
+        lu = sp.linalg.splu(mat, options={"SymmetricMode": True},
+                            permc_spec="MMD_AT_PLUS_A")
+        super().__init__(sp.csr_matrix(lu.solve(np.eye(n))))
+
+
 class CompositeLinOp(SpaceOp):
     """x -> A B x, applied right to left (reference linop.py:68-79)."""
     def __init__(self, linops):
@@ -125,31 +146,28 @@ class CompositeLinOp(SpaceOp):
 def union_pattern(mats):
     """One CSR pattern containing the patterns of all `mats`, and every
     matrix's values expanded onto it (zeros where it has no entry).  The fused
-    Kronecker kernel walks the pattern once for all terms."""
+    kernels walk the pattern once for all matrices."""
     mats = [sp.csr_matrix(m) for m in mats]
     pat = sp.csr_matrix(mats[0].shape)
     for m in mats:
-        a = m.copy()
-        a.data = np.ones_like(a.data)
-        pat = pat + a
+        ones = sp.csr_matrix((np.ones(m.nnz), m.indices, m.indptr),
+                             shape=m.shape)
+        pat = pat + ones
     pat = sp.csr_matrix(pat)
     pat.sort_indices()
-    pat.data[:] = 1.0
+    rows_p = np.repeat(np.arange(pat.shape[0]), np.diff(pat.indptr))
+    key_p = rows_p.astype(np.int64) * pat.shape[1] + pat.indices
     vals = []
     for m in mats:
-        # expand through a sorted-key lookup so explicit zeros survive
-        full = sp.csr_matrix((np.zeros(pat.nnz), pat.indices, pat.indptr),
-                             shape=pat.shape)
         m = m.tocsr()
         m.sort_indices()
-        rows = np.repeat(np.arange(m.shape[0]), np.diff(m.indptr))
-        prow = np.repeat(np.arange(pat.shape[0]), np.diff(pat.indptr))
-        key_p = prow.astype(np.int64) * pat.shape[1] + pat.indices
-        key_m = rows.astype(np.int64) * m.shape[1] + m.indices
+        rows_m = np.repeat(np.arange(m.shape[0]), np.diff(m.indptr))
+        key_m = rows_m.astype(np.int64) * m.shape[1] + m.indices
         pos = np.searchsorted(key_p, key_m)
         assert np.array_equal(key_p[pos], key_m)
-        full.data[pos] = m.data
-        vals.append(full.data)
+        full = np.zeros(pat.nnz)
+        full[pos] = m.data
+        vals.append(full)
     return pat.indptr.astype(np.int32), pat.indices.astype(np.int32), vals
 
 

@@ -238,12 +238,17 @@ class BlockDiagMPI(LinearOperatorMPI):
             t2 = mid.apply(t1, n_loc=n_loc)
             fam.apply(t2, out=vec_out.buf, n_loc=n_loc, cm=cm, kind=kind)
         else:
-            # general case: one time slice at a time
+            # general case: the time slices of every distinct operator object
+            # together (one slice at a time if all operators differ)
             vec_out.buf.zero_()
+            groups = {}
             for t_loc, linop in enumerate(self._local):
-                col = vec_in.buf[:, t_loc:t_loc + 1].contiguous()
-                res = linop.apply(col, n_loc=1)
-                vec_out.buf[:, t_loc:t_loc + 1].copy_(res)
+                groups.setdefault(id(linop), (linop, []))[1].append(t_loc)
+            for linop, cols in groups.values():
+                idx = torch.tensor(cols, device=vec_in.buf.device)
+                xin = vec_in.buf.index_select(1, idx).contiguous()
+                res = linop.apply(xin, n_loc=len(cols))
+                vec_out.buf.index_copy_(1, idx, res[:, :len(cols)])
         vec_out.communicated_bdr = False
         return vec_out
 

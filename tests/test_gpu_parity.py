@@ -383,3 +383,82 @@ def test_ell_overflow_rows_and_ragged_matrix(stk):
     assert op._groups[0].ell.ovf_indptr is not None
     want = okron.sum_apply([(T, S), (T.T.tocsr(), S2)], X)
     assert relerr(_np(op @ _vec(dd, X)), want) < TOL
+
+
+def test_direct_preconditioner_matches_reference_golden(stk, g3):
+    """precond='direct' (reference heateq_mpi.py:154-157; its tests
+    heateq_mpi_test.py:66-135 use it): InvLinOp blocks, reference-shaped S."""
+    from source.linalg import PCG
+    from source.linop import CompositeLinOp, InvLinOp
+    from source.mpi_kron import (BlockDiagMPI, CompositeMPI, SumMPI,
+                                 TridiagKronMatMPI)
+    from source.wavelets import (TransposedWaveletTransformKronIdentityMPI,
+                                 WaveletTransformKronIdentityMPI)
+    m = problem_from(g3)
+    N, M, J = int(g3['N']), int(g3['M']), int(g3['J_time'])
+    dd = _dd(N, M)
+    M_x, A_x = m['M_x'], m['A_x']
+    K = InvLinOp(A_x)
+    C_j = [InvLinOp(2**j * M_x + 0.3 * A_x) for j in range(J + 1)]
+    S = SumMPI(dd, [
+        TridiagKronMatMPI(dd, m['A_t'], CompositeLinOp([M_x, K, M_x])),
+        TridiagKronMatMPI(dd, m['L_t'], CompositeLinOp([M_x, K, A_x])),
+        TridiagKronMatMPI(dd, sp.csr_matrix(m['L_t'].T),
+                          CompositeLinOp([A_x, K, M_x])),
+        TridiagKronMatMPI(dd, m['M_t'], CompositeLinOp([A_x, K, A_x])),
+        TridiagKronMatMPI(dd, m['G_t'], M_x),
+    ])
+    W = WaveletTransformKronIdentityMPI(dd, J)
+    WT = TransposedWaveletTransformKronIdentityMPI(dd, J)
+    CAC = [CompositeLinOp([c, A_x, c]) for c in C_j]
+    P = BlockDiagMPI(dd, [CAC[j] for j in W.levels])
+    WT_S_W = CompositeMPI(dd, [WT, S, W])
+    x = _vec(dd, g3['X'])
+    assert relerr(_np(S @ x), g3['S_direct']) < 1e-9
+    assert relerr(_np(P @ x), g3['P_direct']) < 1e-9
+    assert relerr(_np(WT_S_W @ x), g3['WTSW_direct']) < 1e-9
+    rr = []
+    w, iters = PCG(WT_S_W, P, _vec(dd, g3['rhs']),
+                   callback=lambda w, r, k: rr.append(r.dot(r)))
+    assert iters == int(g3['pcg_iters_direct'])
+    assert np.allclose(rr, g3['pcg_rr_direct'], rtol=1e-6, atol=1e-24)
+    assert relerr(_np(w), g3['pcg_w_direct']) < 1e-7
+
+
+def test_mat_kron_identity_and_original_wavelet_mode(stk):
+    """MatKronIdentityMPI through the all-to-all transpose (reference
+    mpi_kron_test.py:48-54, 96-109) and the drivers' wavelettransform modes."""
+    import heateq_mpi as hm
+    from source.mpi_kron import (CompositeMPI, IdentityKronMatMPI,
+                                 MatKronIdentityMPI)
+    N, M = 9, 16
+    dd = _dd(N, M)
+    mat_time = np.arange(0, N * N).reshape(N, N) * 1.0
+    mat_space = np.arange(0, M * M).reshape(M, M) * 1.0
+    X = np.random.RandomState(4).rand(N, M)
+    x = _vec(dd, X)
+    M_I = MatKronIdentityMPI(dd, mat_time)
+    assert relerr(_np(M_I @ x), mat_time @ X) < TOL
+    I_M = IdentityKronMatMPI(dd, mat_space)
+    comp = CompositeMPI(dd, [I_M, M_I])
+    want = (np.kron(mat_time, mat_space) @ X.reshape(-1)).reshape(N, M)
+    assert relerr(_np(comp @ x), want) < TOL
+    # vec.permute: (t, x) -> (x, t) (reference mpi_vector_test.py:31-48)
+    vp, _ = x.permute()
+    assert np.array_equal(_np(vp), X.T)
+    # the three wavelet-transform modes of the drivers give the same solve
+    ref = None
+    for mode in ('composite', 'interleaved', 'original'):
+        h = hm.HeatEquationMPI(J_space=2, J_time=3, wavelettransform=mode)
+        xx = _vec(h.dofs_distr, np.random.RandomState(9).rand(h.N, h.M))
+        if mode != 'original':  # interleaved numbering: same vectors
+            got = _np(h.WT_S_W @ xx)
+            ref = got if ref is None else ref
+            assert relerr(got, ref) < 1e-11
+        from source.linalg import PCG
+        w, it = PCG(h.WT_S_W, h.P, h.rhs)
+        u = _np(h.W @ w)  # solution in the hat-function basis: mode independent
+        if mode == 'composite':
+            u_ref, it_ref = u, it
+        else:
+            assert abs(it - it_ref) <= 1 and relerr(u, u_ref) < 1e-5
