@@ -57,6 +57,7 @@ struct RowsArgs {
     int32_t pos_begin, pos_end;
     int32_t n_loc, ld, P, R;
     int32_t ngroups, chunk;
+    int32_t reverse;  // walk the row groups of every XCD chunk backwards
     uint32_t x_bytes, y_bytes;
 };
 
@@ -107,7 +108,11 @@ __global__ __launch_bounds__(BS, 6) void rows_ell_kernel(const RowsArgs a)
         pidx[q] = 0;
         pva[q] = pvm[q] = 0.0;
     }
-    auto load_group = [&](int gg) {
+    // Consecutive launches alternate the direction in which they walk the rows:
+    // a launch then starts on the data the previous one touched last, which is
+    // still in the 256 MB Infinity Cache.
+    auto load_group = [&](int gq) {
+        const int gg = a.reverse ? (a.ngroups - 1 - gq) : gq;
         const int first = a.pos_begin + gg * R;
         const int rows = min(R, a.pos_end - first);
         const size_t base = (size_t)first * K;
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(BS, 6) void rows_ell_kernel(const RowsArgs a)
         uint32_t *b_off = reinterpret_cast<uint32_t *>(b_dm + R);
         uint32_t *b_row = b_off + R * KS;
 
-        const int first = a.pos_begin + g * R;
+        const int first = a.pos_begin + (a.reverse ? (a.ngroups - 1 - g) : g) * R;
         const int rows = min(R, a.pos_end - first);
 #pragma unroll
         for (int q = 0; q < NPF; ++q) {
@@ -212,6 +217,8 @@ __global__ __launch_bounds__(BS, 6) void rows_ell_kernel(const RowsArgs a)
 }
 
 int g_rows_wg_per_cu = 0;
+int g_rows_alternate = 1;   // alternate the walking direction between launches
+unsigned g_rows_launch_count = 0;
 
 template <int MODE, int K, bool HAS_M>
 int launch_npf(hipStream_t st, const RowsArgs &a, unsigned grid, size_t lds)
@@ -250,6 +257,10 @@ int launch_k(hipStream_t st, const RowsArgs &a, int K, unsigned grid, size_t lds
 
 int stk_rows_ell_set_tuning(const char *key, int32_t value)
 {
+    if (std::strcmp(key, "rows_alternate") == 0) {
+        g_rows_alternate = value;
+        return 0;
+    }
     if (std::strcmp(key, "rows_wg_per_cu") == 0) {
         g_rows_wg_per_cu = value;
         return 0;
@@ -294,6 +305,7 @@ int stk_rows_ell_launch(hipStream_t st, int mode, const stk_ell_rows *e, int32_t
     if (a.R * e->K > 4 * BS) a.R = 4 * BS / e->K;  // at most 4 prefetched entries per thread
     a.ngroups = (pos_end - pos_begin + a.R - 1) / a.R;
     a.chunk = (a.ngroups + 7) / 8;
+    a.reverse = g_rows_alternate ? (int)(g_rows_launch_count++ & 1u) : 0;
     a.x_bytes = (uint32_t)(x_rows * ld * 8);
     a.y_bytes = (uint32_t)(y_rows * ld * 8);
     if (mode == MODE_GS) STK_REQUIRE(e->dia_a && (!cm || e->dia_m), "rows_ell: GS needs the diagonal arrays");

@@ -20,7 +20,10 @@ ap.add_argument('--J_time', type=int, default=6)
 ap.add_argument('--J_space', type=int, default=9)
 ap.add_argument('--iters', type=int, default=5)
 ap.add_argument('--problem', default='square')
+ap.add_argument('--alternate', type=int, default=1)
 args = ap.parse_args()
+from source import _lib  # noqa: E402
+_lib.check(_lib.lib().stk_set_tuning(b'rows_alternate', args.alternate))
 h = hm.HeatEquationMPI(J_space=args.J_space, J_time=args.J_time, problem=args.problem)
 dd = h.dofs_distr
 x = KronVectorMPI(dd, seeded_slab(dd.t_begin, dd.t_end, h.M))
