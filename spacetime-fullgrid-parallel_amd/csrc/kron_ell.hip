@@ -74,9 +74,12 @@ struct EllArgs {
 
 // K: slots per row (compile time).  NPF: ELL elements each thread prefetches
 // per array and group, NPF * BS >= R * K.
-template <int NT, bool SHARED_IN, int K, int NPF>
+// GENERIC = false compiles the ghost-lane and overflow paths out (single slab, no
+// row longer than K): the common case runs without their branches.
+template <int NT, bool SHARED_IN, int K, int NPF, bool GENERIC>
 __global__ __launch_bounds__(BS, 6 * 512 / BS > 8 ? 8 : 6) void kron_ell_kernel(const EllArgs<NT> a)
 {
+    const int has_lo = GENERIC ? a.has_lo : 0, has_hi = GENERIC ? a.has_hi : 0;
     constexpr int KS = (K + 3) & ~3;  // LDS stride of a row's slots (16-byte vectors)
     extern __shared__ double sm[];
     const int W = a.W, R = a.R, SW = a.n_loc + 3;
@@ -92,12 +95,12 @@ __global__ __launch_bounds__(BS, 6 * 512 / BS > 8 ? 8 : 6) void kron_ell_kernel(
     const int tid = threadIdx.x;
     const int r = tid / W;
     const int l = tid - r * W;
-    const int p = l - a.has_lo;  // pair index; < 0: lo ghost lane, >= P: hi ghost lane
+    const int p = l - has_lo;  // pair index; < 0: lo ghost lane, >= P: hi ghost lane
     const bool is_pair = (p >= 0) && (p < a.P) && (r < R);
-    const bool is_ghost = (r < R) && !is_pair;
+    const bool is_ghost = GENERIC && (r < R) && !is_pair;
     const int t0 = 2 * p;
     const bool has1 = t0 + 1 < a.n_loc;
-    const bool ghosts = a.has_lo || a.has_hi;
+    const bool ghosts = has_lo || has_hi;
     const uint32_t ld_bytes = (uint32_t)a.ld * 8u;
     const uint32_t t0_bytes = (uint32_t)t0 * 8u;
     __amdgpu_buffer_rsrc_t rs_x[NT];
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(BS, 6 * 512 / BS > 8 ? 8 : 6) void kron_ell_kernel(
                     }
                 }
             }
-            if (a.ovf_indptr != nullptr) {  // entries beyond K of very long rows
+            if (GENERIC && a.ovf_indptr != nullptr) {  // entries beyond K of very long rows
                 for (int e = a.ovf_indptr[pos]; e < a.ovf_indptr[pos + 1]; ++e) {
                     const size_t o = (size_t)a.ovf_indices[e] * a.ld + t0;
 #pragma unroll
@@ -287,13 +290,13 @@ __global__ __launch_bounds__(BS, 6 * 512 / BS > 8 ? 8 : 6) void kron_ell_kernel(
                         const double2 dia = *reinterpret_cast<const double2 *>(c + LT);
                         const double2 sup = *reinterpret_cast<const double2 *>(c + 2 * LT);
                         double v0 = dia.x * acc0[k];
-                        if (t0 > 0 || a.has_lo) v0 = fma(sub.x, w[-1], v0);
-                        if (has1 || a.has_hi) v0 = fma(sup.x, has1 ? acc1[k] : w[1], v0);
+                        if (t0 > 0 || has_lo) v0 = fma(sub.x, w[-1], v0);
+                        if (has1 || has_hi) v0 = fma(sup.x, has1 ? acc1[k] : w[1], v0);
                         y0 += v0;
                         if (has1) {
                             double v1 = dia.y * acc1[k];
                             v1 = fma(sub.y, acc0[k], v1);
-                            if (t0 + 2 < a.n_loc || a.has_hi) v1 = fma(sup.y, w[2], v1);
+                            if (t0 + 2 < a.n_loc || has_hi) v1 = fma(sup.y, w[2], v1);
                             y1 += v1;
                         }
                     } else {
@@ -323,23 +326,32 @@ __global__ __launch_bounds__(BS, 6 * 512 / BS > 8 ? 8 : 6) void kron_ell_kernel(
 }
 
 int g_ell_wg_per_cu = 0;
+int g_ell_force_generic = 0;  // benchmarking: run the generic kernel even when the fast path applies
 
-template <int NT, bool SHARED_IN, int K>
-int launch3(hipStream_t st, const EllArgs<NT> &a, unsigned grid, size_t lds)
+template <int NT, bool SHARED_IN, int K, bool GENERIC>
+int launch4(hipStream_t st, const EllArgs<NT> &a, unsigned grid, size_t lds)
 {
     const int npf = (a.R * K + BS - 1) / BS;
     if (npf <= 1)
-        hipLaunchKernelGGL((kron_ell_kernel<NT, SHARED_IN, K, 1>), dim3(grid), dim3(BS), lds, st, a);
+        hipLaunchKernelGGL((kron_ell_kernel<NT, SHARED_IN, K, 1, GENERIC>), dim3(grid), dim3(BS), lds, st, a);
     else if (npf <= 2)
-        hipLaunchKernelGGL((kron_ell_kernel<NT, SHARED_IN, K, 2>), dim3(grid), dim3(BS), lds, st, a);
+        hipLaunchKernelGGL((kron_ell_kernel<NT, SHARED_IN, K, 2, GENERIC>), dim3(grid), dim3(BS), lds, st, a);
     else if (npf <= 4)
-        hipLaunchKernelGGL((kron_ell_kernel<NT, SHARED_IN, K, 4>), dim3(grid), dim3(BS), lds, st, a);
+        hipLaunchKernelGGL((kron_ell_kernel<NT, SHARED_IN, K, 4, GENERIC>), dim3(grid), dim3(BS), lds, st, a);
     else {
         stk_set_error("stk_kron_ell_apply: %d slots per row with %d lanes per row not supported", K, a.W);
         return 2;
     }
     STK_LAUNCH_CHECK();
     return 0;
+}
+
+template <int NT, bool SHARED_IN, int K>
+int launch3(hipStream_t st, const EllArgs<NT> &a, unsigned grid, size_t lds)
+{
+    const bool generic = a.has_lo || a.has_hi || a.ovf_indptr != nullptr || g_ell_force_generic;
+    return generic ? launch4<NT, SHARED_IN, K, true>(st, a, grid, lds)
+                   : launch4<NT, SHARED_IN, K, false>(st, a, grid, lds);
 }
 
 template <int NT, bool SHARED_IN>
@@ -418,6 +430,10 @@ int dispatch(hipStream_t st, const stk_ell_pattern *pat, int32_t n_loc, int32_t 
 
 int stk_kron_ell_set_tuning(const char *key, int32_t value)
 {
+    if (std::strcmp(key, "ell_force_generic") == 0) {
+        g_ell_force_generic = value;
+        return 0;
+    }
     if (std::strcmp(key, "ell_wg_per_cu") == 0) {
         g_ell_wg_per_cu = value;
         return 0;

@@ -67,6 +67,7 @@ times = {(o, b): [] for o, b, _ in variants}
 for rnd in range(args.rounds + 1):
     for order, bs, op in variants:
         _lib.check(_lib.lib().stk_set_tuning(b'kron_block', bs[0]))
+        _lib.check(_lib.lib().stk_set_tuning(b'ell_force_generic', bs[0]))
         _lib.check(_lib.lib().stk_set_tuning(b'ell_wg_per_cu', bs[1]))
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
