@@ -462,3 +462,23 @@ def test_mat_kron_identity_and_original_wavelet_mode(stk):
             u_ref, it_ref = u, it
         else:
             assert abs(it - it_ref) <= 1 and relerr(u, u_ref) < 1e-5
+
+
+def test_midsize_solve_matches_oracle_fixture(stk):
+    """N = 33, M = 16 129: PCG iteration count and r.Pr history against the CPU
+    oracle's trajectory (tests/golden/make_oracle_vectors.py)."""
+    import heateq_mpi as hm
+    from source.linalg import PCG
+    g = load_golden('o1_pcg_J5_J6')
+    h = hm.HeatEquationMPI(J_space=int(g['J_space']), J_time=int(g['J_time']))
+    X = np.random.RandomState(128).rand(h.N, h.M)
+    x = _vec(h.dofs_distr, X)
+    assert relerr(_np(h.S @ x)[::4, ::97], g['SX_sample']) < 1e-11
+    assert relerr(_np(h.P @ x)[::4, ::97], g['PX_sample']) < 1e-11
+    hist = []
+    w, it = PCG(h.WT_S_W, h.P, h.rhs, history=hist)
+    assert it == int(g['iters'])
+    assert np.allclose(hist, g['hist'], rtol=1e-8, atol=1e-28)
+    wn = _np(w)
+    assert abs(np.linalg.norm(wn) - g['w_norm']) < 1e-9 * g['w_norm']
+    assert relerr(wn[::4, ::97], g['w_sample']) < 1e-8
