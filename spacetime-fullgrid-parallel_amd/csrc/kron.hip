@@ -21,6 +21,8 @@
 int stk_kron_ell_set_tuning(const char *key, int32_t value);  // kron_ell.hip
 int stk_rows_ell_set_tuning(const char *key, int32_t value);  // rows_ell.hip
 int stk_wavelet_set_tuning(const char *key, int32_t value);   // wavelet.hip
+extern int g_mg_fuse_coarse, g_mg_coarse_max_rows;            // mg.hip
+extern int g_mg_coarse_pairs;                                 // mg_coarse.hip
 
 namespace {
 
@@ -406,6 +408,18 @@ extern "C" int stk_set_tuning(const char *key, int32_t value)
     if (stk_kron_ell_set_tuning(key, value) == 0) return 0;
     if (stk_rows_ell_set_tuning(key, value) == 0) return 0;
     if (stk_wavelet_set_tuning(key, value) == 0) return 0;
+    if (std::strcmp(key, "mg_coarse_max_rows") == 0) {
+        g_mg_coarse_max_rows = value;
+        return 0;
+    }
+    if (std::strcmp(key, "mg_coarse_pairs") == 0) {
+        g_mg_coarse_pairs = value;
+        return 0;
+    }
+    if (std::strcmp(key, "mg_fuse_coarse") == 0) {
+        g_mg_fuse_coarse = value;
+        return 0;
+    }
     stk_set_error("stk_set_tuning: unknown key '%s'", key);
     return 2;
 }

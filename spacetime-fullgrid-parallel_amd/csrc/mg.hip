@@ -89,6 +89,24 @@ int stk_rows_ell_launch(hipStream_t st, int mode, const stk_ell_rows *e, int32_t
                         int32_t n_loc, int32_t ld, int64_t x_rows, int64_t y_rows, double ca, const double *cm,
                         const double *x, double alpha, double beta, const double *z, double *y);
 
+// mg_coarse.hip: the sub-V-cycle below a cut level as one launch
+struct stk_coarse_plan;
+struct stk_coarse_level {
+    int n;
+    bool ok;
+    stk_ell_rows a, fwd, bwd, p, r;
+    const int32_t *fwd_pos, *bwd_pos;
+    int n_fwd, n_bwd;
+    double *u, *f, *res;
+};
+stk_coarse_plan *stk_coarse_plan_build(const stk_coarse_level *lv, int Lc, int smoothsteps);
+void stk_coarse_plan_free(stk_coarse_plan *p);
+int stk_coarse_plan_run(const stk_coarse_plan *p, hipStream_t st, int n_loc, int ld, double ca, const double *cm,
+                        const int32_t *kind, const double *coarse_inv);
+
+int g_mg_fuse_coarse = 1;       // 0 disables the fused coarse sub-V-cycle
+int g_mg_coarse_max_rows = 1024;  // levels up to this many rows are fused (larger ones fill the GPU by themselves)
+
 struct EllLevel {
     bool has_a = false, has_gs = false, has_p = false, has_r = false;
     stk_ell_rows a, fwd, bwd, p, r;
@@ -103,6 +121,9 @@ struct stk_mg {
     const double *coarse_inv;
     // workspaces per level (level J uses the caller's u, f)
     std::vector<double *> u, f, r;
+    // fused coarse sub-V-cycle: levels 0..Lc in one launch (Lc < 0: none)
+    stk_coarse_plan *coarse = nullptr;
+    int Lc = -1;
 };
 
 static int smooth_level(stk_mg *mg, hipStream_t st, int level, int n_loc, int ld, double ca, const double *cm,
@@ -143,6 +164,8 @@ static int mgm(stk_mg *mg, hipStream_t st, int j, int n_loc, int ld, double ca, 
                const int32_t *kind, const double *f_j, double *u_j)
 {
     const stk_mg_level &L = mg->lv[j];
+    if (g_mg_fuse_coarse && mg->coarse && j == mg->Lc && (ld & 1) == 0 && f_j == mg->f[j] && u_j == mg->u[j])
+        return stk_coarse_plan_run(mg->coarse, st, n_loc, ld, ca, cm, kind, mg->coarse_inv);
     if (j == 0) {
         const int total = L.n * n_loc;
         // the stored inverses are those of (vals_a + cm*vals_m) for cm != NULL,
@@ -251,6 +274,39 @@ extern "C" int stk_mg_create(int32_t n_levels, const stk_mg_level *levels, int32
             return 1;
         }
     }
+    // fuse the coarse end of the V-cycle when every level there has its ELL pieces
+    {
+        int Lc = -1;
+        for (int j = 1; j < n_levels - 1; ++j) {
+            const EllLevel &E = mg->ell[j];
+            if (mg->lv[j].n > g_mg_coarse_max_rows || !(E.has_a && E.has_gs && E.has_p && E.has_r)) break;
+            Lc = j;
+        }
+        if (Lc >= 1) {
+            std::vector<stk_coarse_level> cl(Lc + 1);
+            for (int j = 0; j <= Lc; ++j) {
+                const EllLevel &E = mg->ell[j];
+                cl[j].n = mg->lv[j].n;
+                cl[j].ok = true;
+                if (j >= 1) {
+                    cl[j].a = E.a;
+                    cl[j].fwd = E.fwd;
+                    cl[j].bwd = E.bwd;
+                    cl[j].p = E.p;
+                    cl[j].r = E.r;
+                    cl[j].fwd_pos = E.fwd_pos.data();
+                    cl[j].bwd_pos = E.bwd_pos.data();
+                    cl[j].n_fwd = (int)E.fwd_pos.size() - 1;
+                    cl[j].n_bwd = (int)E.bwd_pos.size() - 1;
+                }
+                cl[j].u = mg->u[j];
+                cl[j].f = mg->f[j];
+                cl[j].res = mg->r[j];
+            }
+            mg->coarse = stk_coarse_plan_build(cl.data(), Lc, smoothsteps);
+            if (mg->coarse) mg->Lc = Lc;
+        }
+    }
     *out = mg;
     return 0;
 }
@@ -261,6 +317,7 @@ extern "C" int stk_mg_destroy(stk_mg *mg)
     for (double *p : mg->u) (void)hipFree(p);
     for (double *p : mg->f) (void)hipFree(p);
     for (double *p : mg->r) (void)hipFree(p);
+    stk_coarse_plan_free(mg->coarse);
     delete mg;
     return 0;
 }

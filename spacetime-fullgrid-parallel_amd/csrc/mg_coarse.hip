@@ -1,0 +1,302 @@
+// The coarse end of a V-cycle in one launch.
+//
+// On the coarse levels of the hierarchy a Gauss-Seidel group or a transfer is
+// a few hundred rows: each of the ~27 launches per level costs more in launch
+// latency than in work.  This kernel runs the whole sub-V-cycle below a cut
+// level Lc -- MGM(Lc, u, f) of reference source/multigrid.py:168-182, i.e.
+// smooth / residual / restrict / ... / exact coarse solve / ... / correct /
+// smooth on levels Lc..0 -- as a list of jobs executed in order.  Time slices
+// never interact, so every workgroup owns a few time pairs of ALL rows and only
+// workgroup barriers separate the jobs: no inter-workgroup synchronisation.
+//
+// The arithmetic of a job is that of rows_ell.hip (same sliced-ELL matrices,
+// same summation order), so results are identical to the level-by-level path.
+#include <vector>
+
+#include "stk_common.h"
+
+namespace {
+
+constexpr int CBS = 512;
+enum { JOB_SPMM = 0, JOB_GS = 1, JOB_ZERO = 2, JOB_COARSE = 3 };
+
+struct Job {
+    int32_t kind, K;
+    int32_t pos_begin, pos_end;   // ELL rows (JOB_ZERO / JOB_COARSE: row count in pos_end)
+    const int32_t *idx;
+    const double *va, *vm;
+    const int32_t *row_ids;
+    const double *dia_a, *dia_m;
+    const double *x;   // gather source (GS: u)
+    const double *z;   // SPMM: beta operand, GS: right-hand side
+    double *y;
+    double alpha, beta;
+    int32_t use_m;     // entries are ca*va + cm[t]*vm (level matrices) or plain va (transfers)
+    int32_t pad;
+};
+
+struct CoarseArgs {
+    const Job *jobs;
+    int32_t n_jobs;
+    int32_t n_loc, ld;
+    int32_t pairs_per_wg;
+    double ca;
+    const double *cm;          // [n_loc] or NULL
+    const int32_t *kind;       // coarse-inverse index per time slice or NULL
+    const double *coarse_inv;  // [n_kinds][n0][n0]
+    double coarse_scale;       // 1/ca when cm == NULL
+};
+
+template <int K, bool HAS_M>
+__device__ inline void run_rows_job(const Job &j, const CoarseArgs &a, int p0, int W)
+{
+    const int nrows = j.pos_end - j.pos_begin;
+    const bool use_m = HAS_M && j.use_m;
+    const double ca = j.use_m ? a.ca : 1.0;
+    for (int item = threadIdx.x; item < nrows * W; item += CBS) {
+        const int r = item / W, p = p0 + (item - r * W);
+        const int t0 = 2 * p;
+        const bool has1 = t0 + 1 < a.n_loc;
+        const int pos = j.pos_begin + r;
+        const size_t e0 = (size_t)pos * K;
+        const int row = j.row_ids ? j.row_ids[pos] : pos;
+        double cm0 = 0.0, cm1 = 0.0;
+        if (use_m) {
+            cm0 = a.cm[t0];
+            if (has1) cm1 = a.cm[t0 + 1];
+        }
+        int col[K];
+        double2 xv[K];
+#pragma unroll
+        for (int u = 0; u < K; ++u) col[u] = j.idx[e0 + u];
+#pragma unroll
+        for (int u = 0; u < K; ++u)
+            xv[u] = *reinterpret_cast<const double2 *>(j.x + (size_t)col[u] * a.ld + t0);
+        const size_t yo = (size_t)row * a.ld + t0;
+        double2 zv = make_double2(0.0, 0.0), own = make_double2(0.0, 0.0);
+        if (j.kind == JOB_GS) {
+            zv = *reinterpret_cast<const double2 *>(j.z + yo);
+            own = *reinterpret_cast<const double2 *>(j.x + yo);
+        } else if (j.beta != 0.0) {
+            zv = *reinterpret_cast<const double2 *>(j.z + yo);
+        }
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            double v0 = ca * j.va[e0 + u], v1 = v0;
+            if (use_m) {
+                const double m = j.vm[e0 + u];
+                v0 = fma(cm0, m, v0);
+                v1 = fma(cm1, m, v1);
+            }
+            s0 = fma(v0, xv[u].x, s0);
+            s1 = fma(v1, xv[u].y, s1);
+        }
+        double o0, o1;
+        if (j.kind == JOB_GS) {
+            double d0 = ca * j.dia_a[pos], d1 = d0;
+            if (use_m) {
+                const double m = j.dia_m[pos];
+                d0 = fma(cm0, m, d0);
+                d1 = fma(cm1, m, d1);
+            }
+            o0 = own.x + (1.0 / d0) * (zv.x - s0);
+            o1 = own.y + (1.0 / d1) * (zv.y - s1);
+        } else {
+            o0 = j.alpha * s0;
+            o1 = j.alpha * s1;
+            if (j.beta != 0.0) {
+                o0 = fma(j.beta, zv.x, o0);
+                o1 = fma(j.beta, zv.y, o1);
+            }
+        }
+        if (!has1) o1 = 0.0;  // padding slot stays zero
+        *reinterpret_cast<double2 *>(j.y + yo) = make_double2(o0, o1);
+    }
+}
+
+template <bool HAS_M>
+__global__ __launch_bounds__(CBS) void mg_coarse_kernel(const CoarseArgs a)
+{
+    const int all_pairs = (a.n_loc + 1) / 2;
+    const int p0 = blockIdx.x * a.pairs_per_wg;
+    const int W = min(a.pairs_per_wg, all_pairs - p0);
+    if (W <= 0) return;
+    for (int jn = 0; jn < a.n_jobs; ++jn) {
+        const Job j = a.jobs[jn];
+        if (j.kind == JOB_ZERO) {
+            const int n = j.pos_end;
+            for (int item = threadIdx.x; item < n * W; item += CBS) {
+                const int r = item / W, p = p0 + (item - r * W);
+                *reinterpret_cast<double2 *>(j.y + (size_t)r * a.ld + 2 * p) = make_double2(0.0, 0.0);
+            }
+        } else if (j.kind == JOB_COARSE) {
+            // exact solve on level 0 with the dense inverse (multigrid.py:161-170)
+            const int n0 = j.pos_end;
+            for (int item = threadIdx.x; item < n0 * W; item += CBS) {
+                const int i = item / W, p = p0 + (item - i * W);
+                const int t0 = 2 * p;
+                const bool has1 = t0 + 1 < a.n_loc;
+                const double *A0 = a.coarse_inv + (size_t)(a.kind ? a.kind[t0] : 0) * n0 * n0 + (size_t)i * n0;
+                const double *A1 =
+                    a.coarse_inv + (size_t)((a.kind && has1) ? a.kind[t0 + 1] : 0) * n0 * n0 + (size_t)i * n0;
+                double s0 = 0.0, s1 = 0.0;
+                for (int c = 0; c < n0; ++c) {
+                    const double2 fv = *reinterpret_cast<const double2 *>(j.z + (size_t)c * a.ld + t0);
+                    s0 = fma(A0[c], fv.x, s0);
+                    s1 = fma(A1[c], fv.y, s1);
+                }
+                *reinterpret_cast<double2 *>(j.y + (size_t)i * a.ld + t0) =
+                    make_double2(a.coarse_scale * s0, has1 ? a.coarse_scale * s1 : 0.0);
+            }
+        } else {
+            switch (j.K) {
+                case 2: run_rows_job<2, HAS_M>(j, a, p0, W); break;
+                case 5: run_rows_job<5, HAS_M>(j, a, p0, W); break;
+                case 7: run_rows_job<7, HAS_M>(j, a, p0, W); break;
+                case 9: run_rows_job<9, HAS_M>(j, a, p0, W); break;
+                case 12: run_rows_job<12, HAS_M>(j, a, p0, W); break;
+                default: run_rows_job<16, HAS_M>(j, a, p0, W); break;
+            }
+        }
+        // the next job reads what this one wrote (same workgroup, same time pairs)
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+int g_mg_coarse_pairs = 0;  // time pairs per workgroup (0 = default)
+
+// Host side: the job list of MGM(Lc, u_Lc, f_Lc) and its launcher (used by mg.hip).
+struct stk_coarse_plan {
+    std::vector<Job> host_jobs;
+    Job *dev_jobs = nullptr;
+    int n_jobs = 0;
+};
+
+void stk_coarse_plan_free(stk_coarse_plan *p)
+{
+    if (!p) return;
+    if (p->dev_jobs) (void)hipFree(p->dev_jobs);
+    delete p;
+}
+
+static Job rows_job(int kind, const stk_ell_rows &e, int pos_begin, int pos_end, const double *x, const double *z,
+                    double *y, double alpha, double beta, bool level_matrix)
+{
+    Job j;
+    j.kind = kind;
+    j.K = e.K;
+    j.pos_begin = pos_begin;
+    j.pos_end = pos_end;
+    j.idx = e.idx;
+    j.va = e.va;
+    j.vm = e.vm;
+    j.row_ids = e.row_ids;
+    j.dia_a = e.dia_a;
+    j.dia_m = e.dia_m;
+    j.x = x;
+    j.z = z;
+    j.y = y;
+    j.alpha = alpha;
+    j.beta = beta;
+    j.use_m = level_matrix ? 1 : 0;
+    j.pad = 0;
+    return j;
+}
+
+// Description of one level handed over by mg.hip.
+struct stk_coarse_level {
+    int n;
+    bool ok;  // all sliced-ELL pieces present
+    stk_ell_rows a, fwd, bwd, p, r;
+    const int32_t *fwd_pos, *bwd_pos;
+    int n_fwd, n_bwd;
+    double *u, *f, *res;  // workspaces of this level
+};
+
+stk_coarse_plan *stk_coarse_plan_build(const stk_coarse_level *lv, int Lc, int smoothsteps)
+{
+    stk_coarse_plan *p = new stk_coarse_plan();
+    std::vector<Job> &J = p->host_jobs;
+    auto smooth = [&](int j, bool backward) {
+        const stk_coarse_level &L = lv[j];
+        const stk_ell_rows &e = backward ? L.bwd : L.fwd;
+        const int32_t *pos = backward ? L.bwd_pos : L.fwd_pos;
+        const int ng = backward ? L.n_bwd : L.n_fwd;
+        for (int it = 0; it < smoothsteps; ++it)
+            for (int g = 0; g < ng; ++g)
+                if (pos[g + 1] > pos[g])
+                    J.push_back(rows_job(JOB_GS, e, pos[g], pos[g + 1], L.u, L.f, L.u, 0.0, 0.0, true));
+    };
+    for (int j = Lc; j >= 1; --j) {
+        const stk_coarse_level &L = lv[j], &C = lv[j - 1];
+        smooth(j, false);
+        J.push_back(rows_job(JOB_SPMM, L.a, 0, L.a.n_pos, L.u, L.f, L.res, 1.0, -1.0, true));   // r = A u - f
+        J.push_back(rows_job(JOB_SPMM, L.r, 0, L.r.n_pos, L.res, nullptr, C.f, 1.0, 0.0, false));  // d = R r
+        Job z;
+        z.kind = JOB_ZERO;
+        z.K = 0;
+        z.pos_begin = 0;
+        z.pos_end = C.n;
+        z.idx = nullptr;
+        z.va = z.vm = z.dia_a = z.dia_m = z.x = z.z = nullptr;
+        z.row_ids = nullptr;
+        z.y = C.u;
+        z.alpha = z.beta = 0.0;
+        z.use_m = z.pad = 0;
+        if (j - 1 >= 1) J.push_back(z);  // level 0 is overwritten by the exact solve
+    }
+    {
+        Job c;
+        c.kind = JOB_COARSE;
+        c.K = 0;
+        c.pos_begin = 0;
+        c.pos_end = lv[0].n;
+        c.idx = nullptr;
+        c.va = c.vm = c.dia_a = c.dia_m = c.x = nullptr;
+        c.row_ids = nullptr;
+        c.z = lv[0].f;
+        c.y = lv[0].u;
+        c.alpha = c.beta = 0.0;
+        c.use_m = c.pad = 0;
+        J.push_back(c);
+    }
+    for (int j = 1; j <= Lc; ++j) {
+        const stk_coarse_level &L = lv[j], &C = lv[j - 1];
+        J.push_back(rows_job(JOB_SPMM, L.p, 0, L.p.n_pos, C.u, L.u, L.u, -1.0, 1.0, false));  // u -= P u_c
+        smooth(j, true);
+    }
+    p->n_jobs = (int)J.size();
+    if (hipMalloc((void **)&p->dev_jobs, sizeof(Job) * J.size()) != hipSuccess ||
+        hipMemcpy(p->dev_jobs, J.data(), sizeof(Job) * J.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        stk_coarse_plan_free(p);
+        return nullptr;
+    }
+    return p;
+}
+
+int stk_coarse_plan_run(const stk_coarse_plan *p, hipStream_t st, int n_loc, int ld, double ca, const double *cm,
+                        const int32_t *kind, const double *coarse_inv)
+{
+    CoarseArgs a;
+    a.jobs = p->dev_jobs;
+    a.n_jobs = p->n_jobs;
+    a.n_loc = n_loc;
+    a.ld = ld;
+    a.pairs_per_wg = g_mg_coarse_pairs > 0 ? g_mg_coarse_pairs : 1;
+    a.ca = ca;
+    a.cm = cm;
+    a.kind = cm ? kind : nullptr;
+    a.coarse_inv = coarse_inv;
+    a.coarse_scale = cm ? 1.0 : 1.0 / ca;
+    const int all_pairs = (n_loc + 1) / 2;
+    const unsigned grid = (unsigned)((all_pairs + a.pairs_per_wg - 1) / a.pairs_per_wg);
+    if (cm)
+        hipLaunchKernelGGL(mg_coarse_kernel<true>, dim3(grid), dim3(CBS), 0, st, a);
+    else
+        hipLaunchKernelGGL(mg_coarse_kernel<false>, dim3(grid), dim3(CBS), 0, st, a);
+    STK_LAUNCH_CHECK();
+    return 0;
+}

@@ -85,11 +85,16 @@ class TriangleMesh:
                 for b in tri:
                     if a != b:
                         nbrs[a].add(b)
-        # process edges grouped by direction so that structured meshes get the
-        # natural (horizontal, vertical, diagonal) classes
+        # process edges grouped by length, then direction: structured meshes get
+        # the natural (horizontal, vertical, diagonal) classes, with the longest
+        # edges (the hypotenuses) in the LAST class.  The stiffness matrix of a
+        # right triangle has no entry across its hypotenuse, so the midpoints of
+        # the two short-edge classes are not coupled by A_x and share one
+        # Gauss-Seidel dependency level: 3 levels for A_x instead of 4.
         d = self.points[edges[:, 1]] - self.points[edges[:, 0]]
         ang = np.round(np.mod(np.arctan2(d[:, 1], d[:, 0]), np.pi), 9)
-        order = np.lexsort((np.arange(ne), ang))
+        length = np.round(np.hypot(d[:, 0], d[:, 1]), 9)
+        order = np.lexsort((np.arange(ne), ang, length))
         col = -np.ones(ne, dtype=np.int64)
         for e in order:
             used = {col[n] for n in nbrs[e] if col[n] >= 0}

@@ -47,6 +47,18 @@ class MeshHierarchy:
         self.J = len(self.P_mats)
 
 
+def _drop_roundoff(mat, rel=1e-14):
+    """Remove stored entries of a Galerkin product that are pure rounding noise
+    (|a_ij| < rel * max|a|).  On nested right-triangle meshes R A P is the coarse
+    stiffness matrix, whose hypotenuse couplings are exactly 0; SciPy keeps them
+    as ~1e-17 entries, which would cost the sweep a dependency level and two ELL
+    slots for contributions below the rounding error of the other terms."""
+    if mat.nnz:
+        mat.data[np.abs(mat.data) < rel * np.abs(mat.data).max()] = 0.0
+        mat.eliminate_zeros()
+    return mat
+
+
 def gauss_seidel_schedule(indptr, indices, backward=False):
     """Groups the rows of a CSR pattern by their depth in the dependency DAG
     of a Gauss-Seidel sweep in dof order: row i must wait for its neighbours
@@ -88,9 +100,9 @@ class _DeviceHierarchy:
         Mm = [sp.csr_matrix(mat_m)] if self.has_m else None
         for j in reversed(range(self.J)):
             R, P = hierarchy.R_mats[j], hierarchy.P_mats[j]
-            A.insert(0, sp.csr_matrix(R @ A[0] @ P))
+            A.insert(0, _drop_roundoff(sp.csr_matrix(R @ A[0] @ P)))
             if self.has_m:
-                Mm.insert(0, sp.csr_matrix(R @ Mm[0] @ P))
+                Mm.insert(0, _drop_roundoff(sp.csr_matrix(R @ Mm[0] @ P)))
         self.mats_a, self.mats_m = A, Mm
         self.shape = A[-1].shape
         self._keep = []  # device tensors / host arrays the plan points into

@@ -289,3 +289,18 @@ def test_mesh_assembly_identities(name):
         b = space_load(mesh, u0)
         pts = mesh.points[~mesh.boundary]
         assert relerr(b, M_x @ u0(pts[:, 0], pts[:, 1])) < 2e-2
+
+
+def test_numbering_gives_shallow_gauss_seidel_schedules():
+    """The build-owned numbering (source/mesh.py) orders the new vertices of a
+    level by edge class with the hypotenuse class last: the sequential sweep of
+    the reference (multigrid.py:89-97) then has 3 dependency levels for the
+    5-point stiffness matrix and 4 for the 7-point mass matrix."""
+    from source.assembly import space_matrices
+    from source.mesh import construct_2d_lshape_mesh, construct_2d_square_mesh
+    from source.multigrid import gauss_seidel_schedule
+    for build in (construct_2d_square_mesh, construct_2d_lshape_mesh):
+        M_x, A_x = space_matrices(build(3)[0])
+        for backward in (False, True):
+            assert len(gauss_seidel_schedule(A_x.indptr, A_x.indices, backward)[0]) - 1 == 3
+            assert len(gauss_seidel_schedule(M_x.indptr, M_x.indices, backward)[0]) - 1 == 4
