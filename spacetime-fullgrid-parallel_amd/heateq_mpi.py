@@ -210,7 +210,7 @@ def main(argv=None):
     parser = argparse.ArgumentParser(
         description='Solve heatequation on MI355X GPUs, one time slab each.')
     parser.add_argument('--problem', default='square',
-                        help='problem type (square, lshape)')
+                        help='problem type (square, lshape, cube)')
     parser.add_argument('--J_time', type=int, default=7,
                         help='number of time refines')
     parser.add_argument('--J_space', type=int, default=7,

@@ -54,24 +54,22 @@ def time_matrices(mesh_time):
 
 
 # ----------------------------------------------------------------------------
-# Space: P1 on a triangulation.
+# Space: P1 on a triangulation (d = 2) or a tetrahedral mesh (d = 3).
 # ----------------------------------------------------------------------------
-def _tri_geometry(mesh):
+def _simplex_geometry(mesh):
+    """Volumes and the gradients of the barycentric coordinates per cell."""
     p = mesh.points
-    t = mesh.tris
-    x0, x1, x2 = p[t[:, 0]], p[t[:, 1]], p[t[:, 2]]
-    e1 = x1 - x0
-    e2 = x2 - x0
-    det = e1[:, 0] * e2[:, 1] - e1[:, 1] * e2[:, 0]
-    area = 0.5 * np.abs(det)
-    # gradients of the barycentric coordinates
-    g = np.empty((len(t), 3, 2))
-    g[:, 1, 0] = e2[:, 1] / det
-    g[:, 1, 1] = -e2[:, 0] / det
-    g[:, 2, 0] = -e1[:, 1] / det
-    g[:, 2, 1] = e1[:, 0] / det
-    g[:, 0] = -g[:, 1] - g[:, 2]
-    return area, g
+    c = mesh.cells
+    d = c.shape[1] - 1
+    E = p[c[:, 1:]] - p[c[:, :1]]  # (nc, d, d): rows = edge vectors
+    det = np.linalg.det(E)
+    fact = 2.0 if d == 2 else 6.0
+    vol = np.abs(det) / fact
+    Einv = np.linalg.inv(E)  # columns = gradients of lambda_1..lambda_d
+    g = np.empty((len(c), d + 1, d))
+    g[:, 1:] = np.swapaxes(Einv, 1, 2)
+    g[:, 0] = -g[:, 1:].sum(axis=1)
+    return vol, g
 
 
 def free_dofs(mesh):
@@ -94,33 +92,27 @@ def tile_row_order(mesh, rows_per_tile=None):
     import os
     if rows_per_tile is None:
         rows_per_tile = int(os.environ.get('STK_ROWS_PER_TILE', '2048'))
-    fd = free_dofs(mesh)
-    p = mesh.points[fd]
-    lo, hi = p.min(axis=0), p.max(axis=0)
-    ext = np.maximum(hi - lo, 1e-300)
-    ntiles = max(1.0, len(fd) / float(rows_per_tile))
-    side = np.sqrt(ext[0] * ext[1] / ntiles)
-    tx = np.floor((p[:, 0] - lo[0]) / side).astype(np.int64)
-    ty = np.floor((p[:, 1] - lo[1]) / side).astype(np.int64)
-    order = np.lexsort((p[:, 0], p[:, 1], tx, ty))
-    return order.astype(np.int32)
+    from .linop import tile_order_from_coords
+    return tile_order_from_coords(mesh.points[free_dofs(mesh)], rows_per_tile,
+                                  small_lexsort=False)
 
 
 def space_matrices(mesh):
     """Mass M_x and stiffness A_x on the free dofs (heateq_mpi.py:91-96)."""
-    area, g = _tri_geometry(mesh)
-    t = mesh.tris
+    vol, g = _simplex_geometry(mesh)
+    c = mesh.cells
+    nl = c.shape[1]
     nv = mesh.nv
-    rows = np.repeat(t, 3, axis=1).reshape(-1)
-    cols = np.tile(t, (1, 3)).reshape(-1)
-    K = np.einsum('tid,tjd->tij', g, g) * area[:, None, None]
-    Mloc = (np.ones((3, 3)) + np.eye(3)) / 12.0
-    Mv = area[:, None, None] * Mloc[None]
+    rows = np.repeat(c, nl, axis=1).reshape(-1)
+    cols = np.tile(c, (1, nl)).reshape(-1)
+    K = np.einsum('tid,tjd->tij', g, g) * vol[:, None, None]
+    Mloc = (np.ones((nl, nl)) + np.eye(nl)) / (nl * (nl + 1.0))
+    Mv = vol[:, None, None] * Mloc[None]
     A = sp.coo_matrix((K.reshape(-1), (rows, cols)), shape=(nv, nv)).tocsr()
     M = sp.coo_matrix((Mv.reshape(-1), (rows, cols)), shape=(nv, nv)).tocsr()
-    # the three-direction mesh yields exact zeros on the diagonal edges only up
-    # to rounding; drop what is numerically zero, as eliminate_zeros would for
-    # NGSolve's exactly integrated entries
+    # the three-direction mesh (Kuhn mesh in 3-D) yields exact zeros on the
+    # diagonal edges only up to rounding; drop what is numerically zero, as
+    # eliminate_zeros would for NGSolve's exactly integrated entries
     A.data[np.abs(A.data) < 1e-14 * np.abs(A.data).max()] = 0.0
     fd = free_dofs(mesh)
     M, A = _restrict(M, fd), _restrict(A, fd)
@@ -128,7 +120,7 @@ def space_matrices(mesh):
     return M, A
 
 
-# Dunavant degree-4 rule (6 points)
+# Dunavant degree-4 rule on the triangle (6 points)
 _QW = np.array([0.223381589678011] * 3 + [0.109951743655322] * 3)
 _a, _b = 0.445948490915965, 0.108103018168070
 _c, _d = 0.091576213509771, 0.816847572980459
@@ -136,16 +128,39 @@ _QL = np.array([[_b, _a, _a], [_a, _b, _a], [_a, _a, _b], [_d, _c, _c],
                 [_c, _d, _c], [_c, _c, _d]])
 
 
+def _keast4():
+    """Keast's degree-4 rule on the tetrahedron (11 points, weights sum to 1)."""
+    import itertools
+    pts, wts = [[0.25] * 4], [-0.0789333333333333]
+    a, b = 0.0714285714285714, 0.785714285714286
+    for k in range(4):
+        q = [a] * 4
+        q[k] = b
+        pts.append(q)
+        wts.append(0.0457333333333333)
+    a, b = 0.399403576166799, 0.100596423833201
+    for i, j in itertools.combinations(range(4), 2):
+        q = [b] * 4
+        q[i] = q[j] = a
+        pts.append(q)
+        wts.append(0.149333333333333)
+    return np.array(wts), np.array(pts)
+
+
+_QW3, _QL3 = _keast4()
+
+
 def space_load(mesh, fn):
     """int fn * phi_i on the free dofs (heateq_mpi.py:102-103)."""
-    area, _ = _tri_geometry(mesh)
+    vol, _ = _simplex_geometry(mesh)
     p = mesh.points
-    t = mesh.tris
-    X = np.einsum('ql,tld->tqd', _QL, p[t])  # quadrature points
-    f = fn(X[..., 0], X[..., 1])  # (nt, nq)
-    loc = np.einsum('tq,q,ql->tl', f, _QW, _QL) * area[:, None]
+    c = mesh.cells
+    qw, ql = (_QW, _QL) if c.shape[1] == 3 else (_QW3, _QL3)
+    X = np.einsum('ql,tld->tqd', ql, p[c])  # quadrature points
+    f = fn(*(X[..., k] for k in range(X.shape[-1])))  # (nt, nq)
+    loc = np.einsum('tq,q,ql->tl', f, qw, ql) * vol[:, None]
     vec = np.zeros(mesh.nv)
-    np.add.at(vec, t.reshape(-1), loc.reshape(-1))
+    np.add.at(vec, c.reshape(-1), loc.reshape(-1))
     return vec[free_dofs(mesh)]
 
 

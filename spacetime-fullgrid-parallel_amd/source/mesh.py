@@ -164,11 +164,118 @@ class TriangleMesh:
         return lv
 
 
+    @property
+    def cells(self):
+        return self.tris
+
+
+class TetMesh:
+    """Red (Bey) refinements of a conforming tetrahedral mesh with hierarchical
+    numbering; same attributes as TriangleMesh, with ``cells`` (nt, 4).
+
+    The new vertices of a level are grouped by the *direction class* of the edge
+    they bisect, shortest edges first, and sorted lexicographically inside a
+    class.  On the Kuhn triangulation of the cube there are 7 classes (3 axes,
+    3 face diagonals, the space diagonal) and no two edges of a tetrahedron share
+    one, so vertices of one class are never adjacent: the dof-order Gauss-Seidel
+    sweep (reference multigrid.py:89-97) has at most 8 dependency levels for the
+    15-point mass matrix and 4 for the stiffness matrix, which on this mesh is
+    the 7-point stencil (axis neighbours only)."""
+    def __init__(self, points, tets, boundary_fn):
+        self.points = np.asarray(points, dtype=np.float64)
+        self.tets = np.asarray(tets, dtype=np.int64)
+        self.boundary_fn = boundary_fn
+        nv = len(self.points)
+        self.nverts = [nv]
+        self.parents = -np.ones((nv, 2), dtype=np.int64)
+        self.vcolor = -np.ones(nv, dtype=np.int64)
+        self.boundary = boundary_fn(self.points)
+
+    _PAIRS = ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))
+
+    def _edges(self):
+        t = self.tets
+        e = np.stack([t[:, list(pr)] for pr in self._PAIRS], axis=1)
+        e = np.sort(e.reshape(-1, 2), axis=1)
+        nv = len(self.points)
+        key = e[:, 0] * nv + e[:, 1]
+        ukey, inv = np.unique(key, return_inverse=True)
+        edges = np.stack([ukey // nv, ukey % nv], axis=1)
+        return edges, inv.reshape(-1, 6)
+
+    def _edge_classes(self, edges):
+        d = self.points[edges[:, 1]] - self.points[edges[:, 0]]
+        length = np.sqrt((d * d).sum(axis=1))
+        u = d / length[:, None]
+        # one representative of +-u: first non-zero component positive
+        u = np.round(u, 9) + 0.0
+        first = np.argmax(np.abs(u) > 0, axis=1)
+        sign = np.sign(u[np.arange(len(u)), first])
+        u = u * sign[:, None]
+        rel = np.round(length / length.min(), 9)
+        key = np.column_stack([rel, u])
+        _, cls = np.unique(key, axis=0, return_inverse=True)
+        return cls.reshape(-1)
+
+    def refine(self):
+        """One uniform red refinement (Bey's rule: the inner octahedron is cut
+        along the diagonal x02-x13); new vertices are appended."""
+        edges, te = self._edges()
+        ne = len(edges)
+        nv = len(self.points)
+        ecls = self._edge_classes(edges)
+        mid = 0.5 * (self.points[edges[:, 0]] + self.points[edges[:, 1]])
+        order = np.lexsort((mid[:, 0], mid[:, 1], mid[:, 2], ecls))
+        rank = np.empty(ne, dtype=np.int64)
+        rank[order] = np.arange(ne)
+        new_id = nv + rank
+
+        self.points = np.vstack([self.points, mid[order]])
+        self.parents = np.vstack([self.parents, edges[order]])
+        self.vcolor = np.concatenate([self.vcolor, ecls[order]])
+        self.nverts.append(nv + ne)
+
+        t = self.tets
+        m = new_id[te]
+        x0, x1, x2, x3 = t[:, 0], t[:, 1], t[:, 2], t[:, 3]
+        x01, x02, x03, x12, x13, x23 = (m[:, k] for k in range(6))
+        self.tets = np.concatenate([
+            np.stack([x0, x01, x02, x03], 1),
+            np.stack([x01, x1, x12, x13], 1),
+            np.stack([x02, x12, x2, x23], 1),
+            np.stack([x03, x13, x23, x3], 1),
+            np.stack([x01, x02, x03, x13], 1),
+            np.stack([x01, x02, x12, x13], 1),
+            np.stack([x02, x03, x13, x23], 1),
+            np.stack([x02, x12, x13, x23], 1),
+        ])
+        self.boundary = self.boundary_fn(self.points)
+
+    @property
+    def cells(self):
+        return self.tets
+
+    @property
+    def nv(self):
+        return len(self.points)
+
+    @property
+    def J(self):
+        return len(self.nverts) - 1
+
+    def levels(self):
+        lv = np.zeros(self.nv, dtype=np.int64)
+        for l in range(1, len(self.nverts)):
+            lv[self.nverts[l - 1]:self.nverts[l]] = l
+        return lv
+
+
 def _on_box_boundary(lo, hi, eps=1e-12):
     def fn(p):
-        return ((np.abs(p[:, 0] - lo[0]) < eps) | (np.abs(p[:, 0] - hi[0]) < eps)
-                | (np.abs(p[:, 1] - lo[1]) < eps)
-                | (np.abs(p[:, 1] - hi[1]) < eps))
+        on = np.zeros(len(p), dtype=bool)
+        for k in range(len(lo)):
+            on |= (np.abs(p[:, k] - lo[k]) < eps) | (np.abs(p[:, k] - hi[k]) < eps)
+        return on
     return fn
 
 
@@ -213,6 +320,31 @@ def construct_2d_lshape_mesh(nrefines=1):
         return outer | inner
 
     mesh = TriangleMesh(pts, tris, bnd)
+    mesh.refine()
+    for _ in range(nrefines):
+        mesh.refine()
+    return mesh, "default"
+
+
+def construct_3d_cube_mesh(nrefines=1):
+    """Unit cube (reference mesh.py:33-43): the Kuhn triangulation (6 tetrahedra
+    around the space diagonal), refined once (the analogue of the Netgen-side
+    ``ngmesh.Refine()``) and then ``nrefines`` times.  Level 0 of the multigrid
+    hierarchy has 1 dof, the finest level (2^(nrefines+1) - 1)^3."""
+    import itertools
+    pts = np.array([[x, y, z] for z in (0., 1.) for y in (0., 1.)
+                    for x in (0., 1.)])
+    vid = lambda v: int(v[0] + 2 * v[1] + 4 * v[2])  # noqa: E731
+    tets = []
+    for perm in itertools.permutations(range(3)):
+        v = np.zeros(3, dtype=np.int64)
+        tet = [vid(v)]
+        for axis in perm:
+            v[axis] = 1
+            tet.append(vid(v))
+        tets.append(tet)
+    mesh = TetMesh(pts, np.array(tets),
+                   _on_box_boundary((0., 0., 0.), (1., 1., 1.)))
     mesh.refine()
     for _ in range(nrefines):
         mesh.refine()

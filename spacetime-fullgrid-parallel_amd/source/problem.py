@@ -3,13 +3,13 @@
 ``square``: u(t,x,y) = exp(-2 pi^2 t) sin(pi x) sin(pi y) on [0,1]^2, no forcing
 (problem.py:7-19).  ``lshape`` is not in the reference (anything but square /
 cube asserts there, problem.py:35-41); BASELINE.json config 4 names it, so it
-is defined here with the same data on the L-shaped domain.  ``cube`` needs a
-tetrahedral mesh generator and is not provided.
+is defined here with the same data on the L-shaped domain.  ``cube``:
+u = exp(-3 pi^2 t) sin(pi x) sin(pi y) sin(pi z) on [0,1]^3 (problem.py:21-32).
 """
 import numpy as np
 
 from .mesh import (construct_2d_lshape_mesh, construct_2d_square_mesh,
-                   construct_interval)
+                   construct_3d_cube_mesh, construct_interval)
 
 
 def _time_mesh(J_space, J_time):
@@ -34,10 +34,22 @@ def lshape(J_space, J_time=None):
     return mesh_space, bc, _time_mesh(J_space, J_time), data, "lshape"
 
 
+def _u0_3d(x, y, z):
+    return np.sin(np.pi * x) * np.sin(np.pi * y) * np.sin(np.pi * z)
+
+
+def cube(J_space, J_time=None):
+    mesh_space, bc = construct_3d_cube_mesh(nrefines=J_space)
+    data = {'g': [], 'u0': _u0_3d}
+    return mesh_space, bc, _time_mesh(J_space, J_time), data, "cube"
+
+
 def problem_helper(problem, J_space, J_time=None):
     if problem == 'square':
         return square(J_space, J_time)
     elif problem == 'lshape':
         return lshape(J_space, J_time)
+    elif problem == 'cube':
+        return cube(J_space, J_time)
     else:
         assert (False)

@@ -266,14 +266,18 @@ def test_heat_operators_and_solve_match_reference_golden(stk, g3, schur):
     assert np.allclose(lz.alpha[:n], g3['lz_alpha_multigrid'][:n], rtol=1e-7)
 
 
-def test_driver_end_to_end_against_oracle(stk):
+@pytest.mark.parametrize('problem,J_space', [('square', 4), ('lshape', 3),
+                                             ('cube', 2)])
+def test_driver_end_to_end_against_oracle(stk, problem, J_space):
     """heateq_mpi.HeatEquationMPI (build-owned assembly) versus the CPU oracle
-    on the same matrices: J_time = 4, J_space = 4 (N = 17, M = 961)."""
+    on the same matrices: J_time = 4 (N = 17); square M = 961, lshape M = 705,
+    cube M = 343 (15-point mass matrix: the K = 16 ELL width, 8 Gauss-Seidel
+    dependency levels)."""
     import heateq_mpi as hm
     from oracle.heat import HeatEquationOracle
     from oracle.krylov import pcg
     from source.linalg import PCG
-    h = hm.HeatEquationMPI(J_space=4, J_time=4)
+    h = hm.HeatEquationMPI(J_space=J_space, J_time=4, problem=problem)
     mats = dict(A_t=h.A_t, L_t=h.L_t, M_t=h.M_t, G_t=h.G_t, M_x=h.M_x,
                 A_x=h.A_x, P_mats=h.hierarchy.P_mats, u0_t=h.u0_t, u0_x=h.u0_x)
     o = HeatEquationOracle(mats, 4)

@@ -243,37 +243,44 @@ def test_pcg_and_lanczos_duck_typed_on_numpy():
 
 
 # ---- build-owned mesh and assembly -------------------------------------------------
-@pytest.mark.parametrize('name', ['square', 'lshape'])
+@pytest.mark.parametrize('name', ['square', 'lshape', 'cube'])
 def test_mesh_assembly_identities(name):
     from source.assembly import (prolongation_matrices, space_load,
                                  space_matrices, tile_row_order, time_matrices)
     from source.mesh import (construct_2d_lshape_mesh,
-                             construct_2d_square_mesh, construct_interval)
+                             construct_2d_square_mesh, construct_3d_cube_mesh,
+                             construct_interval)
     from source.multigrid import gauss_seidel_schedule
-    mk = construct_2d_square_mesh if name == 'square' else construct_2d_lshape_mesh
-    mesh, _ = mk(3)
+    mk = {'square': construct_2d_square_mesh, 'lshape': construct_2d_lshape_mesh,
+          'cube': construct_3d_cube_mesh}[name]
+    J = 2 if name == 'cube' else 3
+    mesh, _ = mk(J)
     M_x, A_x = space_matrices(mesh)
     n = M_x.shape[0]
     if name == 'square':
         assert n == (2**4 - 1)**2  # (2^(J+1) - 1)^2
+    if name == 'cube':
+        assert n == (2**3 - 1)**3
+        # the Kuhn mesh: 15-point mass matrix, 7-point stiffness matrix
+        assert np.diff(M_x.indptr).max() == 15 and np.diff(A_x.indptr).max() == 7
     assert M_x.dtype == np.float64 and M_x.indices.dtype == np.int32
     assert abs(M_x - M_x.T).max() < 1e-16 and abs(A_x - A_x.T).max() < 1e-13
     # mass matrix integrates: sum over free dofs of int phi_i phi_j <= area
-    area = 1.0 if name == 'square' else 3.0
+    area = 3.0 if name == 'lshape' else 1.0
     assert 0.5 * area < M_x.sum() < area
     # stiffness of interior rows away from the boundary sums to zero
-    assert np.sort(np.abs(A_x @ np.ones(n)))[n // 2] < 1e-12
+    assert np.sort(np.abs(A_x @ np.ones(n)))[n // 4] < 1e-12
     assert (np.linalg.eigvalsh(A_x.toarray())[0] > 0)
     # Galerkin products equal assembly on the coarser mesh
     # (reference multigrid_test.py:14-37)
     P = prolongation_matrices(mesh)
-    assert len(P) == 3 and P[-1].shape[0] == n
-    Mc, Ac = space_matrices(mk(2)[0])
+    assert len(P) == J and P[-1].shape[0] == n
+    Mc, Ac = space_matrices(mk(J - 1)[0])
     assert abs(P[-1].T @ A_x @ P[-1] - Ac).max() < 1e-13
     assert abs(P[-1].T @ M_x @ P[-1] - Mc).max() < 1e-15
     # numbering built for shallow Gauss-Seidel dependency DAGs
     ptr, _ = gauss_seidel_schedule(M_x.indptr, M_x.indices)
-    assert len(ptr) - 1 <= 5
+    assert len(ptr) - 1 <= (8 if name == 'cube' else 5)
     order = tile_row_order(mesh)
     assert sorted(order) == list(range(n))
     # time matrices: P1 on the uniform interval
@@ -289,6 +296,11 @@ def test_mesh_assembly_identities(name):
         b = space_load(mesh, u0)
         pts = mesh.points[~mesh.boundary]
         assert relerr(b, M_x @ u0(pts[:, 0], pts[:, 1])) < 2e-2
+    if name == 'cube':
+        u3 = lambda x, y, z: u0(x, y) * np.sin(np.pi * z)
+        b = space_load(mesh, u3)
+        pts = mesh.points[~mesh.boundary]
+        assert relerr(b, M_x @ u3(pts[:, 0], pts[:, 1], pts[:, 2])) < 5e-2
 
 
 def test_numbering_gives_shallow_gauss_seidel_schedules():
