@@ -27,30 +27,6 @@ namespace {
 #endif
 constexpr int BS = STK_ELL_BS;
 
-typedef int v4i __attribute__((ext_vector_type(4)));
-
-// 128-bit buffer descriptor over a whole array: gathers and stores then take a
-// 32-bit byte offset per lane (no 64-bit address arithmetic, fewer VGPRs).
-__device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void *base, uint32_t bytes)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
-}
-
-__device__ inline double2 buf_load2(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off)
-{
-    const v4i v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0);
-    double2 out;
-    __builtin_memcpy(&out, &v, 16);
-    return out;
-}
-
-__device__ inline void buf_store2(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off, double2 val)
-{
-    v4i v;
-    __builtin_memcpy(&v, &val, 16);
-    __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, 0);
-}
-
 template <int NT>
 struct EllArgs {
     const int32_t *ell_idx;     // [M][K] column of every slot
@@ -69,16 +45,19 @@ struct EllArgs {
     int32_t has_lo, has_hi, any_tri;
     int32_t P, W, R;
     int32_t ngroups, chunk;  // groups in total / per XCD
-    uint32_t vec_bytes;      // M * ld * 8
+    uint32_t vec_bytes;      // M * ld * 8 (0 when wide)
+    int32_t wide;            // slab of 4 GiB or more: 64-bit addressing
 };
 
 // K: slots per row (compile time).  NPF: ELL elements each thread prefetches
 // per array and group, NPF * BS >= R * K.
 // GENERIC = false compiles the ghost-lane and overflow paths out (single slab, no
 // row longer than K): the common case runs without their branches.
-template <int NT, bool SHARED_IN, int K, int NPF, bool GENERIC>
+// WIDE (with GENERIC only): slabs of 4 GiB and more, see stk_slab.
+template <int NT, bool SHARED_IN, int K, int NPF, bool GENERIC, bool WIDE>
 __global__ __launch_bounds__(BS, 6 * 512 / BS > 8 ? 8 : 6) void kron_ell_kernel(const EllArgs<NT> a)
 {
+    static_assert(GENERIC || !WIDE, "the fast path is for slabs below 4 GiB");
     const int has_lo = GENERIC ? a.has_lo : 0, has_hi = GENERIC ? a.has_hi : 0;
     constexpr int KS = (K + 3) & ~3;  // LDS stride of a row's slots (16-byte vectors)
     extern __shared__ double sm[];
@@ -101,12 +80,12 @@ __global__ __launch_bounds__(BS, 6 * 512 / BS > 8 ? 8 : 6) void kron_ell_kernel(
     const int t0 = 2 * p;
     const bool has1 = t0 + 1 < a.n_loc;
     const bool ghosts = has_lo || has_hi;
-    const uint32_t ld_bytes = (uint32_t)a.ld * 8u;
+    const uint32_t ld_bytes = stk_slab<WIDE>::row_stride(a.ld);  // row stride in offset units
     const uint32_t t0_bytes = (uint32_t)t0 * 8u;
-    __amdgpu_buffer_rsrc_t rs_x[NT];
+    stk_slab<WIDE> sx[NT];
 #pragma unroll
-    for (int k = 0; k < NT; ++k) rs_x[k] = make_rsrc(a.x[k], a.vec_bytes);
-    const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(a.y, a.vec_bytes);
+    for (int k = 0; k < NT; ++k) sx[k] = stk_slab<WIDE>(a.x[k], a.vec_bytes);
+    const stk_slab<WIDE> sy(a.y, a.vec_bytes);
 
     if (a.any_tri) {
         for (int i = threadIdx.x; i < NT * 3 * LT; i += BS) {
@@ -193,7 +172,7 @@ __global__ __launch_bounds__(BS, 6 * 512 / BS > 8 ? 8 : 6) void kron_ell_kernel(
         const int pos = g * R + r;
         // read now: s_row is rewritten at the top of the next iteration, which a
         // fast wave reaches while a slow one is still storing
-        const uint32_t yo = (rowok ? s_row[r] : 0u) + t0_bytes;
+        const uint32_t yo = rowok ? s_row[r] : 0u;
         double acc0[NT], acc1[NT];
 #pragma unroll
         for (int k = 0; k < NT; ++k) acc0[k] = acc1[k] = 0.0;
@@ -202,11 +181,11 @@ __global__ __launch_bounds__(BS, 6 * 512 / BS > 8 ? 8 : 6) void kron_ell_kernel(
             const uint32_t *so = s_off + r * KS;
             uint32_t off[K];
 #pragma unroll
-            for (int u = 0; u < K; ++u) off[u] = so[u] + t0_bytes;
+            for (int u = 0; u < K; ++u) off[u] = so[u];
             if (SHARED_IN) {
                 double2 xv[K];
 #pragma unroll
-                for (int u = 0; u < K; ++u) xv[u] = buf_load2(rs_x[0], off[u]);
+                for (int u = 0; u < K; ++u) xv[u] = sx[0].load(off[u], t0_bytes);
 #pragma unroll
                 for (int k = 0; k < NT; ++k) {
                     const double *sv = s_val + (k * R + r) * KS;
@@ -223,7 +202,7 @@ __global__ __launch_bounds__(BS, 6 * 512 / BS > 8 ? 8 : 6) void kron_ell_kernel(
                     const double *sv = s_val + (k * R + r) * KS;
                     double2 xv[K];
 #pragma unroll
-                    for (int u = 0; u < K; ++u) xv[u] = buf_load2(rs_x[k], off[u]);
+                    for (int u = 0; u < K; ++u) xv[u] = sx[k].load(off[u], t0_bytes);
 #pragma unroll
                     for (int u = 0; u < K; ++u) {
                         const double v = sv[u];
@@ -316,28 +295,29 @@ __global__ __launch_bounds__(BS, 6 * 512 / BS > 8 ? 8 : 6) void kron_ell_kernel(
         if (rowok && is_pair) {
             if (!has1) y1 = 0.0;  // padding slot stays zero
             if (a.beta != 0.0) {
-                const double2 old = buf_load2(rs_y, yo);
+                const double2 old = sy.load(yo, t0_bytes);
                 y0 = fma(a.beta, old.x, y0);
                 if (has1) y1 = fma(a.beta, old.y, y1);
             }
-            buf_store2(rs_y, yo, make_double2(y0, y1));
+            sy.store(yo, t0_bytes, make_double2(y0, y1));
         }
     }
 }
 
 int g_ell_wg_per_cu = 0;
+int g_ell_force_wide = 0;     // testing: 64-bit addressing on small slabs
 int g_ell_force_generic = 0;  // benchmarking: run the generic kernel even when the fast path applies
 
-template <int NT, bool SHARED_IN, int K, bool GENERIC>
+template <int NT, bool SHARED_IN, int K, bool GENERIC, bool WIDE = false>
 int launch4(hipStream_t st, const EllArgs<NT> &a, unsigned grid, size_t lds)
 {
     const int npf = (a.R * K + BS - 1) / BS;
     if (npf <= 1)
-        hipLaunchKernelGGL((kron_ell_kernel<NT, SHARED_IN, K, 1, GENERIC>), dim3(grid), dim3(BS), lds, st, a);
+        hipLaunchKernelGGL((kron_ell_kernel<NT, SHARED_IN, K, 1, GENERIC, WIDE>), dim3(grid), dim3(BS), lds, st, a);
     else if (npf <= 2)
-        hipLaunchKernelGGL((kron_ell_kernel<NT, SHARED_IN, K, 2, GENERIC>), dim3(grid), dim3(BS), lds, st, a);
+        hipLaunchKernelGGL((kron_ell_kernel<NT, SHARED_IN, K, 2, GENERIC, WIDE>), dim3(grid), dim3(BS), lds, st, a);
     else if (npf <= 4)
-        hipLaunchKernelGGL((kron_ell_kernel<NT, SHARED_IN, K, 4, GENERIC>), dim3(grid), dim3(BS), lds, st, a);
+        hipLaunchKernelGGL((kron_ell_kernel<NT, SHARED_IN, K, 4, GENERIC, WIDE>), dim3(grid), dim3(BS), lds, st, a);
     else {
         stk_set_error("stk_kron_ell_apply: %d slots per row with %d lanes per row not supported", K, a.W);
         return 2;
@@ -349,6 +329,7 @@ int launch4(hipStream_t st, const EllArgs<NT> &a, unsigned grid, size_t lds)
 template <int NT, bool SHARED_IN, int K>
 int launch3(hipStream_t st, const EllArgs<NT> &a, unsigned grid, size_t lds)
 {
+    if (a.wide) return launch4<NT, SHARED_IN, K, true, true>(st, a, grid, lds);
     const bool generic = a.has_lo || a.has_hi || a.ovf_indptr != nullptr || g_ell_force_generic;
     return generic ? launch4<NT, SHARED_IN, K, true>(st, a, grid, lds)
                    : launch4<NT, SHARED_IN, K, false>(st, a, grid, lds);
@@ -362,7 +343,8 @@ int launch2(hipStream_t st, const EllArgs<NT> &a_in, int K)
     if (a.R * K > 4 * BS) a.R = 4 * BS / K;  // at most 4 prefetched entries per thread
     a.ngroups = (a.M + a.R - 1) / a.R;
     a.chunk = (a.ngroups + 7) / 8;
-    a.vec_bytes = (uint32_t)((int64_t)a.M * a.ld * 8);
+    a.wide = g_ell_force_wide || (int64_t)a.M * a.ld * 8 >= ((int64_t)1 << 32);
+    a.vec_bytes = a.wide ? 0u : (uint32_t)((int64_t)a.M * a.ld * 8);
     const int KS = (K + 3) & ~3;
     const size_t lds = sizeof(double) * ((a.any_tri ? (size_t)NT * a.R * (a.n_loc + 3) : 0) +
                                           (size_t)NT * a.R * KS) +
@@ -430,6 +412,10 @@ int dispatch(hipStream_t st, const stk_ell_pattern *pat, int32_t n_loc, int32_t 
 
 int stk_kron_ell_set_tuning(const char *key, int32_t value)
 {
+    if (std::strcmp(key, "ell_force_wide") == 0) {
+        g_ell_force_wide = value;
+        return 0;
+    }
     if (std::strcmp(key, "ell_force_generic") == 0) {
         g_ell_force_generic = value;
         return 0;
@@ -453,9 +439,9 @@ extern "C" int stk_kron_ell_apply(void *stream, const stk_ell_pattern *pat, int3
                 "stk_kron_ell_apply: bad sizes n_loc=%d ld=%d (ld must be even)", n_loc, ld);
     STK_REQUIRE(n_terms >= 1 && n_terms <= 3, "stk_kron_ell_apply: n_terms=%d not in 1..3", n_terms);
     STK_REQUIRE((n_loc + 1) / 2 + 2 <= BS, "stk_kron_ell_apply: n_loc=%d too large", n_loc);
-    STK_REQUIRE((int64_t)pat->M * ld * 8 < ((int64_t)1 << 32),
-                "stk_kron_ell_apply: slab of %lld bytes exceeds the 4 GiB buffer-descriptor range; use "
-                "stk_kron_sum_apply", (long long)pat->M * ld * 8);
+    STK_REQUIRE((int64_t)pat->M * ld * 8 < ((int64_t)1 << 36),
+                "stk_kron_ell_apply: slab of %lld bytes exceeds 64 GiB; use stk_kron_sum_apply",
+                (long long)pat->M * ld * 8);
     STK_REQUIRE(((uintptr_t)y & 15) == 0, "stk_kron_ell_apply: y must be 16-byte aligned");
     for (int k = 0; k < n_terms; ++k) {
         STK_REQUIRE(t[k].ell_vals && t[k].x, "stk_kron_ell_apply: term %d has null vals/x", k);

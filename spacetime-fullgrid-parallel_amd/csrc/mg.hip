@@ -126,12 +126,18 @@ struct stk_mg {
     int Lc = -1;
 };
 
+// The ELL row engine needs 16-byte time pairs (even ld) and slabs below 64 GiB.
+static inline bool ell_slab_ok(int64_t rows, int ld)
+{
+    return (ld & 1) == 0 && rows * ld * 8 < ((int64_t)1 << 36);
+}
+
 static int smooth_level(stk_mg *mg, hipStream_t st, int level, int n_loc, int ld, double ca, const double *cm,
                         int its, bool backward, const double *f, double *u)
 {
     const stk_mg_level &L = mg->lv[level];
     const EllLevel &E = mg->ell[level];
-    if (E.has_gs && (ld & 1) == 0) {
+    if (E.has_gs && ell_slab_ok(L.n, ld)) {
         const stk_ell_rows &e = backward ? E.bwd : E.fwd;
         const std::vector<int32_t> &pos = backward ? E.bwd_pos : E.fwd_pos;
         for (int it = 0; it < its; ++it)
@@ -180,7 +186,7 @@ static int mgm(stk_mg *mg, hipStream_t st, int j, int n_loc, int ld, double ca, 
     const stk_mg_level &C = mg->lv[j - 1];
     double *r_j = mg->r[j], *d_c = mg->f[j - 1], *u_c = mg->u[j - 1];
     const EllLevel &E = mg->ell[j];
-    const bool even = (ld & 1) == 0;
+    const bool even = ell_slab_ok(L.n, ld);
     // r_j = A_j u_j - f_j
     if (E.has_a && even)
         rc = stk_rows_ell_launch(st, 0, &E.a, 0, E.a.n_pos, n_loc, ld, L.n, L.n, ca, cm, u_j, 1.0, -1.0, f_j, r_j);

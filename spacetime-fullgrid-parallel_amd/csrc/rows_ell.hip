@@ -22,28 +22,6 @@ namespace {
 constexpr int BS = 512;
 enum { MODE_SPMM = 0, MODE_GS = 1 };
 
-typedef int v4i __attribute__((ext_vector_type(4)));
-
-__device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void *base, uint32_t bytes)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
-}
-
-__device__ inline double2 buf_load2(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off)
-{
-    const v4i v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0);
-    double2 out;
-    __builtin_memcpy(&out, &v, 16);
-    return out;
-}
-
-__device__ inline void buf_store2(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off, double2 val)
-{
-    v4i v;
-    __builtin_memcpy(&v, &val, 16);
-    __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, 0);
-}
-
 struct RowsArgs {
     const int32_t *idx;      // [n_pos][K]
     const double *va, *vm;   // [n_pos][K]
@@ -59,9 +37,10 @@ struct RowsArgs {
     int32_t ngroups, chunk;
     int32_t reverse;  // walk the row groups of every XCD chunk backwards
     uint32_t x_bytes, y_bytes;
+    int32_t wide;  // a slab of 4 GiB or more: 64-bit addressing
 };
 
-template <int MODE, int K, int NPF, bool HAS_M>
+template <int MODE, int K, int NPF, bool HAS_M, bool WIDE>
 __global__ __launch_bounds__(BS, 6) void rows_ell_kernel(const RowsArgs a)
 {
     constexpr int KS = (K + 3) & ~3;
@@ -75,11 +54,9 @@ __global__ __launch_bounds__(BS, 6) void rows_ell_kernel(const RowsArgs a)
     const bool lane_ok = r < R;
     const int t0 = 2 * p;
     const bool has1 = t0 + 1 < a.n_loc;
-    const uint32_t ld_bytes = (uint32_t)a.ld * 8u;
+    const uint32_t ld_bytes = stk_slab<WIDE>::row_stride(a.ld);  // row stride in offset units
     const uint32_t t0_bytes = (uint32_t)t0 * 8u;
-    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(a.x, a.x_bytes);
-    const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(a.y, a.y_bytes);
-    const __amdgpu_buffer_rsrc_t rs_z = make_rsrc(a.z, a.y_bytes);
+    const stk_slab<WIDE> sx(a.x, a.x_bytes), sy(a.y, a.y_bytes), sz(a.z, a.y_bytes);
 
     double cm0 = 0.0, cm1 = 0.0;
     if (HAS_M && lane_ok) {
@@ -169,16 +146,16 @@ __global__ __launch_bounds__(BS, 6) void rows_ell_kernel(const RowsArgs a)
             const uint32_t *so = b_off + r * KS;
             const double *sva = b_va + r * KS;
             const double *svm = b_vm + r * KS;
-            const uint32_t yo = b_row[r] + t0_bytes;
+            const uint32_t yo = b_row[r];
             double2 xv[K];
 #pragma unroll
-            for (int u = 0; u < K; ++u) xv[u] = buf_load2(rs_x, so[u] + t0_bytes);
+            for (int u = 0; u < K; ++u) xv[u] = sx.load(so[u], t0_bytes);
             double2 zv = make_double2(0.0, 0.0), own = make_double2(0.0, 0.0);
             if (MODE == MODE_GS) {
-                zv = buf_load2(rs_z, yo);
-                own = buf_load2(rs_x, yo);
+                zv = sz.load(yo, t0_bytes);
+                own = sx.load(yo, t0_bytes);
             } else if (a.beta != 0.0) {
-                zv = buf_load2(rs_z, yo);
+                zv = sz.load(yo, t0_bytes);
             }
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll
@@ -211,31 +188,39 @@ __global__ __launch_bounds__(BS, 6) void rows_ell_kernel(const RowsArgs a)
                 }
             }
             if (!has1) o1 = 0.0;  // padding slot stays zero
-            buf_store2(rs_y, yo, make_double2(o0, o1));
+            sy.store(yo, t0_bytes, make_double2(o0, o1));
         }
     }
 }
 
 int g_rows_wg_per_cu = 0;
+int g_rows_force_wide = 0;  // testing: 64-bit addressing on small slabs
 int g_rows_alternate = 1;   // alternate the walking direction between launches
 unsigned g_rows_launch_count = 0;
 
-template <int MODE, int K, bool HAS_M>
-int launch_npf(hipStream_t st, const RowsArgs &a, unsigned grid, size_t lds)
+template <int MODE, int K, bool HAS_M, bool WIDE>
+int launch_npf_w(hipStream_t st, const RowsArgs &a, unsigned grid, size_t lds)
 {
     const int npf = (a.R * K + BS - 1) / BS;
     if (npf <= 1)
-        hipLaunchKernelGGL((rows_ell_kernel<MODE, K, 1, HAS_M>), dim3(grid), dim3(BS), lds, st, a);
+        hipLaunchKernelGGL((rows_ell_kernel<MODE, K, 1, HAS_M, WIDE>), dim3(grid), dim3(BS), lds, st, a);
     else if (npf <= 2)
-        hipLaunchKernelGGL((rows_ell_kernel<MODE, K, 2, HAS_M>), dim3(grid), dim3(BS), lds, st, a);
+        hipLaunchKernelGGL((rows_ell_kernel<MODE, K, 2, HAS_M, WIDE>), dim3(grid), dim3(BS), lds, st, a);
     else if (npf <= 4)
-        hipLaunchKernelGGL((rows_ell_kernel<MODE, K, 4, HAS_M>), dim3(grid), dim3(BS), lds, st, a);
+        hipLaunchKernelGGL((rows_ell_kernel<MODE, K, 4, HAS_M, WIDE>), dim3(grid), dim3(BS), lds, st, a);
     else {
         stk_set_error("rows_ell: %d slots per row with %d lanes per row not supported", K, a.P);
         return 2;
     }
     STK_LAUNCH_CHECK();
     return 0;
+}
+
+template <int MODE, int K, bool HAS_M>
+int launch_npf(hipStream_t st, const RowsArgs &a, unsigned grid, size_t lds)
+{
+    return a.wide ? launch_npf_w<MODE, K, HAS_M, true>(st, a, grid, lds)
+                  : launch_npf_w<MODE, K, HAS_M, false>(st, a, grid, lds);
 }
 
 template <int MODE, bool HAS_M>
@@ -257,6 +242,10 @@ int launch_k(hipStream_t st, const RowsArgs &a, int K, unsigned grid, size_t lds
 
 int stk_rows_ell_set_tuning(const char *key, int32_t value)
 {
+    if (std::strcmp(key, "rows_force_wide") == 0) {
+        g_rows_force_wide = value;
+        return 0;
+    }
     if (std::strcmp(key, "rows_alternate") == 0) {
         g_rows_alternate = value;
         return 0;
@@ -278,8 +267,8 @@ int stk_rows_ell_launch(hipStream_t st, int mode, const stk_ell_rows *e, int32_t
     STK_REQUIRE((cm == nullptr) || e->vm, "rows_ell: cm given but the matrix has no vm");
     STK_REQUIRE(n_loc > 0 && ld >= n_loc && (ld & 1) == 0, "rows_ell: bad n_loc=%d ld=%d (ld must be even)", n_loc,
                 ld);
-    STK_REQUIRE(x_rows * ld * 8 < ((int64_t)1 << 32) && y_rows * ld * 8 < ((int64_t)1 << 32),
-                "rows_ell: slab exceeds the 4 GiB buffer-descriptor range");
+    STK_REQUIRE(x_rows * ld * 8 < ((int64_t)1 << 36) && y_rows * ld * 8 < ((int64_t)1 << 36),
+                "rows_ell: slab exceeds 64 GiB");
     STK_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)z) & 15) == 0, "rows_ell: slabs must be 16-byte aligned");
     STK_REQUIRE((n_loc + 1) / 2 <= BS, "rows_ell: n_loc too large");
     RowsArgs a;
@@ -306,8 +295,9 @@ int stk_rows_ell_launch(hipStream_t st, int mode, const stk_ell_rows *e, int32_t
     a.ngroups = (pos_end - pos_begin + a.R - 1) / a.R;
     a.chunk = (a.ngroups + 7) / 8;
     a.reverse = g_rows_alternate ? (int)(g_rows_launch_count++ & 1u) : 0;
-    a.x_bytes = (uint32_t)(x_rows * ld * 8);
-    a.y_bytes = (uint32_t)(y_rows * ld * 8);
+    a.wide = g_rows_force_wide || x_rows * ld * 8 >= ((int64_t)1 << 32) || y_rows * ld * 8 >= ((int64_t)1 << 32);
+    a.x_bytes = a.wide ? 0u : (uint32_t)(x_rows * ld * 8);
+    a.y_bytes = a.wide ? 0u : (uint32_t)(y_rows * ld * 8);
     if (mode == MODE_GS) STK_REQUIRE(e->dia_a && (!cm || e->dia_m), "rows_ell: GS needs the diagonal arrays");
     const int K = e->K;
     const int KS = (K + 3) & ~3;

@@ -39,3 +39,61 @@ static inline unsigned stk_flat_grid(int64_t work_items, int block, int per_thre
     const int64_t cap = 256 * 16;
     return (unsigned)(blocks < cap ? blocks : cap);
 }
+
+// ---- slab access from device code (kron_ell.hip, rows_ell.hip, mg_coarse.hip) -----
+#if defined(__HIPCC__)
+typedef int stk_v4i __attribute__((ext_vector_type(4)));
+
+// 128-bit buffer descriptor over a whole array: gathers and stores then take a
+// 32-bit byte offset per lane (no 64-bit address arithmetic, fewer VGPRs).
+__device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void *base, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
+
+__device__ inline double2 buf_load2(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off)
+{
+    const stk_v4i v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0);
+    double2 out;
+    __builtin_memcpy(&out, &v, 16);
+    return out;
+}
+
+__device__ inline void buf_store2(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off, double2 val)
+{
+    stk_v4i v;
+    __builtin_memcpy(&v, &val, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, 0);
+}
+
+// A slab x[row*ld + t] as a kernel sees it; a lane moves one pair of time steps.
+// WIDE = false: buffer descriptor, row offsets are 32-bit BYTE offsets (slabs
+// below 4 GiB).  WIDE = true: row offsets count 16-byte units and are widened
+// to 64-bit addresses (slabs up to 64 GiB; costs address VGPRs).
+template <bool WIDE>
+struct stk_slab {
+    __amdgpu_buffer_rsrc_t rs;
+    const char *base;
+    __device__ stk_slab() : base(nullptr) {}
+    __device__ stk_slab(const void *ptr, uint32_t bytes)
+        : rs(make_rsrc(ptr, bytes)), base(static_cast<const char *>(ptr))
+    {
+    }
+    // units of a row offset per row
+    __device__ static inline uint32_t row_stride(int ld) { return WIDE ? ((uint32_t)ld * 8u) >> 4 : (uint32_t)ld * 8u; }
+    __device__ inline double2 load(uint32_t row_off, uint32_t t_bytes) const
+    {
+        if constexpr (WIDE)
+            return *reinterpret_cast<const double2 *>(base + (((size_t)row_off) << 4) + t_bytes);
+        else
+            return buf_load2(rs, row_off + t_bytes);
+    }
+    __device__ inline void store(uint32_t row_off, uint32_t t_bytes, double2 v) const
+    {
+        if constexpr (WIDE)
+            *reinterpret_cast<double2 *>(const_cast<char *>(base) + (((size_t)row_off) << 4) + t_bytes) = v;
+        else
+            buf_store2(rs, row_off + t_bytes, v);
+    }
+};
+#endif

@@ -486,3 +486,29 @@ def test_midsize_solve_matches_oracle_fixture(stk):
     wn = _np(w)
     assert abs(np.linalg.norm(wn) - g['w_norm']) < 1e-9 * g['w_norm']
     assert relerr(wn[::4, ::97], g['w_sample']) < 1e-8
+
+
+def test_wide_slab_addressing_matches(stk):
+    """Slabs of 4 GiB and more use 64-bit addressing inside the ELL kernels
+    (stk_slab<true>).  Forced here on a small problem: S, P and the solve are
+    the same as with the buffer-descriptor path."""
+    import heateq_mpi as hm
+    from source.linalg import PCG
+    h = hm.HeatEquationMPI(J_space=3, J_time=3)
+    X = np.random.RandomState(5).rand(h.N, h.M)
+    x = _vec(h.dofs_distr, X)
+    ref = [_np(h.S @ x), _np(h.P @ x)]
+    hist0 = []
+    w0, it0 = PCG(h.WT_S_W, h.P, h.rhs, history=hist0)
+    try:
+        for key in (b'ell_force_wide', b'rows_force_wide'):
+            stk.check(stk.lib().stk_set_tuning(key, 1))
+        assert relerr(_np(h.S @ x), ref[0]) < 1e-14
+        assert relerr(_np(h.P @ x), ref[1]) < 1e-14
+        hist = []
+        w, it = PCG(h.WT_S_W, h.P, h.rhs, history=hist)
+        assert it == it0 and np.allclose(hist, hist0, rtol=1e-10, atol=1e-30)
+        assert relerr(_np(w), _np(w0)) < 1e-12
+    finally:
+        for key in (b'ell_force_wide', b'rows_force_wide'):
+            stk.check(stk.lib().stk_set_tuning(key, 0))
