@@ -89,21 +89,6 @@ int stk_rows_ell_launch(hipStream_t st, int mode, const stk_ell_rows *e, int32_t
                         int32_t n_loc, int32_t ld, int64_t x_rows, int64_t y_rows, double ca, const double *cm,
                         const double *x, double alpha, double beta, const double *z, double *y);
 
-// mg_coarse.hip: the sub-V-cycle below a cut level as one launch
-struct stk_coarse_plan;
-struct stk_coarse_level {
-    int n;
-    bool ok;
-    stk_ell_rows a, fwd, bwd, p, r;
-    const int32_t *fwd_pos, *bwd_pos;
-    int n_fwd, n_bwd;
-    double *u, *f, *res;
-};
-stk_coarse_plan *stk_coarse_plan_build(const stk_coarse_level *lv, int Lc, int smoothsteps);
-void stk_coarse_plan_free(stk_coarse_plan *p);
-int stk_coarse_plan_run(const stk_coarse_plan *p, hipStream_t st, int n_loc, int ld, double ca, const double *cm,
-                        const int32_t *kind, const double *coarse_inv);
-
 int g_mg_fuse_coarse = 1;       // 0 disables the fused coarse sub-V-cycle
 int g_mg_coarse_max_rows = 1024;  // levels up to this many rows are fused (larger ones fill the GPU by themselves)
 

@@ -32,12 +32,17 @@ struct Job {
     double *y;
     double alpha, beta;
     int32_t use_m;     // entries are ca*va + cm[t]*vm (level matrices) or plain va (transfers)
-    int32_t pad;
+    int32_t lx, lz, ly;  // the same three vectors as row offsets into the LDS arena (LDS variant)
 };
 
 struct CoarseArgs {
     const Job *jobs;
     int32_t n_jobs;
+    // LDS variant: arena of lds_rows double2 rows; f of the cut level comes from /
+    // u of the cut level goes to global memory, everything else stays in LDS
+    int32_t lds_rows, top_n, top_lu, top_lf;
+    const double *top_f;
+    double *top_u;
     int32_t n_loc, ld;
     int32_t pairs_per_wg;
     double ca;
@@ -115,6 +120,128 @@ __device__ inline void run_rows_job(const Job &j, const CoarseArgs &a, int p0, i
     }
 }
 
+// LDS variant of run_rows_job: one time pair per workgroup, every vector of the
+// sub-V-cycle lives in the LDS arena sv (one double2 per row).
+template <int K, bool HAS_M>
+__device__ inline void run_rows_job_lds(const Job &j, const CoarseArgs &a, double2 *sv, double cm0, double cm1,
+                                        bool has1)
+{
+    const int nrows = j.pos_end - j.pos_begin;
+    const bool use_m = HAS_M && j.use_m;
+    const double ca = j.use_m ? a.ca : 1.0;
+    const double2 *vx = sv + j.lx;
+    for (int r = threadIdx.x; r < nrows; r += CBS) {
+        const int pos = j.pos_begin + r;
+        const size_t e0 = (size_t)pos * K;
+        const int row = j.row_ids ? j.row_ids[pos] : pos;
+        int col[K];
+        double va[K], vm[K];
+#pragma unroll
+        for (int u = 0; u < K; ++u) col[u] = j.idx[e0 + u];
+#pragma unroll
+        for (int u = 0; u < K; ++u) va[u] = j.va[e0 + u];
+        if (use_m) {
+#pragma unroll
+            for (int u = 0; u < K; ++u) vm[u] = j.vm[e0 + u];
+        }
+        double da = 0.0, dm = 0.0;
+        if (j.kind == JOB_GS) {
+            da = j.dia_a[pos];
+            if (use_m) dm = j.dia_m[pos];
+        }
+        double2 xv[K];
+#pragma unroll
+        for (int u = 0; u < K; ++u) xv[u] = vx[col[u]];
+        double2 zv = make_double2(0.0, 0.0), own = make_double2(0.0, 0.0);
+        if (j.kind == JOB_GS) {
+            zv = sv[j.lz + row];
+            own = vx[row];
+        } else if (j.beta != 0.0) {
+            zv = sv[j.lz + row];
+        }
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            double v0 = ca * va[u], v1 = v0;
+            if (use_m) {
+                v0 = fma(cm0, vm[u], v0);
+                v1 = fma(cm1, vm[u], v1);
+            }
+            s0 = fma(v0, xv[u].x, s0);
+            s1 = fma(v1, xv[u].y, s1);
+        }
+        double o0, o1;
+        if (j.kind == JOB_GS) {
+            double d0 = ca * da, d1 = d0;
+            if (use_m) {
+                d0 = fma(cm0, dm, d0);
+                d1 = fma(cm1, dm, d1);
+            }
+            o0 = own.x + (1.0 / d0) * (zv.x - s0);
+            o1 = own.y + (1.0 / d1) * (zv.y - s1);
+        } else {
+            o0 = j.alpha * s0;
+            o1 = j.alpha * s1;
+            if (j.beta != 0.0) {
+                o0 = fma(j.beta, zv.x, o0);
+                o1 = fma(j.beta, zv.y, o1);
+            }
+        }
+        if (!has1) o1 = 0.0;  // padding slot stays zero
+        sv[j.ly + row] = make_double2(o0, o1);
+    }
+}
+
+template <bool HAS_M>
+__global__ __launch_bounds__(CBS) void mg_coarse_lds_kernel(const CoarseArgs a)
+{
+    extern __shared__ double2 sv[];
+    const int t0 = 2 * (int)blockIdx.x;
+    const bool has1 = t0 + 1 < a.n_loc;
+    double cm0 = 0.0, cm1 = 0.0;
+    if (HAS_M) {
+        cm0 = a.cm[t0];
+        if (has1) cm1 = a.cm[t0 + 1];
+    }
+    for (int r = threadIdx.x; r < a.top_n; r += CBS) {
+        sv[a.top_lf + r] = *reinterpret_cast<const double2 *>(a.top_f + (size_t)r * a.ld + t0);
+        sv[a.top_lu + r] = make_double2(0.0, 0.0);  // MGM starts from zero (multigrid.py:176)
+    }
+    __syncthreads();
+    for (int jn = 0; jn < a.n_jobs; ++jn) {
+        const Job j = a.jobs[jn];
+        if (j.kind == JOB_ZERO) {
+            for (int r = threadIdx.x; r < j.pos_end; r += CBS) sv[j.ly + r] = make_double2(0.0, 0.0);
+        } else if (j.kind == JOB_COARSE) {
+            const int n0 = j.pos_end;
+            for (int i = threadIdx.x; i < n0; i += CBS) {
+                const double *A0 = a.coarse_inv + (size_t)(a.kind ? a.kind[t0] : 0) * n0 * n0 + (size_t)i * n0;
+                const double *A1 =
+                    a.coarse_inv + (size_t)((a.kind && has1) ? a.kind[t0 + 1] : 0) * n0 * n0 + (size_t)i * n0;
+                double s0 = 0.0, s1 = 0.0;
+                for (int c = 0; c < n0; ++c) {
+                    const double2 fv = sv[j.lz + c];
+                    s0 = fma(A0[c], fv.x, s0);
+                    s1 = fma(A1[c], fv.y, s1);
+                }
+                sv[j.ly + i] = make_double2(a.coarse_scale * s0, has1 ? a.coarse_scale * s1 : 0.0);
+            }
+        } else {
+            switch (j.K) {
+                case 2: run_rows_job_lds<2, HAS_M>(j, a, sv, cm0, cm1, has1); break;
+                case 5: run_rows_job_lds<5, HAS_M>(j, a, sv, cm0, cm1, has1); break;
+                case 7: run_rows_job_lds<7, HAS_M>(j, a, sv, cm0, cm1, has1); break;
+                case 9: run_rows_job_lds<9, HAS_M>(j, a, sv, cm0, cm1, has1); break;
+                case 12: run_rows_job_lds<12, HAS_M>(j, a, sv, cm0, cm1, has1); break;
+                default: run_rows_job_lds<16, HAS_M>(j, a, sv, cm0, cm1, has1); break;
+            }
+        }
+        __syncthreads();
+    }
+    for (int r = threadIdx.x; r < a.top_n; r += CBS)
+        *reinterpret_cast<double2 *>(a.top_u + (size_t)r * a.ld + t0) = sv[a.top_lu + r];
+}
+
 template <bool HAS_M>
 __global__ __launch_bounds__(CBS) void mg_coarse_kernel(const CoarseArgs a)
 {
@@ -166,13 +293,18 @@ __global__ __launch_bounds__(CBS) void mg_coarse_kernel(const CoarseArgs a)
 
 }  // namespace
 
-int g_mg_coarse_pairs = 0;  // time pairs per workgroup (0 = default)
+int g_mg_coarse_pairs = 0;  // time pairs per workgroup (0 = default: 1, vectors resident in LDS)
+int g_mg_coarse_lds = 1;    // 0: keep the level vectors in global memory
 
 // Host side: the job list of MGM(Lc, u_Lc, f_Lc) and its launcher (used by mg.hip).
 struct stk_coarse_plan {
     std::vector<Job> host_jobs;
     Job *dev_jobs = nullptr;
     int n_jobs = 0;
+    // LDS arena: rows of u, f, res of every level 0..Lc
+    int lds_rows = 0, top_n = 0, top_lu = 0, top_lf = 0;
+    const double *top_f = nullptr;
+    double *top_u = nullptr;
 };
 
 void stk_coarse_plan_free(stk_coarse_plan *p)
@@ -202,19 +334,9 @@ static Job rows_job(int kind, const stk_ell_rows &e, int pos_begin, int pos_end,
     j.alpha = alpha;
     j.beta = beta;
     j.use_m = level_matrix ? 1 : 0;
-    j.pad = 0;
+    j.lx = j.lz = j.ly = -1;
     return j;
 }
-
-// Description of one level handed over by mg.hip.
-struct stk_coarse_level {
-    int n;
-    bool ok;  // all sliced-ELL pieces present
-    stk_ell_rows a, fwd, bwd, p, r;
-    const int32_t *fwd_pos, *bwd_pos;
-    int n_fwd, n_bwd;
-    double *u, *f, *res;  // workspaces of this level
-};
 
 stk_coarse_plan *stk_coarse_plan_build(const stk_coarse_level *lv, int Lc, int smoothsteps)
 {
@@ -245,7 +367,8 @@ stk_coarse_plan *stk_coarse_plan_build(const stk_coarse_level *lv, int Lc, int s
         z.row_ids = nullptr;
         z.y = C.u;
         z.alpha = z.beta = 0.0;
-        z.use_m = z.pad = 0;
+        z.use_m = 0;
+        z.lx = z.lz = z.ly = -1;
         if (j - 1 >= 1) J.push_back(z);  // level 0 is overwritten by the exact solve
     }
     {
@@ -260,13 +383,40 @@ stk_coarse_plan *stk_coarse_plan_build(const stk_coarse_level *lv, int Lc, int s
         c.z = lv[0].f;
         c.y = lv[0].u;
         c.alpha = c.beta = 0.0;
-        c.use_m = c.pad = 0;
+        c.use_m = 0;
+        c.lx = c.lz = c.ly = -1;
         J.push_back(c);
     }
     for (int j = 1; j <= Lc; ++j) {
         const stk_coarse_level &L = lv[j], &C = lv[j - 1];
         J.push_back(rows_job(JOB_SPMM, L.p, 0, L.p.n_pos, C.u, L.u, L.u, -1.0, 1.0, false));  // u -= P u_c
         smooth(j, true);
+    }
+    // LDS arena offsets of every global workspace the jobs name
+    {
+        std::vector<std::pair<const double *, int>> where;
+        int rows = 0;
+        for (int j = 0; j <= Lc; ++j)
+            for (const double *v : {(const double *)lv[j].u, (const double *)lv[j].f, (const double *)lv[j].res}) {
+                where.push_back({v, rows});
+                rows += lv[j].n;
+            }
+        auto off = [&](const double *v) {
+            for (auto &w : where)
+                if (w.first == v) return w.second;
+            return -1;
+        };
+        for (Job &j : J) {
+            j.lx = off(j.x);
+            j.lz = off(j.z);
+            j.ly = off(j.y);
+        }
+        p->lds_rows = rows;
+        p->top_n = lv[Lc].n;
+        p->top_lu = off(lv[Lc].u);
+        p->top_lf = off(lv[Lc].f);
+        p->top_f = lv[Lc].f;
+        p->top_u = lv[Lc].u;
     }
     p->n_jobs = (int)J.size();
     if (hipMalloc((void **)&p->dev_jobs, sizeof(Job) * J.size()) != hipSuccess ||
@@ -292,6 +442,29 @@ int stk_coarse_plan_run(const stk_coarse_plan *p, hipStream_t st, int n_loc, int
     a.coarse_inv = coarse_inv;
     a.coarse_scale = cm ? 1.0 : 1.0 / ca;
     const int all_pairs = (n_loc + 1) / 2;
+    a.lds_rows = p->lds_rows;
+    a.top_n = p->top_n;
+    a.top_lu = p->top_lu;
+    a.top_lf = p->top_lf;
+    a.top_f = p->top_f;
+    a.top_u = p->top_u;
+    const size_t lds = sizeof(double2) * (size_t)p->lds_rows;
+    if (g_mg_coarse_lds && g_mg_coarse_pairs <= 1 && lds <= 144 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            STK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mg_coarse_lds_kernel<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+            STK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mg_coarse_lds_kernel<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+            attr_set = true;
+        }
+        if (cm)
+            hipLaunchKernelGGL(mg_coarse_lds_kernel<true>, dim3(all_pairs), dim3(CBS), lds, st, a);
+        else
+            hipLaunchKernelGGL(mg_coarse_lds_kernel<false>, dim3(all_pairs), dim3(CBS), lds, st, a);
+        STK_LAUNCH_CHECK();
+        return 0;
+    }
     const unsigned grid = (unsigned)((all_pairs + a.pairs_per_wg - 1) / a.pairs_per_wg);
     if (cm)
         hipLaunchKernelGGL(mg_coarse_kernel<true>, dim3(grid), dim3(CBS), 0, st, a);

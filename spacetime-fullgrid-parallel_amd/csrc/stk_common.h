@@ -40,6 +40,27 @@ static inline unsigned stk_flat_grid(int64_t work_items, int block, int per_thre
     return (unsigned)(blocks < cap ? blocks : cap);
 }
 
+// ---- fused coarse sub-V-cycle (mg_coarse.hip), driven by mg.hip --------------------
+// Description of one multigrid level handed over by mg.hip.
+struct stk_coarse_plan;
+struct stk_coarse_level {
+    int n;
+    bool ok;  // all sliced-ELL pieces present
+    stk_ell_rows a, fwd, bwd, p, r;
+    const int32_t *fwd_pos, *bwd_pos;  // group g of a sweep = ELL positions pos[g]..pos[g+1]
+    int n_fwd, n_bwd;
+    double *u, *f, *res;  // workspaces of this level
+};
+stk_coarse_plan *stk_coarse_plan_build(const stk_coarse_level *lv, int Lc, int smoothsteps);
+void stk_coarse_plan_free(stk_coarse_plan *p);
+int stk_coarse_plan_run(const stk_coarse_plan *p, hipStream_t st, int n_loc, int ld, double ca, const double *cm,
+                        const int32_t *kind, const double *coarse_inv);
+
+// Row-gather engine launcher of rows_ell.hip (mode 0 = SPMM, 1 = Gauss-Seidel group).
+int stk_rows_ell_launch(hipStream_t st, int mode, const stk_ell_rows *e, int32_t pos_begin, int32_t pos_end,
+                        int32_t n_loc, int32_t ld, int64_t x_rows, int64_t y_rows, double ca, const double *cm,
+                        const double *x, double alpha, double beta, const double *z, double *y);
+
 // ---- slab access from device code (kron_ell.hip, rows_ell.hip, mg_coarse.hip) -----
 #if defined(__HIPCC__)
 typedef int stk_v4i __attribute__((ext_vector_type(4)));

@@ -237,7 +237,7 @@ extern "C" int stk_wavelet_apply(void *stream, int32_t M, int32_t J, int32_t ld,
     STK_REQUIRE(ld >= N, "stk_wavelet_apply: ld=%d < 2^J+1=%d", ld, N);
     STK_REQUIRE(x && y, "stk_wavelet_apply: null pointer");
     STK_REQUIRE(N <= TILE_ELEMS, "stk_wavelet_apply: J too large");
-    if (g_wavelet_variant == 0 && J >= 1 && J <= 6 && ld == N + 1 &&
+    if (g_wavelet_variant == 0 && J >= 1 && J <= 7 && ld == N + 1 &&
         (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
         hipStream_t st = stk_stream(stream);
         switch (J) {
@@ -246,7 +246,8 @@ extern "C" int stk_wavelet_apply(void *stream, int32_t M, int32_t J, int32_t ld,
             case 3: return launch_reg<3>(st, M, transposed, x, y);
             case 4: return launch_reg<4>(st, M, transposed, x, y);
             case 5: return launch_reg<5>(st, M, transposed, x, y);
-            default: return launch_reg<6>(st, M, transposed, x, y);
+            case 6: return launch_reg<6>(st, M, transposed, x, y);
+            default: return launch_reg<7>(st, M, transposed, x, y);
         }
     }
     int R = TILE_ELEMS / N;

@@ -80,6 +80,24 @@ def _restrict(mat, fd):
     return _finish(sp.csr_matrix(mat)[fd, :].tocsc()[:, fd].tocsr())
 
 
+def tile_order_from_coords(coords, rows_per_tile=2048, small_lexsort=True):
+    """A processing order that follows the geometry: the bounding box is cut
+    into square (cubic) tiles of about `rows_per_tile` vertices, tiles are
+    visited lexicographically and so are the vertices inside a tile."""
+    p = np.asarray(coords)
+    d = p.shape[1]
+    lex = tuple(p[:, k] for k in range(d))
+    if small_lexsort and len(p) <= rows_per_tile:
+        return np.lexsort(lex).astype(np.int32)
+    lo, hi = p.min(axis=0), p.max(axis=0)
+    ext = np.maximum(hi - lo, 1e-300)
+    ntiles = max(1.0, len(p) / float(rows_per_tile))
+    side = (np.prod(ext) / ntiles)**(1.0 / d)
+    tiles = tuple(np.floor((p[:, k] - lo[k]) / side).astype(np.int64)
+                  for k in range(d))
+    return np.lexsort(lex + tiles).astype(np.int32)
+
+
 def tile_row_order(mesh, rows_per_tile=None):
     """A processing order for the free dofs that follows the geometry: the
     bounding box is cut into square tiles of about `rows_per_tile` vertices,
@@ -92,7 +110,6 @@ def tile_row_order(mesh, rows_per_tile=None):
     import os
     if rows_per_tile is None:
         rows_per_tile = int(os.environ.get('STK_ROWS_PER_TILE', '2048'))
-    from .linop import tile_order_from_coords
     return tile_order_from_coords(mesh.points[free_dofs(mesh)], rows_per_tile,
                                   small_lexsort=False)
 

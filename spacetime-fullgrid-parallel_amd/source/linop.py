@@ -22,6 +22,7 @@ import torch
 from scipy.sparse.linalg import LinearOperator
 
 from . import _lib
+from .assembly import tile_order_from_coords  # noqa: F401 (re-exported)
 
 
 class SpaceOp:
@@ -258,24 +259,6 @@ class EllRowsMatrix:
                                    _lib.ptr(self.va), _lib.ptr(self.vm),
                                    _lib.ptr(self.row_ids),
                                    _lib.ptr(self.dia_a), _lib.ptr(self.dia_m))
-
-
-def tile_order_from_coords(coords, rows_per_tile=2048, small_lexsort=True):
-    """A processing order that follows the geometry: the bounding box is cut
-    into square (cubic) tiles of about `rows_per_tile` vertices, tiles are
-    visited lexicographically and so are the vertices inside a tile."""
-    p = np.asarray(coords)
-    d = p.shape[1]
-    lex = tuple(p[:, k] for k in range(d))
-    if small_lexsort and len(p) <= rows_per_tile:
-        return np.lexsort(lex).astype(np.int32)
-    lo, hi = p.min(axis=0), p.max(axis=0)
-    ext = np.maximum(hi - lo, 1e-300)
-    ntiles = max(1.0, len(p) / float(rows_per_tile))
-    side = (np.prod(ext) / ntiles)**(1.0 / d)
-    tiles = tuple(np.floor((p[:, k] - lo[k]) / side).astype(np.int64)
-                  for k in range(d))
-    return np.lexsort(lex + tiles).astype(np.int32)
 
 
 class EllMatrices:

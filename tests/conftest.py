@@ -49,6 +49,6 @@ def relerr(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
 
 
-@pytest.fixture(params=['g3_square', 'g3_lshape', 'g3_square3'])
+@pytest.fixture(params=['g3_square', 'g3_lshape', 'g3_square3', 'g3_cube'])
 def g3(request):
     return load_golden(request.param)

@@ -243,6 +243,7 @@ def main():
         ('square', mesh_mod.construct_2d_square_mesh, 2, 3),
         ('lshape', mesh_mod.construct_2d_lshape_mesh, 1, 3),
         ('square3', mesh_mod.construct_2d_square_mesh, 3, 2),
+        ('cube', mesh_mod.construct_3d_cube_mesh, 1, 2),
     ]:
         mesh, _ = meshfn(J_space)
         tmesh = mesh_mod.construct_interval(2**J_time)
@@ -250,7 +251,7 @@ def main():
         M_x, A_x = asm.space_matrices(mesh)
         P_mats = asm.prolongation_matrices(mesh)
         u0_x = asm.space_load(
-            mesh, lambda x, y: np.sin(np.pi * x) * np.sin(np.pi * y))
+            mesh, lambda *c: np.prod([np.sin(np.pi * ck) for ck in c], axis=0))
         N, M = A_t.shape[0], M_x.shape[0]
         dd = DofDistributionMPI(comm, N, M)
         rng = np.random.RandomState(128)

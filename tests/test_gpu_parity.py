@@ -163,12 +163,14 @@ def test_wavelet_op_matrices(stk):
             assert np.allclose(as_matrix(op.T), g['WT_' + key], rtol=0,
                                atol=1e-14)
             assert np.array_equal(np.asarray(op.levels), g['levels_' + key])
-    # J = 7 (N = 129) goes through the same kernel with a different tile
+    # J = 6, 7: register kernel (full 64-column tiles and a ragged last one);
+    # J = 8: the generic LDS kernel
     from oracle import wavelets as ow
-    op = WaveletTransformOp(7, interleaved=True)
-    X = np.random.RandomState(5).rand(129, 37)
-    assert relerr(op @ X, ow.apply(7, X)) < TOL
-    assert relerr(op.T @ X, ow.apply_transposed(7, X)) < TOL
+    for J in (6, 7, 8):
+        op = WaveletTransformOp(J, interleaved=True)
+        X = np.random.RandomState(5).rand(2**J + 1, 64 + 37)
+        assert relerr(op @ X, ow.apply(J, X)) < TOL
+        assert relerr(op.T @ X, ow.apply_transposed(J, X)) < TOL
 
 
 def test_gauss_seidel_and_multigrid_match_reference_golden(stk, g3):
@@ -512,3 +514,26 @@ def test_wide_slab_addressing_matches(stk):
     finally:
         for key in (b'ell_force_wide', b'rows_force_wide'):
             stk.check(stk.lib().stk_set_tuning(key, 0))
+
+
+def test_coarse_subcycle_variants_agree(stk):
+    """The coarse end of the V-cycle runs level by level, as one job-list
+    kernel on global workspaces, or as one kernel with all level vectors in LDS
+    (csrc/mg_coarse.hip): same arithmetic in the same order, identical output."""
+    import heateq_mpi as hm
+    outs = []
+    for problem, J_space in (('square', 5), ('cube', 2)):
+        h = hm.HeatEquationMPI(J_space=J_space, J_time=3, problem=problem)
+        X = np.random.RandomState(11).rand(h.N, h.M)
+        x = _vec(h.dofs_distr, X)
+        res = []
+        try:
+            for fuse, lds in ((0, 0), (1, 0), (1, 1)):
+                stk.check(stk.lib().stk_set_tuning(b'mg_fuse_coarse', fuse))
+                stk.check(stk.lib().stk_set_tuning(b'mg_coarse_lds', lds))
+                res.append((_np(h.P @ x), _np(h.S @ x)))
+        finally:
+            stk.check(stk.lib().stk_set_tuning(b'mg_fuse_coarse', 1))
+            stk.check(stk.lib().stk_set_tuning(b'mg_coarse_lds', 1))
+        for Pv, Sv in res[1:]:
+            assert np.array_equal(Pv, res[0][0]) and np.array_equal(Sv, res[0][1])

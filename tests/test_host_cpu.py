@@ -112,7 +112,7 @@ def _scheduled_sweep(mat, u, f, ptr, rows):
     return u
 
 
-@pytest.mark.parametrize('fixture', ['g3_square3', 'g3_lshape'])
+@pytest.mark.parametrize('fixture', ['g3_square3', 'g3_lshape', 'g3_cube'])
 def test_gauss_seidel_schedule_reproduces_sequential_sweep(fixture):
     from oracle.multigrid import Smoother
     from source.multigrid import gauss_seidel_schedule
