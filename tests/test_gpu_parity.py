@@ -537,3 +537,52 @@ def test_coarse_subcycle_variants_agree(stk):
             stk.check(stk.lib().stk_set_tuning(b'mg_coarse_lds', 1))
         for Pv, Sv in res[1:]:
             assert np.array_equal(Pv, res[0][0]) and np.array_equal(Sv, res[0][1])
+
+
+@pytest.mark.parametrize('problem,J_space,J_time', [('square', 9, 6),
+                                                    ('lshape', 8, 5)])
+def test_baseline_configs_full_size_against_oracle(stk, problem, J_space, J_time):
+    """BASELINE.json configs 3 and 4 at their full size (square: N = 65,
+    M = 1 046 529).  The Kronecker metric operator and W / W^T are compared
+    with the oracle on the WHOLE vector; S and P, whose oracle needs seconds
+    per time slice, on sampled time slices (space operators act slice by slice,
+    so (S x)[t] only needs the rows t-1, t, t+1 of the time factors); the solve
+    through the iteration count and the residual the reference prints."""
+    import heateq_mpi as hm
+    from oracle import kron as okron
+    from oracle import wavelets as ow
+    from oracle.multigrid import MultiGrid as OracleMG
+    from source.linalg import PCG
+    from source.mpi_kron import SumMPI, TridiagKronMatMPI
+    h = hm.HeatEquationMPI(J_space=J_space, J_time=J_time, problem=problem)
+    dd, N, M = h.dofs_distr, h.N, h.M
+    X = np.random.RandomState(128).rand(N, M)
+    x = _vec(dd, X)
+    # the bench's operator, whole output
+    op = SumMPI(dd, [TridiagKronMatMPI(dd, h.A_t, h.M_x),
+                     TridiagKronMatMPI(dd, h.M_t, h.A_x)])
+    assert relerr(_np(op @ x), okron.sum_apply([(h.A_t, h.M_x), (h.M_t, h.A_x)], X)) < 1e-13
+    assert relerr(_np(h.W @ x), ow.apply(J_time, X)) < 1e-13
+    assert relerr(_np(h.WT @ x), ow.apply_transposed(J_time, X)) < 1e-13
+    # S and P on sampled time slices
+    P_mats = h.hierarchy.P_mats
+    levels = ow.levels(J_time, interleaved=True)
+    sample = [0, N // 2 + 1]
+    Sx, Px = _np(h.S @ x), _np(h.P @ x)
+    K = OracleMG(h.A_x, P_mats, 3, 2)
+    Mx, Ax = h.M_x, h.A_x
+    want = np.zeros((len(sample), M))
+    for T, ops in [(h.A_t, [Mx, K, Mx]), (h.L_t, [Mx, K, Ax]),
+                   (sp.csr_matrix(h.L_t.T), [Ax, K, Mx]), (h.M_t, [Ax, K, Ax]),
+                   (h.G_t, [Mx])]:  # heateq_mpi.py:166-181
+        Z = sp.csr_matrix(T)[sample] @ X
+        want += okron.composite_space(ops, Z.T).T
+    assert relerr(Sx[sample], want) < 1e-10
+    for t in sample:
+        C = OracleMG(sp.csr_matrix(2.0**levels[t] * Mx + 0.3 * Ax), P_mats, 3, 2)
+        assert relerr(Px[t], C @ (Ax @ (C @ X[t]))) < 1e-10
+    del Sx, Px
+    hist = []
+    w, iters = PCG(h.WT_S_W, h.P, h.rhs, history=hist)
+    assert 10 <= iters <= 16 and hist[-1] < 1e-12
+    assert all(b < a for a, b in zip(hist, hist[1:]))
