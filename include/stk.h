@@ -106,11 +106,26 @@ typedef struct {
 } stk_kron_ell_term;
 
 /* Tuning key (stk_set_tuning): "ell_wg_per_cu" (persistent workgroups per CU,
- * 0 = default).  K must be one of 5, 7, 9, 12, 16; at most 3 terms. */
+ * 0 = default).  K must be one of 5, 7, 9, 12, 16; at most 3 terms.
+ * Terms with ghost rows (x_lo / x_hi) are handled as two launches: the
+ * slab-local part, then stk_kron_ell_ghost_apply. */
 int stk_kron_ell_apply(void *stream, const stk_ell_pattern *pattern_host,
                        int32_t n_loc, int32_t ld, int32_t n_terms,
                        const stk_kron_ell_term *terms_host, double beta,
                        double *y);
+
+/* Only the contribution of the ghost time rows of the same operator:
+ *   y[:, 0]       += sum_k sub_k[0]       * X_k x_lo_k
+ *   y[:, n_loc-1] += sum_k sup_k[n_loc-1] * X_k x_hi_k
+ * i.e. what the first and last row of the ghosted block contribute in
+ * TridiagKronIdentityMPI._matvec (mpi_kron.py:186-201, "first/last rows after
+ * the halo arrived", :199-200).  A caller that overlaps the halo exchange with
+ * compute calls stk_kron_ell_apply with x_lo = x_hi = NULL while the exchange
+ * is in flight and this function once it has completed.  The x members of the
+ * terms are ignored. */
+int stk_kron_ell_ghost_apply(void *stream, const stk_ell_pattern *pattern_host,
+                             int32_t n_loc, int32_t ld, int32_t n_terms,
+                             const stk_kron_ell_term *terms_host, double *y);
 
 /* ---- (I_t kron A) for a general, possibly rectangular CSR A ---------------
  * y = alpha * A x + beta * z  on `rows` x n_loc outputs (IdentityKronMatMPI,

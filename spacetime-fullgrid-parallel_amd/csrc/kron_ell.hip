@@ -16,6 +16,15 @@
 // groups of one contiguous chunk of the row order, which keeps their gathers
 // in that XCD's L2.  HBM-bound by design: x, y and the matrix arrays are each
 // read or written once.
+//
+// Ghost time rows (a slab with neighbour ranks) are NOT part of this kernel: it
+// computes the slab-local part, which needs no halo and can therefore run
+// while the exchange is in flight, and kron_ell_ghost_kernel adds
+//   y[:, 0] += sum_k sub_k[0] X_k x_lo_k,  y[:, n_loc-1] += sum_k sup_k[n_loc-1] X_k x_hi_k
+// afterwards.  (An earlier version gave every row extra "ghost lanes" that
+// gathered 8-byte values of the ghost rows inside the main kernel: those
+// scattered gathers doubled its time -- 0.39 ms instead of 0.195 ms for the
+// 33-step slab of a 2-GPU run.)
 #include <cstring>
 
 #include "stk_common.h"
@@ -37,13 +46,11 @@ struct EllArgs {
     const double *ovf_vals[NT];
     const double *tri[NT];
     const double *x[NT];
-    const double *lo[NT];
-    const double *hi[NT];
     double *y;
     double beta;
     int32_t M, n_loc, ld;
-    int32_t has_lo, has_hi, any_tri;
-    int32_t P, W, R;
+    int32_t any_tri;
+    int32_t P, R;
     int32_t ngroups, chunk;  // groups in total / per XCD
     uint32_t vec_bytes;      // M * ld * 8 (0 when wide)
     int32_t wide;            // slab of 4 GiB or more: 64-bit addressing
@@ -51,35 +58,30 @@ struct EllArgs {
 
 // K: slots per row (compile time).  NPF: ELL elements each thread prefetches
 // per array and group, NPF * BS >= R * K.
-// GENERIC = false compiles the ghost-lane and overflow paths out (single slab, no
-// row longer than K): the common case runs without their branches.
+// GENERIC = false compiles the overflow path out (no row longer than K): the
+// common case runs without its branches.
 // WIDE (with GENERIC only): slabs of 4 GiB and more, see stk_slab.
 template <int NT, bool SHARED_IN, int K, int NPF, bool GENERIC, bool WIDE>
 __global__ __launch_bounds__(BS, 6 * 512 / BS > 8 ? 8 : 6) void kron_ell_kernel(const EllArgs<NT> a)
 {
     static_assert(GENERIC || !WIDE, "the fast path is for slabs below 4 GiB");
-    const int has_lo = GENERIC ? a.has_lo : 0, has_hi = GENERIC ? a.has_hi : 0;
     constexpr int KS = (K + 3) & ~3;  // LDS stride of a row's slots (16-byte vectors)
     extern __shared__ double sm[];
-    const int W = a.W, R = a.R, SW = a.n_loc + 3;
+    const int W = a.P, R = a.R, SW = a.n_loc + 3;
     double *s_w = sm;                                                    // [NT][R][SW]
     double *s_val = s_w + (a.any_tri ? NT * R * SW : 0);                 // [NT][R][KS]
     uint32_t *s_off = reinterpret_cast<uint32_t *>(s_val + NT * R * KS); // [R][KS] byte offset of the column
-    int32_t *s_idx = reinterpret_cast<int32_t *>(s_off + R * KS);        // [R][KS] ghost lanes only
-    uint32_t *s_row = reinterpret_cast<uint32_t *>(s_idx + R * KS);      // [R] byte offset of the output row
+    uint32_t *s_row = s_off + R * KS;                                    // [R] byte offset of the output row
     // time-stencil coefficients [NT][3][LT], staged once (16-byte aligned rows)
     const int LT = (a.n_loc + 2) & ~1;
     double *s_tri = reinterpret_cast<double *>(s_row + ((R + 3) & ~3));
 
     const int tid = threadIdx.x;
     const int r = tid / W;
-    const int l = tid - r * W;
-    const int p = l - has_lo;  // pair index; < 0: lo ghost lane, >= P: hi ghost lane
-    const bool is_pair = (p >= 0) && (p < a.P) && (r < R);
-    const bool is_ghost = GENERIC && (r < R) && !is_pair;
+    const int p = tid - r * W;  // pair of time steps
+    const bool is_pair = r < R;
     const int t0 = 2 * p;
     const bool has1 = t0 + 1 < a.n_loc;
-    const bool ghosts = has_lo || has_hi;
     const uint32_t ld_bytes = stk_slab<WIDE>::row_stride(a.ld);  // row stride in offset units
     const uint32_t t0_bytes = (uint32_t)t0 * 8u;
     stk_slab<WIDE> sx[NT];
@@ -141,7 +143,6 @@ __global__ __launch_bounds__(BS, 6 * 512 / BS > 8 ? 8 : 6) void kron_ell_kernel(
             const int i = tid + q * BS;
             if (i < rows * K) {
                 s_off[st_lds[q]] = (uint32_t)pidx[q] * ld_bytes;
-                if (ghosts) s_idx[st_lds[q]] = pidx[q];
 #pragma unroll
                 for (int k = 0; k < NT; ++k) s_val[k * R * KS + st_lds[q]] = pval[k][q];
             }
@@ -223,39 +224,18 @@ __global__ __launch_bounds__(BS, 6 * 512 / BS > 8 ? 8 : 6) void kron_ell_kernel(
                     }
                 }
             }
-        } else if (rowok && is_ghost) {
-            // ghost lane: one value of the neighbour rank's boundary time row
-            const int32_t *si = s_idx + r * KS;
-#pragma unroll
-            for (int k = 0; k < NT; ++k) {
-                const double *gp = (p < 0) ? a.lo[k] : a.hi[k];
-                if (gp == nullptr) continue;
-                const double *sv = s_val + (k * R + r) * KS;
-                double gv[K];
-#pragma unroll
-                for (int u = 0; u < K; ++u) gv[u] = gp[si[u]];
-#pragma unroll
-                for (int u = 0; u < K; ++u) acc0[k] = fma(sv[u], gv[u], acc0[k]);
-                if (a.ovf_indptr != nullptr)
-                    for (int e = a.ovf_indptr[pos]; e < a.ovf_indptr[pos + 1]; ++e)
-                        acc0[k] = fma(a.ovf_vals[k][e], gp[a.ovf_indices[e]], acc0[k]);
-            }
         }
 
         // ---- time stencil through LDS, store ---------------------------------
         double y0 = 0.0, y1 = 0.0;
         if (a.any_tri) {
-            // s_w[k][r][q]: q = t + 1; q = 0 is the lo ghost, q = n_loc + 1 the hi ghost
-            if (rowok) {
+            // s_w[k][r][q]: q = t + 1
+            if (rowok && is_pair) {
 #pragma unroll
                 for (int k = 0; k < NT; ++k) {
                     double *w = s_w + (k * R + r) * SW;
-                    if (is_pair) {
-                        w[t0 + 1] = acc0[k];
-                        if (has1) w[t0 + 2] = acc1[k];
-                    } else {
-                        w[p < 0 ? 0 : a.n_loc + 1] = acc0[k];
-                    }
+                    w[t0 + 1] = acc0[k];
+                    if (has1) w[t0 + 2] = acc1[k];
                 }
             }
             __syncthreads();
@@ -269,13 +249,13 @@ __global__ __launch_bounds__(BS, 6 * 512 / BS > 8 ? 8 : 6) void kron_ell_kernel(
                         const double2 dia = *reinterpret_cast<const double2 *>(c + LT);
                         const double2 sup = *reinterpret_cast<const double2 *>(c + 2 * LT);
                         double v0 = dia.x * acc0[k];
-                        if (t0 > 0 || has_lo) v0 = fma(sub.x, w[-1], v0);
-                        if (has1 || has_hi) v0 = fma(sup.x, has1 ? acc1[k] : w[1], v0);
+                        if (t0 > 0) v0 = fma(sub.x, w[-1], v0);
+                        if (has1) v0 = fma(sup.x, acc1[k], v0);
                         y0 += v0;
                         if (has1) {
                             double v1 = dia.y * acc1[k];
                             v1 = fma(sub.y, acc0[k], v1);
-                            if (t0 + 2 < a.n_loc || has_hi) v1 = fma(sup.y, w[2], v1);
+                            if (t0 + 2 < a.n_loc) v1 = fma(sup.y, w[2], v1);
                             y1 += v1;
                         }
                     } else {
@@ -319,7 +299,7 @@ int launch4(hipStream_t st, const EllArgs<NT> &a, unsigned grid, size_t lds)
     else if (npf <= 4)
         hipLaunchKernelGGL((kron_ell_kernel<NT, SHARED_IN, K, 4, GENERIC, WIDE>), dim3(grid), dim3(BS), lds, st, a);
     else {
-        stk_set_error("stk_kron_ell_apply: %d slots per row with %d lanes per row not supported", K, a.W);
+        stk_set_error("stk_kron_ell_apply: %d slots per row with %d lanes per row not supported", K, a.P);
         return 2;
     }
     STK_LAUNCH_CHECK();
@@ -330,7 +310,7 @@ template <int NT, bool SHARED_IN, int K>
 int launch3(hipStream_t st, const EllArgs<NT> &a, unsigned grid, size_t lds)
 {
     if (a.wide) return launch4<NT, SHARED_IN, K, true, true>(st, a, grid, lds);
-    const bool generic = a.has_lo || a.has_hi || a.ovf_indptr != nullptr || g_ell_force_generic;
+    const bool generic = a.ovf_indptr != nullptr || g_ell_force_generic;
     return generic ? launch4<NT, SHARED_IN, K, true>(st, a, grid, lds)
                    : launch4<NT, SHARED_IN, K, false>(st, a, grid, lds);
 }
@@ -339,7 +319,7 @@ template <int NT, bool SHARED_IN>
 int launch2(hipStream_t st, const EllArgs<NT> &a_in, int K)
 {
     EllArgs<NT> a = a_in;
-    a.R = BS / a.W;
+    a.R = BS / a.P;
     if (a.R * K > 4 * BS) a.R = 4 * BS / K;  // at most 4 prefetched entries per thread
     a.ngroups = (a.M + a.R - 1) / a.R;
     a.chunk = (a.ngroups + 7) / 8;
@@ -348,7 +328,7 @@ int launch2(hipStream_t st, const EllArgs<NT> &a_in, int K)
     const int KS = (K + 3) & ~3;
     const size_t lds = sizeof(double) * ((a.any_tri ? (size_t)NT * a.R * (a.n_loc + 3) : 0) +
                                           (size_t)NT * a.R * KS) +
-                       sizeof(int32_t) * (2 * (size_t)a.R * KS + a.R + 4) +
+                       sizeof(int32_t) * ((size_t)a.R * KS + a.R + 4) +
                        sizeof(double) * (size_t)NT * 3 * (a.n_loc + 2) + 32;
     int n_cu = 256;
     {
@@ -375,6 +355,112 @@ int launch2(hipStream_t st, const EllArgs<NT> &a_in, int K)
     return 2;
 }
 
+// ---- ghost-row correction ---------------------------------------------------
+// y[row, 0]       += sum_k sub_k[0]       * sum_j X_k[row, j] x_lo_k[j]
+// y[row, n_loc-1] += sum_k sup_k[n_loc-1] * sum_j X_k[row, j] x_hi_k[j]
+// (the rows t_begin-1 and t_end of the time factors; reference mpi_kron.py:165-183,
+// 186-201 keep them as the first and last row of the ghosted block).  One lane
+// per matrix row; terms that share a ghost row gather it once.
+template <int NT>
+struct GhostArgs {
+    const int32_t *ell_idx, *row_ids, *ovf_indptr, *ovf_indices;
+    const double *ell_vals[NT];
+    const double *ovf_vals[NT];
+    const double *tri[NT];
+    const double *lo[NT];
+    const double *hi[NT];
+    double *y;
+    int32_t M, n_loc, ld;
+};
+
+constexpr int GBSZ = 256;
+
+template <int NT, int K>
+__global__ __launch_bounds__(GBSZ) void kron_ell_ghost_kernel(const GhostArgs<NT> a)
+{
+    const int pos = blockIdx.x * GBSZ + threadIdx.x;
+    if (pos >= a.M) return;
+    const size_t e0 = (size_t)pos * K;
+    int32_t col[K];
+#pragma unroll
+    for (int u = 0; u < K; ++u) col[u] = a.ell_idx[e0 + u];
+    const int o0 = a.ovf_indptr ? a.ovf_indptr[pos] : 0, o1 = a.ovf_indptr ? a.ovf_indptr[pos + 1] : 0;
+    double add[2] = {0.0, 0.0};
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const double *loaded = nullptr;
+        double gv[K];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const double *gp = side ? a.hi[k] : a.lo[k];
+            if (gp == nullptr || a.tri[k] == nullptr) continue;
+            // sub[0] couples to t_begin - 1, sup[n_loc - 1] to t_end
+            const double c = side ? a.tri[k][2 * a.n_loc + a.n_loc - 1] : a.tri[k][0];
+            if (c == 0.0) continue;
+            if (gp != loaded) {
+#pragma unroll
+                for (int u = 0; u < K; ++u) gv[u] = gp[col[u]];
+                loaded = gp;
+            }
+            double s = 0.0;
+#pragma unroll
+            for (int u = 0; u < K; ++u) s = fma(a.ell_vals[k][e0 + u], gv[u], s);
+            for (int e = o0; e < o1; ++e) s = fma(a.ovf_vals[k][e], gp[a.ovf_indices[e]], s);
+            add[side] = fma(c, s, add[side]);
+        }
+    }
+    const int row = a.row_ids ? a.row_ids[pos] : pos;
+    double *yr = a.y + (size_t)row * a.ld;
+    if (a.n_loc == 1) {
+        yr[0] += add[0] + add[1];
+    } else {
+        if (add[0] != 0.0) yr[0] += add[0];
+        if (add[1] != 0.0) yr[a.n_loc - 1] += add[1];
+    }
+}
+
+template <int NT, int K>
+int ghost_launch(hipStream_t st, const GhostArgs<NT> &a)
+{
+    hipLaunchKernelGGL((kron_ell_ghost_kernel<NT, K>), dim3((a.M + GBSZ - 1) / GBSZ), dim3(GBSZ), 0, st, a);
+    STK_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int NT>
+int ghost_dispatch(hipStream_t st, const stk_ell_pattern *pat, int32_t n_loc, int32_t ld,
+                   const stk_kron_ell_term *t, double *y)
+{
+    GhostArgs<NT> a;
+    bool any = false;
+    for (int k = 0; k < NT; ++k) {
+        a.ell_vals[k] = t[k].ell_vals;
+        a.ovf_vals[k] = t[k].ovf_vals;
+        a.tri[k] = t[k].tri;
+        a.lo[k] = t[k].x_lo;
+        a.hi[k] = t[k].x_hi;
+        if (t[k].tri && (t[k].x_lo || t[k].x_hi)) any = true;
+    }
+    if (!any) return 0;
+    a.ell_idx = pat->ell_idx;
+    a.row_ids = pat->row_ids;
+    a.ovf_indptr = pat->ovf_indptr;
+    a.ovf_indices = pat->ovf_indices;
+    a.y = y;
+    a.M = pat->M;
+    a.n_loc = n_loc;
+    a.ld = ld;
+    switch (pat->K) {
+        case 5: return ghost_launch<NT, 5>(st, a);
+        case 7: return ghost_launch<NT, 7>(st, a);
+        case 9: return ghost_launch<NT, 9>(st, a);
+        case 12: return ghost_launch<NT, 12>(st, a);
+        case 16: return ghost_launch<NT, 16>(st, a);
+    }
+    stk_set_error("stk_kron_ell_apply: K=%d is not one of 5, 7, 9, 12, 16", pat->K);
+    return 2;
+}
+
 template <int NT>
 int dispatch(hipStream_t st, const stk_ell_pattern *pat, int32_t n_loc, int32_t ld, const stk_kron_ell_term *t,
              double beta, double *y)
@@ -389,23 +475,20 @@ int dispatch(hipStream_t st, const stk_ell_pattern *pat, int32_t n_loc, int32_t 
     a.M = pat->M;
     a.n_loc = n_loc;
     a.ld = ld;
-    a.has_lo = a.has_hi = a.any_tri = 0;
+    a.any_tri = 0;
     bool shared = true;
     for (int k = 0; k < NT; ++k) {
         a.ell_vals[k] = t[k].ell_vals;
         a.ovf_vals[k] = t[k].ovf_vals;
         a.tri[k] = t[k].tri;
         a.x[k] = t[k].x;
-        a.lo[k] = t[k].x_lo;
-        a.hi[k] = t[k].x_hi;
-        if (t[k].x_lo) a.has_lo = 1;
-        if (t[k].x_hi) a.has_hi = 1;
         if (t[k].tri) a.any_tri = 1;
         if (t[k].x != t[0].x) shared = false;
     }
     a.P = (n_loc + 1) / 2;
-    a.W = a.P + a.has_lo + a.has_hi;
-    return shared ? launch2<NT, true>(st, a, pat->K) : launch2<NT, false>(st, a, pat->K);
+    int rc = shared ? launch2<NT, true>(st, a, pat->K) : launch2<NT, false>(st, a, pat->K);
+    if (rc) return rc;
+    return ghost_dispatch<NT>(st, pat, n_loc, ld, t, y);
 }
 
 }  // namespace
@@ -425,6 +508,26 @@ int stk_kron_ell_set_tuning(const char *key, int32_t value)
         return 0;
     }
     return 1;
+}
+
+extern "C" int stk_kron_ell_ghost_apply(void *stream, const stk_ell_pattern *pat, int32_t n_loc, int32_t ld,
+                                        int32_t n_terms, const stk_kron_ell_term *t, double *y)
+{
+    STK_REQUIRE(pat && t && y, "stk_kron_ell_ghost_apply: null pointer");
+    STK_REQUIRE(pat->M > 0 && pat->K >= 1 && pat->ell_idx, "stk_kron_ell_ghost_apply: bad pattern");
+    STK_REQUIRE(n_loc > 0 && ld >= n_loc, "stk_kron_ell_ghost_apply: bad sizes n_loc=%d ld=%d", n_loc, ld);
+    STK_REQUIRE(n_terms >= 1 && n_terms <= 3, "stk_kron_ell_ghost_apply: n_terms=%d not in 1..3", n_terms);
+    for (int k = 0; k < n_terms; ++k) {
+        STK_REQUIRE(t[k].ell_vals, "stk_kron_ell_ghost_apply: term %d has null vals", k);
+        STK_REQUIRE(pat->ovf_indptr == nullptr || t[k].ovf_vals, "stk_kron_ell_ghost_apply: term %d lacks ovf_vals",
+                    k);
+    }
+    hipStream_t st = stk_stream(stream);
+    switch (n_terms) {
+        case 1: return ghost_dispatch<1>(st, pat, n_loc, ld, t, y);
+        case 2: return ghost_dispatch<2>(st, pat, n_loc, ld, t, y);
+        default: return ghost_dispatch<3>(st, pat, n_loc, ld, t, y);
+    }
 }
 
 extern "C" int stk_kron_ell_apply(void *stream, const stk_ell_pattern *pat, int32_t n_loc, int32_t ld,

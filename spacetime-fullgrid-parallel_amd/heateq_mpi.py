@@ -56,28 +56,48 @@ class SchurMPI(LinearOperatorMPI):
         super().__init__(dofs_distr)
         self.Kinv_x = as_space_op(Kinv_x)
         self.ell = EllMatrices([M_x, A_x])  # matrix 0 = M_x, 1 = A_x
-        tri = lambda T: _lib.to_dev(_local_tridiag(dofs_distr, T))
+        self._couples = {}
+
+        def tri(T):
+            host = _local_tridiag(dofs_distr, T)
+            dev = _lib.to_dev(host)
+            # does the factor reach the neighbour ranks' time rows at all?
+            self._couples[id(dev)] = (host[0, 0] != 0.0, host[2, -1] != 0.0)
+            return dev
+
         self.tA, self.tL, self.tM, self.tG = tri(A_t), tri(L_t), tri(
             M_t), tri(G_t)
         self.tLT = tri(L_t.T.tocsr())
 
+    def _spec(self, tri, k, vec):
+        """(tri, matrix, x, x_lo, x_hi) with the ghost rows only where the time
+        factor couples to them."""
+        lo, hi = self._couples[id(tri)]
+        return (tri, k, vec.buf, vec.X_lo if lo else None,
+                vec.X_hi if hi else None)
+
     def _matvec(self, vec_in, vec_out):
         assert (vec_in is not vec_out)
         self.time_communication = 0
-        if self.dofs_distr.size > 1:
-            self.time_communication = vec_in.communicate_bdr()
-        x, lo, hi = vec_in.buf, vec_in.X_lo, vec_in.X_hi
+        x = vec_in.buf
         n_loc, ld = vec_in.n_loc, vec_in.ld
         u = torch.empty_like(x)
-        kron = self.ell.apply
-        kron([(self.tA, 0, x, lo, hi), (self.tL, 1, x, lo, hi)], n_loc, ld,
-             0.0, u)
+        first = [(self.tA, 0, x, None, None), (self.tL, 1, x, None, None)]
+        if self.dofs_distr.size > 1:
+            # slab-local part of the first launch while the halo is in flight
+            self.time_communication = vec_in.communicate_bdr(
+                callback=lambda: self.ell.apply_local(first, n_loc, ld, 0.0, u))
+        else:
+            self.ell.apply_local(first, n_loc, ld, 0.0, u)
+        self.ell.apply_ghost([self._spec(self.tA, 0, vec_in),
+                              self._spec(self.tL, 1, vec_in)], n_loc, ld, u)
         v1 = self.Kinv_x.apply(u, n_loc=n_loc)
-        kron([(self.tLT, 0, x, lo, hi), (self.tM, 1, x, lo, hi)], n_loc, ld,
-             0.0, u)
+        self.ell.apply([self._spec(self.tLT, 0, vec_in),
+                        self._spec(self.tM, 1, vec_in)], n_loc, ld, 0.0, u)
         v2 = self.Kinv_x.apply(u, n_loc=n_loc)
-        kron([(None, 0, v1, None, None), (None, 1, v2, None, None),
-              (self.tG, 0, x, lo, hi)], n_loc, ld, 0.0, vec_out.buf)
+        self.ell.apply([(None, 0, v1, None, None), (None, 1, v2, None, None),
+                        self._spec(self.tG, 0, vec_in)], n_loc, ld, 0.0,
+                       vec_out.buf)
         vec_out.communicated_bdr = False
         return vec_out
 

@@ -71,6 +71,10 @@ _PROTOTYPES = {
         c_p, ctypes.POINTER(EllPattern), c_i32, c_i32, c_i32,
         ctypes.POINTER(KronEllTerm), c_f64, c_p
     ]),
+    'stk_kron_ell_ghost_apply': (ctypes.c_int, [
+        c_p, ctypes.POINTER(EllPattern), c_i32, c_i32, c_i32,
+        ctypes.POINTER(KronEllTerm), c_p
+    ]),
     'stk_ell_spmm': (ctypes.c_int, [
         c_p, ctypes.POINTER(EllRows), c_i32, c_i32, c_i32, c_f64, c_p, c_p,
         c_f64, c_f64, c_p, c_p

@@ -308,16 +308,36 @@ class EllMatrices:
                                        _lib.ptr(self.ovf_indptr),
                                        _lib.ptr(self.ovf_indices))
 
-    def apply(self, specs, n_loc, ld, beta, out):
-        """y = beta*y + sum over specs (tri, matrix index, x, x_lo, x_hi)."""
+    def _terms(self, specs, ghosts):
         terms = (_lib.KronEllTerm * len(specs))()
         for t, (tri, k, x, lo, hi) in zip(terms, specs):
             t.tri, t.ell_vals = _lib.ptr(tri), _lib.ptr(self.ell_vals[k])
             t.ovf_vals = _lib.ptr(self.ovf_vals[k])
-            t.x, t.x_lo, t.x_hi = _lib.ptr(x), _lib.ptr(lo), _lib.ptr(hi)
+            t.x = _lib.ptr(x)
+            t.x_lo = _lib.ptr(lo) if ghosts else None
+            t.x_hi = _lib.ptr(hi) if ghosts else None
+        return terms
+
+    def apply(self, specs, n_loc, ld, beta, out):
+        """y = beta*y + sum over specs (tri, matrix index, x, x_lo, x_hi)."""
         _lib.check(_lib.lib().stk_kron_ell_apply(
             _lib.stream(), ctypes.byref(self.pattern), n_loc, ld, len(specs),
-            terms, beta, _lib.ptr(out)))
+            self._terms(specs, True), beta, _lib.ptr(out)))
+
+    def apply_local(self, specs, n_loc, ld, beta, out):
+        """The part of `apply` that needs no ghost rows (x_lo, x_hi ignored):
+        can run while the halo exchange is in flight."""
+        _lib.check(_lib.lib().stk_kron_ell_apply(
+            _lib.stream(), ctypes.byref(self.pattern), n_loc, ld, len(specs),
+            self._terms(specs, False), beta, _lib.ptr(out)))
+
+    def apply_ghost(self, specs, n_loc, ld, out):
+        """Adds what the ghost rows contribute: apply = apply_local, then
+        apply_ghost once the exchange has completed."""
+        if any(lo is not None or hi is not None for _, _, _, lo, hi in specs):
+            _lib.check(_lib.lib().stk_kron_ell_ghost_apply(
+                _lib.stream(), ctypes.byref(self.pattern), n_loc, ld,
+                len(specs), self._terms(specs, True), _lib.ptr(out)))
 
 
 # ----------------------------------------------------------------------------

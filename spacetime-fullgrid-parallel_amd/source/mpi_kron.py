@@ -404,15 +404,30 @@ class _FusedKronSum:
 
     def apply(self, vec_in, vec_out, beta=0.0):
         time_comm = 0.0
+        if self.use_ell:
+            # the slab-local part runs while the halo exchange is in flight
+            # (the reference overlaps the interior rows, mpi_kron.py:193-196)
+            def local():
+                self.ell.apply_local(
+                    [(self.tri[k], k, vec_in.buf, None, None)
+                     for k in range(self.n_terms)], vec_in.n_loc, vec_in.ld,
+                    beta, vec_out.buf)
+
+            if self.dofs_distr.size > 1 and (self.needs_lo or self.needs_hi):
+                time_comm = vec_in.communicate_bdr(callback=local)
+                lo = vec_in.X_lo if self.needs_lo else None
+                hi = vec_in.X_hi if self.needs_hi else None
+                self.ell.apply_ghost(
+                    [(self.tri[k], k, vec_in.buf, lo, hi)
+                     for k in range(self.n_terms)], vec_in.n_loc, vec_in.ld,
+                    vec_out.buf)
+            else:
+                local()
+            return time_comm
         if self.dofs_distr.size > 1:
             time_comm = vec_in.communicate_bdr()
         lo = vec_in.X_lo if self.needs_lo else None
         hi = vec_in.X_hi if self.needs_hi else None
-        if self.use_ell:
-            self.ell.apply([(self.tri[k], k, vec_in.buf, lo, hi)
-                            for k in range(self.n_terms)], vec_in.n_loc,
-                           vec_in.ld, beta, vec_out.buf)
-            return time_comm
         x = _lib.ptr(vec_in.buf)
         for k in range(self.n_terms):
             t = self.terms[k]

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Times the Kronecker kernel in the slab shapes the ranks of a 2/4/8-GPU run
+see at J_time=6, J_space=9 (n_loc = 33/17/9 with one or two ghost rows), on ONE
+GPU: the ghost rows are filled with random data instead of being received.
+Gives the compute part of a multi-GPU step without a multi-GPU node."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, 'spacetime-fullgrid-parallel_amd'))
+from source import _lib  # noqa: E402
+from source.assembly import space_matrices  # noqa: E402
+from source.linop import EllMatrices  # noqa: E402
+from source.mesh import construct_2d_square_mesh  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--J_space', type=int, default=9)
+ap.add_argument('--shapes', default='65:0:0,33:0:1,32:1:0,17:1:1,16:1:1,9:1:1,8:1:1')
+ap.add_argument('--tune', default='')  # key=value,...
+args = ap.parse_args()
+for kv in filter(None, args.tune.split(',')):
+    k, v = kv.split('=')
+    _lib.check(_lib.lib().stk_set_tuning(k.encode(), int(v)))
+
+mesh, _ = construct_2d_square_mesh(args.J_space)
+M_x, A_x = space_matrices(mesh)
+M = M_x.shape[0]
+ell = EllMatrices([M_x, A_x], [M_x])
+rng = np.random.RandomState(0)
+for shape in args.shapes.split(','):
+    n_loc, lo, hi = (int(v) for v in shape.split(':'))
+    ld = n_loc + (n_loc & 1)
+    x = torch.rand((M, ld), dtype=torch.float64, device='cuda')
+    x[:, n_loc:] = 0
+    y = torch.empty_like(x)
+    g = torch.rand((2, M), dtype=torch.float64, device='cuda')
+    tri = [_lib.to_dev(rng.rand(3, n_loc)) for _ in range(2)]
+    specs = [(tri[0], 0, x, g[0] if lo else None, g[1] if hi else None),
+             (tri[1], 1, x, g[0] if lo else None, g[1] if hi else None)]
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 20
+
+    ms = timed(lambda: ell.apply(specs, n_loc, ld, 0.0, y))
+    ms_local = timed(lambda: ell.apply_local(specs, n_loc, ld, 0.0, y))
+    ms_ghost = timed(lambda: ell.apply_ghost(specs, n_loc, ld, y))
+    nbytes = 16 * n_loc * M + 8 * (lo + hi) * M + 12 * (M_x.nnz + A_x.nnz) + 8 * (M + 1)
+    print('n_loc=%2d ghosts=%d%d  %.3f ms (local %.3f + ghost rows %.3f)  %.0f GB/s algorithmic (%.1f%% of 8 TB/s)  -> x%d ranks: %.2f TB/s aggregate'
+          % (n_loc, lo, hi, ms, ms_local, ms_ghost, nbytes / ms / 1e6, nbytes / ms / 1e6 / 80, round(65 / n_loc),
+             round(65 / n_loc) * nbytes / ms / 1e9))
