@@ -90,7 +90,7 @@ def tile_order_from_coords(coords, rows_per_tile=2048, small_lexsort=True):
     if small_lexsort and len(p) <= rows_per_tile:
         return np.lexsort(lex).astype(np.int32)
     lo, hi = p.min(axis=0), p.max(axis=0)
-    ext = np.maximum(hi - lo, 1e-300)
+    ext = np.maximum(hi - lo, 1e-30)
     ntiles = max(1.0, len(p) / float(rows_per_tile))
     side = (np.prod(ext) / ntiles)**(1.0 / d)
     tiles = tuple(np.floor((p[:, k] - lo[k]) / side).astype(np.int64)

@@ -33,8 +33,9 @@ M = M_x.shape[0]
 ell = EllMatrices([M_x, A_x], [M_x])
 rng = np.random.RandomState(0)
 for shape in args.shapes.split(','):
-    n_loc, lo, hi = (int(v) for v in shape.split(':'))
-    ld = n_loc + (n_loc & 1)
+    f = [int(v) for v in shape.split(':')]
+    n_loc, lo, hi = f[:3]
+    ld = f[3] if len(f) > 3 else n_loc + (n_loc & 1)  # optional 4th field: row stride
     x = torch.rand((M, ld), dtype=torch.float64, device='cuda')
     x[:, n_loc:] = 0
     y = torch.empty_like(x)
