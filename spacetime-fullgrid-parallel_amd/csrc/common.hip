@@ -18,6 +18,20 @@ extern "C" const char *stk_last_error(void) { return g_err; }
 
 extern "C" int stk_version(void) { return 100; }
 
+int stk_cu_count()
+{
+    static int cached = 0;
+    if (cached == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            cached = n;
+        else
+            cached = 256;
+    }
+    return cached;
+}
+
 extern "C" int stk_device_info(int32_t *n_cu, int32_t *wave_size, int64_t *hbm_bytes)
 {
     int dev = 0;

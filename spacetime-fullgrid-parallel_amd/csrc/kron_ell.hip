@@ -330,13 +330,7 @@ int launch2(hipStream_t st, const EllArgs<NT> &a_in, int K)
                                           (size_t)NT * a.R * KS) +
                        sizeof(int32_t) * ((size_t)a.R * KS + a.R + 4) +
                        sizeof(double) * (size_t)NT * 3 * (a.n_loc + 2) + 32;
-    int n_cu = 256;
-    {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            n_cu = prop.multiProcessorCount;
-    }
+    const int n_cu = stk_cu_count();
     int per_cu = g_ell_wg_per_cu > 0 ? g_ell_wg_per_cu : 3;
     const int by_lds = (int)(160 * 1024 / (lds + 256));
     if (per_cu > by_lds) per_cu = by_lds > 0 ? by_lds : 1;

@@ -305,13 +305,7 @@ int stk_rows_ell_launch(hipStream_t st, int mode, const stk_ell_rows *e, int32_t
     const size_t buf_doubles =
         ((size_t)(has_m ? 2 : 1) * a.R * KS + 2 * a.R + ((size_t)a.R * KS + a.R + 1) / 2 + 2) & ~(size_t)1;
     const size_t lds = 2 * buf_doubles * sizeof(double) + 16;
-    int n_cu = 256;
-    {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            n_cu = prop.multiProcessorCount;
-    }
+    const int n_cu = stk_cu_count();
     int per_cu = g_rows_wg_per_cu > 0 ? g_rows_wg_per_cu : 3;
     int per_xcd = (n_cu / 8) * per_cu;
     if (per_xcd > a.chunk) per_xcd = a.chunk;

@@ -30,6 +30,10 @@ void stk_set_error(const char *fmt, ...);
 
 static inline hipStream_t stk_stream(void *s) { return (hipStream_t)s; }
 
+// Compute units of the current device, queried once (a property query per
+// launch costs more host time than the launch itself).
+int stk_cu_count();
+
 // Grid size for a flat, memory-bound kernel: enough workgroups to fill
 // 256 CUs x 8 resident blocks, grid-stride for the rest.
 static inline unsigned stk_flat_grid(int64_t work_items, int block, int per_thread = 1)
