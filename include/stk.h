@@ -172,6 +172,16 @@ int stk_time_csr_apply(void *stream, int32_t M, int32_t n_loc, int32_t ld,
                        const double *t_vals, const double *x,
                        const double *recv, int32_t add_identity, double *y);
 
+/* ---- (T kron I) for a dense, possibly rectangular time factor --------------
+ * y[i, r] = sum_c T[r*n_in + c] * x[i*ld_in + c] for r < n_out; columns
+ * n_out..ld_out-1 of y are set to zero.  The time side of the serial KronLinOp
+ * (linop.py:6-15: mat_time.dot(X)) when the factor is not square -- the trial
+ * and test spaces in time of heateq.py:37-51 differ -- or is given as a
+ * LinearOperator; x and y are slabs with their own row strides. */
+int stk_time_dense_apply(void *stream, int32_t M, int32_t n_in, int32_t ld_in,
+                         int32_t n_out, int32_t ld_out, const double *T,
+                         const double *x, double *y);
+
 /* ---- wavelet transform in time, whole time axis on this GPU ---------------
  * y = (W_t kron I) x or (W_t^T kron I) x in the interleaved numbering, all
  * J levels in one pass (WaveletTransformOp._matmat / _rmatmat,

@@ -473,6 +473,41 @@ extern "C" int stk_csr_spmm(void *stream, int32_t rows, int32_t n_loc, int32_t l
     return 0;
 }
 
+namespace {
+// y[i, r] = sum_c T[r, c] x[i, c]: a dense (n_out x n_in) time factor on every
+// spatial row.  One thread per output; T and the x row come through the caches.
+__global__ __launch_bounds__(256) void time_dense_kernel(int64_t total, int32_t n_in, int32_t ld_in, int32_t n_out,
+                                                         int32_t ld_out, const double *__restrict__ T,
+                                                         const double *__restrict__ x, double *__restrict__ y)
+{
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t i = idx / ld_out;
+        const int r = (int)(idx - i * ld_out);
+        double s = 0.0;
+        if (r < n_out) {
+            const double *xi = x + (size_t)i * ld_in;
+            const double *Tr = T + (size_t)r * n_in;
+            for (int c = 0; c < n_in; ++c) s = fma(Tr[c], xi[c], s);
+        }
+        y[idx] = s;  // padding columns are written as zero
+    }
+}
+}  // namespace
+
+extern "C" int stk_time_dense_apply(void *stream, int32_t M, int32_t n_in, int32_t ld_in, int32_t n_out,
+                                    int32_t ld_out, const double *T, const double *x, double *y)
+{
+    STK_REQUIRE(M > 0 && n_in > 0 && n_out > 0 && ld_in >= n_in && ld_out >= n_out,
+                "stk_time_dense_apply: bad sizes M=%d n_in=%d ld_in=%d n_out=%d ld_out=%d", M, n_in, ld_in, n_out,
+                ld_out);
+    STK_REQUIRE(T && x && y && x != y, "stk_time_dense_apply: null or aliased pointer");
+    const int64_t total = (int64_t)M * ld_out;
+    hipLaunchKernelGGL(time_dense_kernel, dim3(stk_flat_grid(total, 256)), dim3(256), 0, stk_stream(stream), total,
+                       n_in, ld_in, n_out, ld_out, T, x, y);
+    STK_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int stk_time_csr_apply(void *stream, int32_t M, int32_t n_loc, int32_t ld, const int32_t *t_indptr,
                                   const int32_t *t_cols, const double *t_vals, const double *x,
                                   const double *recv, int32_t add_identity, double *y)

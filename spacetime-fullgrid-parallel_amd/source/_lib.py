@@ -86,6 +86,9 @@ _PROTOTYPES = {
     'stk_time_csr_apply': (ctypes.c_int, [
         c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p, c_p, c_i32, c_p
     ]),
+    'stk_time_dense_apply': (ctypes.c_int, [
+        c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p
+    ]),
     'stk_wavelet_apply': (ctypes.c_int,
                           [c_p, c_i32, c_i32, c_i32, c_i32, c_p, c_p]),
     'stk_mg_create': (ctypes.c_int, [

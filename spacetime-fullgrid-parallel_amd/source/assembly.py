@@ -53,6 +53,36 @@ def time_matrices(mesh_time):
     return A_t, L_t, M_t, G_t, u0_t
 
 
+def time_matrices_test_space(mesh_time):
+    """Time factors of the serial driver (reference heateq.py:37-63), whose test
+    space Y is L2(order 1) in time: discontinuous P1, two dofs per element
+    (2e, 2e + 1 = the two nodal functions of element e).  Returns
+      M_Y   (2Ne x 2Ne)  mass matrix of Y_t (block diagonal),
+      Minv_Y             its inverse (`Preconditioner(A_bf.time.bf, 'direct')`),
+      B1_t  (2Ne x N)    int phi_j' psi_i   (B1_bf, heateq.py:45-46),
+      B2_t  (2Ne x N)    int phi_j  psi_i   (B2_bf, heateq.py:47-48).
+    NGSolve uses a Legendre basis for L2; S = B^T K B does not depend on the
+    basis of Y because K inverts the mass matrix of Y exactly."""
+    n, h = mesh_time.nv, mesh_time.h
+    ne = n - 1
+    e = np.arange(ne)
+    r = np.concatenate([2 * e, 2 * e, 2 * e + 1, 2 * e + 1])
+
+    def blocks(k00, k01, k10, k11, cols):
+        vals = np.concatenate([np.full(ne, k00), np.full(ne, k01),
+                               np.full(ne, k10), np.full(ne, k11)])
+        shape = (2 * ne, 2 * ne if cols is r_cols else n)
+        return _finish(sp.coo_matrix((vals, (r, cols)), shape=shape))
+
+    r_cols = np.concatenate([2 * e, 2 * e + 1, 2 * e, 2 * e + 1])
+    x_cols = np.concatenate([e, e + 1, e, e + 1])
+    M_Y = blocks(h / 3, h / 6, h / 6, h / 3, r_cols)
+    Minv_Y = blocks(4 / h, -2 / h, -2 / h, 4 / h, r_cols)
+    B1_t = blocks(-0.5, 0.5, -0.5, 0.5, x_cols)
+    B2_t = blocks(h / 3, h / 6, h / 6, h / 3, x_cols)
+    return M_Y, Minv_Y, B1_t, B2_t
+
+
 # ----------------------------------------------------------------------------
 # Space: P1 on a triangulation (d = 2) or a tetrahedral mesh (d = 3).
 # ----------------------------------------------------------------------------

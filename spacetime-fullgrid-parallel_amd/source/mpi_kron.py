@@ -526,22 +526,32 @@ class MatKronIdentityMPI(LinearOperatorMPI):
 
 class SerialKron:
     """(A kron B) on a flat host vector, run on the device (single rank);
-    backs linop.KronLinOp (reference linop.py:6-15)."""
+    backs linop.KronLinOp (reference linop.py:6-15).  The time factor may be
+    rectangular and may be a matrix or any LinearOperator (it is small: it is
+    applied as a dense matrix); the space factor is a matrix or a space
+    operator (multigrid, a direct inverse, a composite)."""
     def __init__(self, mat_time, mat_space):
-        N, K = mat_time.shape
-        assert N == K, 'square time factors only'
-        self.N, self.M = N, mat_space.shape[0]
-        assert mat_space.shape[0] == mat_space.shape[1]
-        mt = scipy.sparse.csr_matrix(mat_time).tocoo()
-        self._csr = _TimeCSR(N, list(mt.row), list(mt.col), list(mt.data))
+        self.N, self.K = mat_time.shape
+        self.M, self.L = mat_space.shape
+        if scipy.sparse.issparse(mat_time):
+            dense = mat_time.toarray()
+        elif isinstance(mat_time, np.ndarray):
+            dense = mat_time
+        else:  # a LinearOperator, e.g. WaveletTransformOp or its transpose
+            dense = mat_time @ np.eye(self.K)
+        self._time = _lib.to_dev(np.ascontiguousarray(dense, dtype=np.float64))
         self._space = as_space_op(mat_space)
-        from .comm import Comm
-        self._dd = DofDistributionMPI(Comm(distributed=False), N, self.M)
 
     def matvec(self, x):
-        X = np.asarray(x, dtype=np.float64).reshape(self.N, self.M)
-        v = KronVectorMPI(self._dd, X)
-        z = v._like()
-        self._csr.apply(v, None, False, z)
-        y = self._space.apply(z.buf, n_loc=self.N)
+        X = np.asarray(x, dtype=np.float64).reshape(self.K, self.L)
+        ld_in, ld_out = self.K + (self.K & 1), self.N + (self.N & 1)
+        xin = torch.zeros((self.L, ld_in), dtype=torch.float64,
+                          device=_lib.compute_device())
+        xin[:, :self.K].copy_(torch.from_numpy(X).to(xin.device).t())
+        z = torch.empty((self.L, ld_out), dtype=torch.float64,
+                        device=xin.device)
+        _lib.check(_lib.lib().stk_time_dense_apply(
+            _lib.stream(), self.L, self.K, ld_in, self.N, ld_out,
+            _lib.ptr(self._time), _lib.ptr(xin), _lib.ptr(z)))
+        y = self._space.apply(z, n_loc=self.N)
         return y[:, :self.N].t().contiguous().cpu().numpy().reshape(-1)

@@ -586,3 +586,54 @@ def test_baseline_configs_full_size_against_oracle(stk, problem, J_space, J_time
     w, iters = PCG(h.WT_S_W, h.P, h.rhs, history=hist)
     assert 10 <= iters <= 16 and hist[-1] < 1e-12
     assert all(b < a for a, b in zip(hist, hist[1:]))
+
+
+def test_serial_kron_linop_rectangular_and_operator_factors(stk):
+    """KronLinOp (reference linop.py:6-15) with a rectangular sparse time
+    factor, a dense one and a LinearOperator one, against numpy.kron."""
+    from source.linop import KronLinOp
+    from source.wavelets import WaveletTransformOp
+    rng = np.random.RandomState(2)
+    B = sp.random(23, 17, density=0.3, random_state=rng, format='csr')
+    for A in (sp.random(6, 9, density=0.5, random_state=rng, format='csr'),
+              rng.rand(9, 5), WaveletTransformOp(3), WaveletTransformOp(3).T):
+        dense_A = A.toarray() if sp.issparse(A) else (
+            A if isinstance(A, np.ndarray) else A @ np.eye(A.shape[1]))
+        op = KronLinOp(A, B)
+        x = rng.rand(op.shape[1])
+        assert op.shape == (dense_A.shape[0] * 23, dense_A.shape[1] * 17)
+        assert relerr(op @ x, np.kron(dense_A, B.toarray()) @ x) < 1e-13
+
+
+@pytest.mark.parametrize('precond', ['multigrid', 'direct'])
+def test_serial_driver_against_oracle(stk, precond):
+    """heateq.HeatEquation (the reference's serial wiring, heateq.py:18-107) on
+    the device versus its CPU oracle, and versus the parallel driver's S."""
+    import heateq as hs
+    import heateq_mpi as hm
+    from oracle.heat_serial import HeatSerialOracle
+    from oracle.krylov import pcg
+    from source.assembly import prolongation_matrices
+    from source.linalg import PCG
+    from source.mesh import construct_2d_square_mesh
+    J_space, J_time = 3, 3
+    h = hs.HeatEquation(J_space=J_space, J_time=J_time, precond=precond)
+    mats = dict(h.time_mats, M_x=h.M_x, A_x=h.A_x, u0_x=h.u0_x,
+                P_mats=prolongation_matrices(construct_2d_square_mesh(J_space)[0]))
+    o = HeatSerialOracle(mats, J_time, precond=precond)
+    x = np.random.RandomState(4).rand(h.N * h.M)
+    assert relerr(h.B @ x, o.B(x)) < 1e-13
+    assert relerr(h.S @ x, o.S(x)) < 1e-11
+    assert relerr(h.P @ x, o.P(x)) < 1e-11
+    assert relerr(h.WT_S_W @ x, o.WT_S_W(x)) < 1e-11
+    assert relerr(h.f, o.f()) < 1e-15
+    hist = []
+    w, iters = PCG(h.WT_S_W, h.P, h.WT @ h.f, history=hist)
+    wo, iters_o, hist_o = pcg(o.WT_S_W, o.P, o.WT(o.f()))
+    assert iters == iters_o
+    assert np.allclose(hist, hist_o, rtol=1e-7, atol=1e-26)
+    assert relerr(w, wo) < 1e-7
+    # the parallel driver builds the same Schur complement from five terms
+    hp = hm.HeatEquationMPI(J_space=J_space, J_time=J_time, precond=precond)
+    xv = _vec(hp.dofs_distr, x.reshape(h.N, h.M))
+    assert relerr(_np(hp.S @ xv).reshape(-1), h.S @ x) < 1e-11

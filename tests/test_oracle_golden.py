@@ -213,3 +213,44 @@ def test_heat_wiring_pcg_lanczos_match_reference(g3, precond):
                        g3['lz_alpha_' + precond][:min(n, 8)], rtol=1e-7)
     assert abs(lz.lmax - g3['lz_lmax_' + precond]) < 1e-6 * lz.lmax
     assert abs(lz.lmin - g3['lz_lmin_' + precond]) < 1e-6 * lz.lmin
+
+
+def test_serial_wiring_equals_parallel_wiring():
+    """The serial driver's S = B^T K B + G with Y = L2_t(order 1) x H1_x
+    (reference heateq.py:37-91) is the five-term Schur complement of the
+    parallel driver (heateq_mpi.py:166-181): X_t and its derivative lie in Y_t.
+    Pins the build's test-space time matrices and the serial oracle."""
+    from oracle.heat_serial import HeatSerialOracle
+    from source.assembly import (prolongation_matrices, space_load,
+                                 space_matrices, time_matrices,
+                                 time_matrices_test_space)
+    from source.problem import problem_helper
+    for problem, J_space, J_time in (('square', 2, 3), ('cube', 1, 2)):
+        mesh, _, tmesh, data, _ = problem_helper(problem, J_space, J_time)
+        A_t, L_t, M_t, G_t, u0_t = time_matrices(tmesh)
+        M_Y, Minv_Y, B1_t, B2_t = time_matrices_test_space(tmesh)
+        assert abs(M_Y @ Minv_Y - sp.eye(M_Y.shape[0])).max() < 1e-15
+        assert abs(B1_t.T @ Minv_Y @ B1_t - A_t).max() < 1e-13
+        assert abs(B2_t.T @ Minv_Y @ B2_t - M_t).max() < 1e-15
+        assert abs(B1_t.T @ Minv_Y @ B2_t - L_t).max() < 1e-15
+        M_x, A_x = space_matrices(mesh)
+        mats = dict(A_t=A_t, L_t=L_t, M_t=M_t, G_t=G_t, M_x=M_x, A_x=A_x,
+                    P_mats=prolongation_matrices(mesh), u0_t=u0_t,
+                    u0_x=space_load(mesh, data['u0']))
+        par = HeatEquationOracle(mats, J_time)
+        ser = HeatSerialOracle(dict(mats, Minv_Y=Minv_Y, B1_t=B1_t, B2_t=B2_t),
+                               J_time)
+        X = np.random.RandomState(0).rand(par.N, par.M)
+        x = X.reshape(-1)
+        assert relerr(ser.S(x).reshape(X.shape), par.S(X)) < 1e-14
+        assert np.array_equal(ser.f(), par.rhs().reshape(-1))
+        # the serial driver numbers the wavelets level by level (heateq.py:66),
+        # the parallel one interleaved (heateq_mpi.py:105-111): same operators
+        # up to that permutation of the time index
+        perm = np.argsort(wavelets.levels(J_time, interleaved=True),
+                          kind='stable')
+        assert np.array_equal(np.asarray(par.levels)[perm], ser.levels)
+        Xp = X[perm]
+        assert relerr(ser.P(Xp.reshape(-1)).reshape(X.shape), par.P(X)[perm]) < 1e-15
+        assert relerr(ser.WT_S_W(Xp.reshape(-1)).reshape(X.shape),
+                      par.WT_S_W(X)[perm]) < 1e-13
