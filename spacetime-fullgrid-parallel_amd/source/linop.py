@@ -353,13 +353,27 @@ def KronLinOp(mat_time, mat_space):
 
 
 def BlockDiagLinOp(linops):
-    """Block diagonal of space operators (reference linop.py:29-44)."""
+    """Block diagonal of space operators (reference linop.py:29-44).  Blocks
+    that are the same operator object (the preconditioner repeats one block per
+    wavelet level, heateq.py:81-85) are applied together, one right-hand side
+    per column of a single slab."""
     linops = [as_space_op(op) for op in linops]
     height = sum(op.shape[0] for op in linops)
     width = sum(op.shape[1] for op in linops)
+    shapes = {op.shape for op in linops}
+    uniform = len(shapes) == 1 and next(iter(shapes))[0] == next(iter(shapes))[1]
+    groups = {}
+    for t, op in enumerate(linops):
+        groups.setdefault(id(op), (op, []))[1].append(t)
 
     def matvec(x):
         x = np.asarray(x, dtype=np.float64).reshape(-1)
+        if uniform:
+            X = x.reshape(len(linops), -1)
+            Y = np.empty_like(X)
+            for op, ts in groups.values():
+                Y[ts] = (op @ np.ascontiguousarray(X[ts].T)).T
+            return Y.reshape(-1)
         y = np.zeros(height)
         start_r = start_c = 0
         for op in linops:

@@ -603,6 +603,16 @@ def test_serial_kron_linop_rectangular_and_operator_factors(stk):
         x = rng.rand(op.shape[1])
         assert op.shape == (dense_A.shape[0] * 23, dense_A.shape[1] * 17)
         assert relerr(op @ x, np.kron(dense_A, B.toarray()) @ x) < 1e-13
+    # BlockDiagLinOp (linop.py:29-44): repeated blocks are batched, mixed
+    # block sizes take the block-by-block path
+    from source.linop import BlockDiagLinOp
+    C1 = sp.random(11, 11, density=0.4, random_state=rng, format='csr')
+    C2 = sp.random(11, 11, density=0.4, random_state=rng, format='csr')
+    C3 = sp.random(7, 7, density=0.5, random_state=rng, format='csr')
+    for blocks in ([C1, C2, C1, C1], [C1, C3, C1]):
+        op = BlockDiagLinOp(blocks)
+        x = rng.rand(op.shape[1])
+        assert relerr(op @ x, sp.block_diag(blocks) @ x) < 1e-14
 
 
 @pytest.mark.parametrize('precond', ['multigrid', 'direct'])
