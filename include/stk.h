@@ -60,6 +60,31 @@ int stk_axpbyz(void *stream, int64_t n, double a, const double *x, double b,
 int64_t stk_dot_work_size(void);
 int stk_dot(void *stream, int64_t n, const double *x, const double *y,
             double *work, double *out);
+/* ---- time-slab partition (DofDistributionMPI, mpi_vector.py:5-38) ---------
+ * Rank p owns the time rows [displs[p], displs[p] + counts[p]): N / size rows
+ * each, the N % size extra rows go to the last ranks.  Any output pointer may
+ * be NULL; counts / displs hold `size` entries. */
+int stk_partition(int32_t N, int32_t size, int32_t rank, int32_t *t_begin,
+                  int32_t *t_end, int32_t *counts, int32_t *displs);
+
+/* ---- preconditioned CG (PCG, linalg.py:6-42) ------------------------------
+ * Solves T w = b on this rank's slab (n = M*ld doubles, padding zero) with the
+ * reference's recurrence and stopping rule: stop when r.Pr < eps^2, at most
+ * kmax-1 iterations, return immediately if b = 0 or the initial r.Pr is small.
+ * The operators are callbacks (they launch on `stream`; T may communicate);
+ * `allreduce` sums host doubles over the ranks (NULL on one rank).  `w` holds
+ * the initial guess on entry.  `work`: stk_pcg_work_size(n) device doubles.
+ * history (host, kmax entries or NULL) receives r.Pr after the initial
+ * residual and after every iteration; *iters the iteration count. */
+typedef int (*stk_operator_fn)(void *ctx, void *stream, const double *x,
+                               double *y);
+typedef int (*stk_allreduce_fn)(void *ctx, double *values, int32_t n);
+int64_t stk_pcg_work_size(int64_t n);
+int stk_pcg_solve(void *stream, int64_t n, stk_operator_fn T, void *T_ctx,
+                  stk_operator_fn P, void *P_ctx, stk_allreduce_fn allreduce,
+                  void *allreduce_ctx, const double *b, double *w, double eps,
+                  int32_t kmax, double *work, double *history, int32_t *iters);
+
 /* ---- sum of Kronecker terms  y = beta*y + sum_k (T_k kron X_k) x_k --------
  * Replaces TridiagKronMatMPI._matvec (mpi_kron.py:214-219), i.e.
  * TridiagKronIdentityMPI (:186-201) followed by IdentityKronMatMPI (:143-150),

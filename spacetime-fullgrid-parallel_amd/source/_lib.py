@@ -23,6 +23,13 @@ class KronTerm(ctypes.Structure):
                 ('x_hi', c_p)]
 
 
+# callbacks of stk_pcg_solve (include/stk.h)
+OPERATOR_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                               ctypes.c_void_p, ctypes.c_void_p)
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p,
+                                ctypes.POINTER(ctypes.c_double), ctypes.c_int32)
+
+
 class EllPattern(ctypes.Structure):
     _fields_ = [('M', c_i32), ('K', c_i32), ('ell_idx', c_p),
                 ('row_ids', c_p), ('ovf_indptr', c_p), ('ovf_indices', c_p)]
@@ -63,6 +70,12 @@ _PROTOTYPES = {
     'stk_dot_work_size': (c_i64, []),
     'stk_dot': (ctypes.c_int, [c_p, c_i64, c_p, c_p, c_p, c_p]),
     'stk_set_tuning': (ctypes.c_int, [ctypes.c_char_p, c_i32]),
+    'stk_partition': (ctypes.c_int, [c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p]),
+    'stk_pcg_work_size': (c_i64, [c_i64]),
+    'stk_pcg_solve': (ctypes.c_int, [
+        c_p, c_i64, OPERATOR_FN, c_p, OPERATOR_FN, c_p, ALLREDUCE_FN, c_p, c_p,
+        c_p, c_f64, c_i32, c_p, c_p, c_p
+    ]),
     'stk_kron_sum_apply': (ctypes.c_int, [
         c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_i32,
         ctypes.POINTER(KronTerm), c_f64, c_p

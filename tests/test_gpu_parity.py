@@ -647,3 +647,53 @@ def test_serial_driver_against_oracle(stk, precond):
     hp = hm.HeatEquationMPI(J_space=J_space, J_time=J_time, precond=precond)
     xv = _vec(hp.dofs_distr, x.reshape(h.N, h.M))
     assert relerr(_np(hp.S @ xv).reshape(-1), h.S @ x) < 1e-11
+
+
+def test_c_pcg_solve_matches_python_pcg(stk):
+    """stk_pcg_solve (C ABI, reference linalg.py:6-42) driven through ctypes
+    callbacks into the same operators as the Python PCG: identical iteration
+    count, r.Pr history and solution."""
+    import ctypes
+    import heateq_mpi as hm
+    from source.linalg import PCG
+    from source.mpi_vector import KronVectorMPI
+    h = hm.HeatEquationMPI(J_space=3, J_time=3)
+    dd = h.dofs_distr
+    hist_py = []
+    w_py, it_py = PCG(h.WT_S_W, h.P, h.rhs, history=hist_py)
+
+    lib = stk.lib()
+    n = h.rhs.buf.numel()
+    work = torch.zeros(lib.stk_pcg_work_size(n), dtype=torch.float64, device='cuda')
+    w = KronVectorMPI(dd)
+    # the callbacks receive raw device pointers into `work`, b and w
+    known = {}
+    for k in range(4):
+        view = work[k * n:(k + 1) * n].view(h.M, -1)
+        known[view.data_ptr()] = view
+    known[w.buf.data_ptr()] = w.buf
+    known[h.rhs.buf.data_ptr()] = h.rhs.buf
+
+    def wrap(op):
+        def fn(ctx, stream, x_ptr, y_ptr):
+            try:
+                vin, vout = KronVectorMPI(dd), KronVectorMPI(dd)
+                vin._buf = known[x_ptr]
+                out = op @ vin
+                known[y_ptr].copy_(out.buf)
+                return 0
+            except Exception:  # never let an exception cross the C frame
+                return 1
+        return stk.OPERATOR_FN(fn)
+
+    T_cb, P_cb = wrap(h.WT_S_W), wrap(h.P)
+    kmax = 100
+    history = (ctypes.c_double * kmax)()
+    iters = ctypes.c_int32()
+    stk.check(lib.stk_pcg_solve(stk.stream(), n, T_cb, None, P_cb, None,
+                                stk.ALLREDUCE_FN(), None, stk.ptr(h.rhs.buf),
+                                stk.ptr(w.buf), 1e-6, kmax, stk.ptr(work),
+                                history, ctypes.byref(iters)))
+    assert iters.value == it_py
+    assert np.allclose(list(history)[:it_py + 1], hist_py, rtol=1e-9, atol=1e-28)
+    assert relerr(_np(w), _np(w_py)) < 1e-9

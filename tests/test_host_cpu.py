@@ -316,3 +316,29 @@ def test_numbering_gives_shallow_gauss_seidel_schedules():
         for backward in (False, True):
             assert len(gauss_seidel_schedule(A_x.indptr, A_x.indices, backward)[0]) - 1 == 3
             assert len(gauss_seidel_schedule(M_x.indptr, M_x.indices, backward)[0]) - 1 == 4
+
+
+def test_c_partition_matches_reference_tables():
+    """stk_partition (host code of libstk, no GPU needed) against the tables the
+    reference's DofDistributionMPI produced (tests/golden/g2_partition.npz)."""
+    import ctypes
+    from source import _lib
+    lib = _lib.lib()
+    g = load_golden('g2_partition')
+    for N in (9, 33, 65, 129):
+        for size in (1, 2, 4, 8):
+            tag = 'N%d_s%d' % (N, size)
+            counts = (ctypes.c_int32 * size)()
+            displs = (ctypes.c_int32 * size)()
+            for rank in range(size):
+                tb, te = ctypes.c_int32(), ctypes.c_int32()
+                assert lib.stk_partition(N, size, rank, ctypes.byref(tb),
+                                         ctypes.byref(te), counts, displs) == 0
+                assert [tb.value, te.value] == list(g['dist_' + tag][rank])
+            # the reference's counts / displs are in vector entries (rows * M)
+            dist = g['dist_' + tag]
+            M = g['counts_' + tag][0] / (dist[0][1] - dist[0][0])
+            assert [c * M for c in counts] == list(g['counts_' + tag])
+            assert [d * M for d in displs] == list(g['displs_' + tag])
+    assert lib.stk_partition(3, 4, 0, None, None, None, None) != 0
+    assert b'more ranks' in lib.stk_last_error()
