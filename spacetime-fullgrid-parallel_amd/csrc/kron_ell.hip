@@ -62,7 +62,7 @@ struct EllArgs {
 // common case runs without its branches.
 // WIDE (with GENERIC only): slabs of 4 GiB and more, see stk_slab.
 template <int NT, bool SHARED_IN, int K, int NPF, bool GENERIC, bool WIDE>
-__global__ __launch_bounds__(BS, 6 * 512 / BS > 8 ? 8 : 6) void kron_ell_kernel(const EllArgs<NT> a)
+__global__ __launch_bounds__(BS, K >= 12 ? 4 : 6) void kron_ell_kernel(const EllArgs<NT> a)
 {
     static_assert(GENERIC || !WIDE, "the fast path is for slabs below 4 GiB");
     constexpr int KS = (K + 3) & ~3;  // LDS stride of a row's slots (16-byte vectors)
@@ -331,7 +331,8 @@ int launch2(hipStream_t st, const EllArgs<NT> &a_in, int K)
                        sizeof(int32_t) * ((size_t)a.R * KS + a.R + 4) +
                        sizeof(double) * (size_t)NT * 3 * (a.n_loc + 2) + 32;
     const int n_cu = stk_cu_count();
-    int per_cu = g_ell_wg_per_cu > 0 ? g_ell_wg_per_cu : 3;
+    // wide rows (K >= 12, e.g. the 15-point mass matrix of the cube) get 128 VGPRs: 2 workgroups per CU
+    int per_cu = g_ell_wg_per_cu > 0 ? g_ell_wg_per_cu : (K >= 12 ? 2 : 3);
     const int by_lds = (int)(160 * 1024 / (lds + 256));
     if (per_cu > by_lds) per_cu = by_lds > 0 ? by_lds : 1;
     int per_xcd = (n_cu / 8) * per_cu;

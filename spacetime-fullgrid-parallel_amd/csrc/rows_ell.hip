@@ -41,7 +41,7 @@ struct RowsArgs {
 };
 
 template <int MODE, int K, int NPF, bool HAS_M, bool WIDE>
-__global__ __launch_bounds__(BS, 6) void rows_ell_kernel(const RowsArgs a)
+__global__ __launch_bounds__(BS, K >= 12 ? 4 : 6) void rows_ell_kernel(const RowsArgs a)
 {
     constexpr int KS = (K + 3) & ~3;
     extern __shared__ double sm[];
@@ -306,7 +306,8 @@ int stk_rows_ell_launch(hipStream_t st, int mode, const stk_ell_rows *e, int32_t
         ((size_t)(has_m ? 2 : 1) * a.R * KS + 2 * a.R + ((size_t)a.R * KS + a.R + 1) / 2 + 2) & ~(size_t)1;
     const size_t lds = 2 * buf_doubles * sizeof(double) + 16;
     const int n_cu = stk_cu_count();
-    int per_cu = g_rows_wg_per_cu > 0 ? g_rows_wg_per_cu : 3;
+    // wide rows (K >= 12) get 128 VGPRs: 2 workgroups per CU
+    int per_cu = g_rows_wg_per_cu > 0 ? g_rows_wg_per_cu : (K >= 12 ? 2 : 3);
     int per_xcd = (n_cu / 8) * per_cu;
     if (per_xcd > a.chunk) per_xcd = a.chunk;
     if (per_xcd < 1) per_xcd = 1;
