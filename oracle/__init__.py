@@ -3,7 +3,8 @@
 This package restates, in NumPy/SciPy (plus one small C file for the
 sequential Gauss-Seidel sweep), the algorithms of the reference's hot path
 (Jannertje/spacetime-fullgrid-parallel: source/mpi_vector.py, mpi_kron.py,
-wavelets.py, multigrid.py, linalg.py, lanczos.py, heateq_mpi.py:126-191).
+wavelets.py, multigrid.py, linalg.py, lanczos.py, heateq_mpi.py:126-191, and
+the serial wiring heateq.py:18-107 in heat_serial.py).
 Each function cites the reference file:line it follows.
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
@@ -22,4 +23,7 @@ petsc4py, unpinned version, absent here); the golden multigrid vectors were
 produced with the reference's own ``MGM`` control flow (multigrid.py:168-193)
 driving the reference's own pure-Python ``Smoother`` (multigrid.py:83-97) in
 place of PETSc.  Parity at the PETSc boundary itself is unpinned.
+heat_serial.py (the serial driver, which needs NGSolve to run in the reference)
+is pinned through the rest: its Schur complement is checked to equal the
+parallel wiring's, which the goldens pin (test_serial_wiring_equals_parallel_wiring).
 """
