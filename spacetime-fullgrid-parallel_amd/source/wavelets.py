@@ -46,6 +46,32 @@ def _level_matrix(J, j):
     return sp.csr_matrix((vals, (rows, cols)), shape=(n, n))
 
 
+def WaveletTransformMat(J):
+    """The transform as an explicit matrix, wavelets ordered level by level
+    (debug helper of the reference, wavelets.py:9-42; dense-ish, host only).
+    Built from the two-scale relations directly, independently of the device
+    kernel: T_0 = I_2 and T_j = [P_j T_{j-1} | Q_j], where P_j interpolates hat
+    functions from 2^(j-1) to 2^j elements and column m of Q_j is the 3-point
+    wavelet at the odd node 2m+1: 2^(j/2) * (-1/2, 1, -1/2), with -1 instead
+    of -1/2 on a boundary node."""
+    T = np.eye(2)
+    for j in range(1, J + 1):
+        nc, nf = 2**(j - 1) + 1, 2**j + 1
+        P = np.zeros((nf, nc))
+        P[np.arange(0, nf, 2), np.arange(nc)] = 1.0
+        odd = np.arange(1, nf, 2)
+        P[odd, odd // 2] = 0.5
+        P[odd, odd // 2 + 1] = 0.5
+        Q = np.zeros((nf, nc - 1))
+        cols = np.arange(nc - 1)
+        Q[odd, cols] = 1.0
+        Q[odd - 1, cols] = -0.5
+        Q[odd + 1, cols] = -0.5
+        Q[0, 0] = Q[-1, -1] = -1.0
+        T = np.hstack([P @ T, 2**(j / 2) * Q])
+    return sp.csr_matrix(T)
+
+
 class WaveletTransformOp(sp.linalg.LinearOperator):
     """Matrix-free W_t, applied on the device (reference wavelets.py:45-169).
 
