@@ -54,6 +54,8 @@ class SchurMPI(LinearOperatorMPI):
     of V-cycles from zero) is linear; tests bound the difference."""
     def __init__(self, dofs_distr, A_t, L_t, M_t, G_t, M_x, A_x, Kinv_x):
         super().__init__(dofs_distr)
+        self._factors = (A_t, L_t, M_t, G_t, M_x, A_x)
+        self._linops = None
         self.Kinv_x = as_space_op(Kinv_x)
         self.ell = EllMatrices([M_x, A_x])  # matrix 0 = M_x, 1 = A_x
         self._couples = {}
@@ -68,6 +70,25 @@ class SchurMPI(LinearOperatorMPI):
         self.tA, self.tL, self.tM, self.tG = tri(A_t), tri(L_t), tri(
             M_t), tri(G_t)
         self.tLT = tri(L_t.T.tocsr())
+
+    @property
+    def linops(self):
+        """The five Kronecker terms of the reference's SumMPI
+        (heateq_mpi.py:166-181), built on first use: for callers that inspect
+        ``S.linops`` (heateq_mpi_test.py:59-61, 120); the apply does not use
+        them."""
+        if self._linops is None:
+            A_t, L_t, M_t, G_t, M_x, A_x = self._factors
+            dd, K = self.dofs_distr, self.Kinv_x
+            self._linops = [
+                TridiagKronMatMPI(dd, A_t, CompositeLinOp([M_x, K, M_x])),
+                TridiagKronMatMPI(dd, L_t, CompositeLinOp([M_x, K, A_x])),
+                TridiagKronMatMPI(dd, L_t.T.tocsr(),
+                                  CompositeLinOp([A_x, K, M_x])),
+                TridiagKronMatMPI(dd, M_t, CompositeLinOp([A_x, K, A_x])),
+                TridiagKronMatMPI(dd, G_t, M_x),
+            ]
+        return self._linops
 
     def _spec(self, tri, k, vec):
         """(tri, matrix, x, x_lo, x_hi) with the ghost rows only where the time

@@ -341,3 +341,193 @@ def test_multigrid_symmetric(comm):  # multigrid_test.py:87-98
         mg = MultiGrid(A, MeshHierarchy(mesh))
         mg_mat = as_matrix(mg)
         assert np.allclose(mg_mat.T, mg_mat)
+
+
+# ---- heateq_mpi_test.py -------------------------------------------------------
+refines = 2
+
+
+def linop_test_apply_MPI(linop_mpi, linop):  # heateq_mpi_test.py:191-205
+    from source.mpi_vector import KronVectorMPI
+    np.random.seed(123123)
+    x_mpi = KronVectorMPI(linop_mpi.dofs_distr)
+    x_glob = y_glob = None
+    if x_mpi.rank == 0:
+        x_glob = np.random.rand(linop_mpi.N * linop_mpi.M)
+        y_glob = linop @ x_glob
+    x_mpi.scatter(x_glob)
+    x_mpi = linop_mpi @ x_mpi
+    x_mpi.gather(x_glob)
+    if x_mpi.rank == 0:
+        assert np.allclose(x_glob, y_glob)
+
+
+def test_multigrid(comm):  # heateq_mpi_test.py:17-33
+    from heateq_mpi import HeatEquationMPI
+    from source.linop import CompositeLinOp
+    from source.mpi_kron import as_matrix
+    heat_eq_mpi = HeatEquationMPI(2, precond='multigrid')
+    M = heat_eq_mpi.M
+    for linop in [
+            heat_eq_mpi.Kinv_x,
+            CompositeLinOp([heat_eq_mpi.Kinv_x, heat_eq_mpi.M_x]),
+            CompositeLinOp([heat_eq_mpi.Kinv_x, heat_eq_mpi.A_x])
+    ]:
+        x = np.random.rand(M)
+        mat = as_matrix(linop)
+        assert np.allclose(linop @ x, mat @ x)
+
+
+def test_bilforms(comm):  # heateq_mpi_test.py:36-63
+    from heateq_mpi import HeatEquationMPI
+    from source.mpi_kron import as_matrix
+    from source.mpi_vector import DofDistributionMPI, KronVectorMPI
+
+    def check_linop(N, M, linop):
+        dofs_distr = DofDistributionMPI(comm, N, M)
+        x_mpi = KronVectorMPI(dofs_distr)
+        x_glob = y_glob = None
+        if comm.Get_rank() == 0:
+            x_glob = np.random.rand(N * M) * 1.0
+            y_glob = np.kron(as_matrix(linop.mat_time),
+                             as_matrix(linop.mat_space)) @ x_glob
+        x_mpi.scatter(x_glob)
+        x_mpi = linop @ x_mpi
+        x_mpi.gather(x_glob)
+        if comm.Get_rank() == 0:
+            assert np.allclose(y_glob, x_glob)
+
+    heat_eq_mpi = HeatEquationMPI(2)
+    for linop in heat_eq_mpi.S.linops:
+        check_linop(heat_eq_mpi.N, heat_eq_mpi.M, linop)
+
+
+def test_matrices(comm):  # heateq_mpi_test.py:66-94
+    from heateq import HeatEquation
+    from heateq_mpi import HeatEquationMPI
+    from source.mpi_kron import as_matrix
+    J_time, J_space, problem = 4, 2, 'square'
+    heat_eq_mpi = HeatEquationMPI(J_time=J_time, J_space=J_space,
+                                  problem=problem, wavelettransform='original',
+                                  precond='direct')
+    WT_S_W_mpi = heat_eq_mpi.WT_S_W.as_global_matrix()
+    P_mpi = heat_eq_mpi.P.as_global_matrix()
+    if comm.Get_rank() == 0:
+        heat_eq = HeatEquation(J_time=J_time, J_space=J_space, problem=problem,
+                               precond='direct')
+        assert np.allclose(as_matrix(heat_eq.WT_S_W), WT_S_W_mpi)
+        assert np.allclose(as_matrix(heat_eq.P), P_mpi)
+
+
+def test_S_apply(comm):  # heateq_mpi_test.py:97-135
+    from heateq import HeatEquation
+    from heateq_mpi import HeatEquationMPI
+    from source.mpi_vector import DofDistributionMPI, KronVectorMPI
+    J_time, J_space = 4, 2
+    heat_eq_mpi = HeatEquationMPI(J_time=J_time, J_space=J_space,
+                                  precond='direct')
+    N, M = heat_eq_mpi.N, heat_eq_mpi.M
+    rank = comm.Get_rank()
+    dofs_distr = DofDistributionMPI(comm, N, M)
+    x_mpi = KronVectorMPI(dofs_distr)
+    x_glob = y_glob = z_glob = None
+    if rank == 0:
+        np.random.seed(0)
+        x_glob = np.random.rand(N * M) * 1.0
+        heat_eq = HeatEquation(J_time=J_time, J_space=refines,
+                               problem='square', precond='direct')
+        y_glob = heat_eq.S @ x_glob
+        S = sum([linop.as_matrix() for linop in heat_eq_mpi.S.linops])
+        z_glob = S @ x_glob
+    x_mpi.scatter(x_glob)
+    y_mpi = heat_eq_mpi.S @ x_mpi
+    y_mpi.gather(x_glob)
+    if rank == 0:
+        assert np.allclose(x_glob, z_glob)
+        assert np.allclose(x_glob, y_glob)
+
+
+def test_solve(comm):  # heateq_mpi_test.py:138-188
+    import scipy.sparse
+    from heateq import HeatEquation
+    from heateq_mpi import HeatEquationMPI
+    from source.linalg import PCG
+    from source.mpi_kron import IdentityMPI
+    from source.mpi_vector import DofDistributionMPI
+    J_time, J_space = 4, 2
+    for precond in ['direct', 'multigrid']:
+        heat_eq_mpi = HeatEquationMPI(J_time=J_time, J_space=J_space,
+                                      problem='square', precond=precond,
+                                      smoothsteps=3, vcycles=4)
+        N, M = heat_eq_mpi.N, heat_eq_mpi.M
+        dofs_distr = DofDistributionMPI(comm, N, M)
+        rank = comm.Get_rank()
+        u_glob_mpi = f_glob_mpi = None
+        if rank == 0:
+            u_glob_mpi = np.empty(N * M)
+            f_glob_mpi = np.empty(N * M)
+            heat_eq = HeatEquation(J_time=J_time, J_space=refines,
+                                   problem='square', precond='direct')
+            u_glob_demo, _ = PCG(heat_eq.S, scipy.sparse.identity(N * M),
+                                 heat_eq.f)
+        u_mpi, _ = PCG(heat_eq_mpi.S, IdentityMPI(dofs_distr), heat_eq_mpi.rhs)
+        u_mpi.gather(u_glob_mpi)
+        heat_eq_mpi.rhs.gather(f_glob_mpi)
+        if rank == 0:
+            assert np.allclose(heat_eq.f, f_glob_mpi)
+            assert np.allclose(u_glob_demo, u_glob_mpi)
+
+
+def test_demo(comm):  # heateq_mpi_test.py:208-243
+    from heateq import HeatEquation
+    from heateq_mpi import HeatEquationMPI
+    from source.mpi_kron import as_matrix
+    for problem in ['square', 'cube']:
+        refs = 2 if problem == 'square' else 1
+        heat_eq_mpi = HeatEquationMPI(refs, precond='direct',
+                                      wavelettransform='original',
+                                      problem=problem)
+        heat_eq = HeatEquation(problem=problem, J_space=refs, precond='direct')
+        linop_test_MPI(comm, heat_eq_mpi.WT_S_W,
+                       as_matrix(heat_eq.WT @ heat_eq.S @ heat_eq.W))
+        linop_test_MPI(comm, heat_eq_mpi.P, as_matrix(heat_eq.P))
+        for refs in range(1, 3):
+            heat_eq_mpi = HeatEquationMPI(refs, precond='direct',
+                                          wavelettransform='original',
+                                          problem=problem)
+            for op in (heat_eq_mpi.S, heat_eq_mpi.W, heat_eq_mpi.WT,
+                       heat_eq_mpi.WT_S_W, heat_eq_mpi.P):
+                linearity_test_MPI(comm, op)
+            heat_eq = HeatEquation(problem=problem, J_space=refs,
+                                   precond='direct')
+            linop_test_apply_MPI(heat_eq_mpi.S, heat_eq.S)
+            linop_test_apply_MPI(heat_eq_mpi.W, heat_eq.W)
+            linop_test_apply_MPI(heat_eq_mpi.WT, heat_eq.WT)
+            linop_test_apply_MPI(heat_eq_mpi.WT_S_W,
+                                 heat_eq.WT @ heat_eq.S @ heat_eq.W)
+            linop_test_apply_MPI(heat_eq_mpi.P, heat_eq.P)
+
+
+def test_preconditioner(comm):  # heateq_mpi_test.py:246-274
+    from heateq import HeatEquation
+    from heateq_mpi import HeatEquationMPI
+    from source.lanczos import Lanczos
+    from source.linalg import PCG
+    from source.mpi_kron import IdentityMPI
+    from source.mpi_vector import DofDistributionMPI, KronVectorMPI
+    J_time, J_space, precond = 4, 2, 'direct'
+    heat_eq_mpi = HeatEquationMPI(J_time=J_time, J_space=J_space,
+                                  precond=precond)
+    N, M = heat_eq_mpi.N, heat_eq_mpi.M
+    dofs_distr = DofDistributionMPI(comm, N, M)
+    w_mpi = KronVectorMPI(dofs_distr)
+    _fill(w_mpi, np.random.rand(w_mpi.X_loc.shape[0], M))
+    lanczos_mpi = Lanczos(heat_eq_mpi.WT_S_W, heat_eq_mpi.P, w=w_mpi)
+    u_mpi_I, iters_I = PCG(heat_eq_mpi.S, IdentityMPI(dofs_distr),
+                           heat_eq_mpi.rhs)
+    u_mpi_P, iters_P = PCG(heat_eq_mpi.WT_S_W, heat_eq_mpi.P, heat_eq_mpi.rhs)
+    assert iters_P < iters_I
+    if w_mpi.rank == 0:
+        heat_eq = HeatEquation(J_time=J_time, J_space=J_space, precond=precond)
+        lanczos_demo = Lanczos(heat_eq.WT_S_W, heat_eq.P)
+        assert abs(lanczos_mpi.cond() - lanczos_demo.cond()) < 0.1
