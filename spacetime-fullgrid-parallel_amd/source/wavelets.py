@@ -242,8 +242,10 @@ class WaveletTransformKronIdentityMPI(CompositeMPI):
         self._fused = _FusedWavelet(J, False) if dofs_distr.size == 1 else None
         # across ranks: 'transpose' (default) or 'composite' (the reference's
         # per-level exchange)
-        self.mode = 'transpose'
-        self._transposed = _TransposedWavelet(dofs_distr, J, False)
+        # (with fewer space dofs than ranks there is nothing to transpose onto)
+        self.mode = 'transpose' if dofs_distr.M >= dofs_distr.size else 'composite'
+        self._transposed = (_TransposedWavelet(dofs_distr, J, False)
+                            if self.mode == 'transpose' else None)
 
     def _matvec(self, vec_in, vec_out):
         if self._fused is None and self.mode == 'composite':
@@ -271,8 +273,10 @@ class TransposedWaveletTransformKronIdentityMPI(CompositeMPI):
                                       add_identity=True))
         super().__init__(dofs_distr, linops)
         self._fused = _FusedWavelet(J, True) if dofs_distr.size == 1 else None
-        self.mode = 'transpose'
-        self._transposed = _TransposedWavelet(dofs_distr, J, True)
+        # (with fewer space dofs than ranks there is nothing to transpose onto)
+        self.mode = 'transpose' if dofs_distr.M >= dofs_distr.size else 'composite'
+        self._transposed = (_TransposedWavelet(dofs_distr, J, True)
+                            if self.mode == 'transpose' else None)
 
     def _matvec(self, vec_in, vec_out):
         if self._fused is None and self.mode == 'composite':

@@ -49,3 +49,12 @@ def test_distributed_solve_ranks_sharing_one_gpu(nproc, problem):
     out = _run('mp_gpu_worker.py', nproc, {'STK_BACKEND': 'gloo',
                                            'STK_TEST_PROBLEM': problem})
     assert 'mp_gpu_worker ok' in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('nproc', [2, 3])
+def test_reference_unit_tests_on_several_ranks(nproc):
+    """The reference runs its unit tests under mpirun; the mirrored suite
+    (test_reference_suite.py) likewise on 2 and 3 ranks sharing the GPU."""
+    out = _run('mp_refsuite_worker.py', nproc, {'STK_BACKEND': 'gloo'})
+    assert 'mp_refsuite_worker ok' in out
