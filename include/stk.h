@@ -243,9 +243,13 @@ typedef struct {
      * locality order, for the residual.  ell_fwd / ell_bwd: the level matrix
      * with its rows listed group by group of the forward / backward
      * Gauss-Seidel schedule; *_pos_host[g] .. [g+1] is the position range of
-     * group g (n_fwd+1 / n_bwd+1 entries).  ell_p / ell_r: the transfers. */
+     * group g (n_fwd+1 / n_bwd+1 entries).  ell_p / ell_r: the transfers.
+     * ell_ra (optional): the product R * (level matrix) on the coarse rows
+     * (va = R*vals_a, vm = R*vals_m): the restricted residual is then formed
+     * as (R A) u - R f without writing the fine residual. */
     const stk_ell_rows *ell_a, *ell_fwd, *ell_bwd, *ell_p, *ell_r;
     const int32_t *fwd_pos_host, *bwd_pos_host;
+    const stk_ell_rows *ell_ra;
 } stk_mg_level;
 
 typedef struct stk_mg stk_mg;

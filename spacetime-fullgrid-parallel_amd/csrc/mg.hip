@@ -89,12 +89,13 @@ int stk_rows_ell_launch(hipStream_t st, int mode, const stk_ell_rows *e, int32_t
                         int32_t n_loc, int32_t ld, int64_t x_rows, int64_t y_rows, double ca, const double *cm,
                         const double *x, double alpha, double beta, const double *z, double *y);
 
+int g_mg_fuse_restrict = 1;     // 0: residual and restriction as two steps
 int g_mg_fuse_coarse = 1;       // 0 disables the fused coarse sub-V-cycle
 int g_mg_coarse_max_rows = 1024;  // levels up to this many rows are fused (larger ones fill the GPU by themselves)
 
 struct EllLevel {
-    bool has_a = false, has_gs = false, has_p = false, has_r = false;
-    stk_ell_rows a, fwd, bwd, p, r;
+    bool has_a = false, has_gs = false, has_p = false, has_r = false, has_ra = false;
+    stk_ell_rows a, fwd, bwd, p, r, ra;
     std::vector<int32_t> fwd_pos, bwd_pos;
 };
 
@@ -172,21 +173,31 @@ static int mgm(stk_mg *mg, hipStream_t st, int j, int n_loc, int ld, double ca, 
     double *r_j = mg->r[j], *d_c = mg->f[j - 1], *u_c = mg->u[j - 1];
     const EllLevel &E = mg->ell[j];
     const bool even = ell_slab_ok(L.n, ld);
-    // r_j = A_j u_j - f_j
-    if (E.has_a && even)
-        rc = stk_rows_ell_launch(st, 0, &E.a, 0, E.a.n_pos, n_loc, ld, L.n, L.n, ca, cm, u_j, 1.0, -1.0, f_j, r_j);
-    else
-        rc = stk_csr_spmm(st, L.n, n_loc, ld, L.indptr, L.indices, L.vals_a, ca, cm ? L.vals_m : nullptr, cm, u_j,
-                          1.0, -1.0, f_j, r_j);
-    if (rc) return rc;
-    // d_c = R r_j
-    if (E.has_r && even)
-        rc = stk_rows_ell_launch(st, 0, &E.r, 0, E.r.n_pos, n_loc, ld, L.n, C.n, 1.0, nullptr, r_j, 1.0, 0.0,
-                                 nullptr, d_c);
-    else
-        rc = stk_csr_spmm(st, C.n, n_loc, ld, L.r_indptr, L.r_indices, L.r_vals, 1.0, nullptr, nullptr, r_j, 1.0,
-                          0.0, nullptr, d_c);
-    if (rc) return rc;
+    if (g_mg_fuse_restrict && E.has_ra && E.has_r && even) {
+        // d_c = R (A_j u_j - f_j) = (R A_j) u_j - R f_j: the fine residual is never written
+        rc = stk_rows_ell_launch(st, 0, &E.r, 0, E.r.n_pos, n_loc, ld, L.n, C.n, 1.0, nullptr, f_j, 1.0, 0.0, nullptr,
+                                 d_c);
+        if (rc) return rc;
+        rc = stk_rows_ell_launch(st, 0, &E.ra, 0, E.ra.n_pos, n_loc, ld, L.n, C.n, ca, cm, u_j, 1.0, -1.0, d_c, d_c);
+        if (rc) return rc;
+    } else {
+        // r_j = A_j u_j - f_j
+        if (E.has_a && even)
+            rc = stk_rows_ell_launch(st, 0, &E.a, 0, E.a.n_pos, n_loc, ld, L.n, L.n, ca, cm, u_j, 1.0, -1.0, f_j,
+                                     r_j);
+        else
+            rc = stk_csr_spmm(st, L.n, n_loc, ld, L.indptr, L.indices, L.vals_a, ca, cm ? L.vals_m : nullptr, cm,
+                              u_j, 1.0, -1.0, f_j, r_j);
+        if (rc) return rc;
+        // d_c = R r_j
+        if (E.has_r && even)
+            rc = stk_rows_ell_launch(st, 0, &E.r, 0, E.r.n_pos, n_loc, ld, L.n, C.n, 1.0, nullptr, r_j, 1.0, 0.0,
+                                     nullptr, d_c);
+        else
+            rc = stk_csr_spmm(st, C.n, n_loc, ld, L.r_indptr, L.r_indices, L.r_vals, 1.0, nullptr, nullptr, r_j,
+                              1.0, 0.0, nullptr, d_c);
+        if (rc) return rc;
+    }
     STK_HIP(hipMemsetAsync(u_c, 0, sizeof(double) * (size_t)C.n * ld, st));
     rc = mgm(mg, st, j - 1, n_loc, ld, ca, cm, kind, d_c, u_c);
     if (rc) return rc;
@@ -223,6 +234,7 @@ extern "C" int stk_mg_create(int32_t n_levels, const stk_mg_level *levels, int32
         if (L.ell_a) { E.a = *L.ell_a; E.has_a = true; }
         if (L.ell_p) { E.p = *L.ell_p; E.has_p = true; }
         if (L.ell_r) { E.r = *L.ell_r; E.has_r = true; }
+        if (L.ell_ra) { E.ra = *L.ell_ra; E.has_ra = true; }
         if (L.ell_fwd && L.ell_bwd && L.fwd_pos_host && L.bwd_pos_host) {
             E.fwd = *L.ell_fwd;
             E.bwd = *L.ell_bwd;
@@ -231,6 +243,7 @@ extern "C" int stk_mg_create(int32_t n_levels, const stk_mg_level *levels, int32
             E.has_gs = true;
         }
         mg->lv[j].ell_a = mg->lv[j].ell_fwd = mg->lv[j].ell_bwd = mg->lv[j].ell_p = mg->lv[j].ell_r = nullptr;
+        mg->lv[j].ell_ra = nullptr;
     }
     mg->u.assign(n_levels, nullptr);
     mg->f.assign(n_levels, nullptr);

@@ -233,8 +233,9 @@ int launch_k(hipStream_t st, const RowsArgs &a, int K, unsigned grid, size_t lds
         case 9: return launch_npf<MODE, 9, HAS_M>(st, a, grid, lds);
         case 12: return launch_npf<MODE, 12, HAS_M>(st, a, grid, lds);
         case 16: return launch_npf<MODE, 16, HAS_M>(st, a, grid, lds);
+        case 20: return launch_npf<MODE, 20, HAS_M>(st, a, grid, lds);
     }
-    stk_set_error("rows_ell: K=%d is not one of 2, 5, 7, 9, 12, 16", K);
+    stk_set_error("rows_ell: K=%d is not one of 2, 5, 7, 9, 12, 16, 20", K);
     return 2;
 }
 

@@ -58,7 +58,8 @@ class MGLevel(ctypes.Structure):
                 ('ell_bwd', ctypes.POINTER(EllRows)),
                 ('ell_p', ctypes.POINTER(EllRows)),
                 ('ell_r', ctypes.POINTER(EllRows)),
-                ('fwd_pos_host', c_p), ('bwd_pos_host', c_p)]
+                ('fwd_pos_host', c_p), ('bwd_pos_host', c_p),
+                ('ell_ra', ctypes.POINTER(EllRows))]
 
 
 _PROTOTYPES = {

@@ -211,7 +211,7 @@ class EllRowsMatrix:
     include/stk.h).  `order` lists the rows in processing order; `diag` adds
     the diagonal arrays the Gauss-Seidel mode needs.  `ok` is False when a row
     has more entries than the largest instantiated slot count."""
-    SLOTS = (2, 5, 7, 9, 12, 16)
+    SLOTS = (2, 5, 7, 9, 12, 16, 20)
 
     def __init__(self, indptr, indices, va, vm=None, order=None, n_cols=None,
                  diag=False):

@@ -179,6 +179,13 @@ class _DeviceHierarchy:
                 ells[name] = EllRowsMatrix(m.indptr, m.indices, m.data, None,
                                            order)
             if all(e.ok for e in ells.values()):
+                # restricted residual in one step: d = (R A) u - R f
+                prods = [_drop_roundoff(sp.csr_matrix(R @ m)) for m in mats]
+                ra_ptr, ra_idx, ra_vals = union_pattern(prods)
+                ra = EllRowsMatrix(ra_ptr, ra_idx, ra_vals[0],
+                                   ra_vals[1] if self.has_m else None, tile_c)
+                if ra.ok:
+                    ells['ra'] = ra
                 for name, e in ells.items():
                     setattr(L, 'ell_' + name, ctypes.pointer(e.struct))
                 host['ells'] = ells

@@ -528,6 +528,10 @@ def test_coarse_subcycle_variants_agree(stk):
         x = _vec(h.dofs_distr, X)
         res = []
         try:
+            # the level-by-level path would otherwise form its restricted
+            # residuals through R*A (test_restricted_residual_variants_agree),
+            # which the job list does not: compare like with like
+            stk.check(stk.lib().stk_set_tuning(b'mg_fuse_restrict', 0))
             for fuse, lds in ((0, 0), (1, 0), (1, 1)):
                 stk.check(stk.lib().stk_set_tuning(b'mg_fuse_coarse', fuse))
                 stk.check(stk.lib().stk_set_tuning(b'mg_coarse_lds', lds))
@@ -535,6 +539,7 @@ def test_coarse_subcycle_variants_agree(stk):
         finally:
             stk.check(stk.lib().stk_set_tuning(b'mg_fuse_coarse', 1))
             stk.check(stk.lib().stk_set_tuning(b'mg_coarse_lds', 1))
+            stk.check(stk.lib().stk_set_tuning(b'mg_fuse_restrict', 1))
         for Pv, Sv in res[1:]:
             assert np.array_equal(Pv, res[0][0]) and np.array_equal(Sv, res[0][1])
 
@@ -697,3 +702,22 @@ def test_c_pcg_solve_matches_python_pcg(stk):
     assert iters.value == it_py
     assert np.allclose(list(history)[:it_py + 1], hist_py, rtol=1e-9, atol=1e-28)
     assert relerr(_np(w), _np(w_py)) < 1e-9
+
+
+def test_restricted_residual_variants_agree(stk):
+    """d = R (A u - f) in two steps, or as (R A) u - R f with the precomputed
+    product R A (stk_mg_level.ell_ra): same V-cycle up to rounding."""
+    import heateq_mpi as hm
+    for problem, J_space in (('square', 5), ('lshape', 4)):
+        h = hm.HeatEquationMPI(J_space=J_space, J_time=3, problem=problem)
+        x = _vec(h.dofs_distr, np.random.RandomState(12).rand(h.N, h.M))
+        res = []
+        try:
+            for fuse in (0, 1):
+                stk.check(stk.lib().stk_set_tuning(b'mg_fuse_restrict', fuse))
+                res.append((_np(h.P @ x), _np(h.S @ x)))
+        finally:
+            stk.check(stk.lib().stk_set_tuning(b'mg_fuse_restrict', 1))
+        assert relerr(res[1][0], res[0][0]) < 1e-13
+        assert relerr(res[1][1], res[0][1]) < 1e-13
+        assert not np.array_equal(res[1][0], res[0][0])  # the fused path did run
