@@ -233,7 +233,8 @@ __global__ __launch_bounds__(CBS) void mg_coarse_lds_kernel(const CoarseArgs a)
                 case 7: run_rows_job_lds<7, HAS_M>(j, a, sv, cm0, cm1, has1); break;
                 case 9: run_rows_job_lds<9, HAS_M>(j, a, sv, cm0, cm1, has1); break;
                 case 12: run_rows_job_lds<12, HAS_M>(j, a, sv, cm0, cm1, has1); break;
-                default: run_rows_job_lds<16, HAS_M>(j, a, sv, cm0, cm1, has1); break;
+                case 16: run_rows_job_lds<16, HAS_M>(j, a, sv, cm0, cm1, has1); break;
+                default: run_rows_job_lds<20, HAS_M>(j, a, sv, cm0, cm1, has1); break;
             }
         }
         __syncthreads();
@@ -283,7 +284,8 @@ __global__ __launch_bounds__(CBS) void mg_coarse_kernel(const CoarseArgs a)
                 case 7: run_rows_job<7, HAS_M>(j, a, p0, W); break;
                 case 9: run_rows_job<9, HAS_M>(j, a, p0, W); break;
                 case 12: run_rows_job<12, HAS_M>(j, a, p0, W); break;
-                default: run_rows_job<16, HAS_M>(j, a, p0, W); break;
+                case 16: run_rows_job<16, HAS_M>(j, a, p0, W); break;
+                default: run_rows_job<20, HAS_M>(j, a, p0, W); break;
             }
         }
         // the next job reads what this one wrote (same workgroup, same time pairs)

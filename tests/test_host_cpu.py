@@ -207,7 +207,7 @@ def test_union_pattern_and_ell_formats(host_uploads):
         for s in range(e.K):
             D[ridx[pos], e.idx.numpy()[pos, s]] += e.va.numpy()[pos, s]
     assert abs(D - C.toarray()).max() == 0
-    wide = sp.csr_matrix(np.ones((3, 20)))
+    wide = sp.csr_matrix(np.ones((3, EllRowsMatrix.SLOTS[-1] + 1)))
     assert not EllRowsMatrix(wide.indptr, wide.indices, wide.data).ok
 
 
