@@ -153,7 +153,11 @@ __global__ __launch_bounds__(BS, K >= 12 ? 4 : 6) void rows_ell_kernel(const Row
             double2 zv = make_double2(0.0, 0.0), own = make_double2(0.0, 0.0);
             if (MODE == MODE_GS) {
                 zv = sz.load(yo, t0_bytes);
-                own = sx.load(yo, t0_bytes);
+                // the row's own value is one of the K gathers (every row of a
+                // Gauss-Seidel matrix has its diagonal entry): no extra load
+#pragma unroll
+                for (int u = 0; u < K; ++u)
+                    if (so[u] == yo) own = xv[u];
             } else if (a.beta != 0.0) {
                 zv = sz.load(yo, t0_bytes);
             }
