@@ -721,3 +721,129 @@ def test_restricted_residual_variants_agree(stk):
         assert relerr(res[1][0], res[0][0]) < 1e-13
         assert relerr(res[1][1], res[0][1]) < 1e-13
         assert not np.array_equal(res[1][0], res[0][0])  # the fused path did run
+
+
+def _lib_dev(a):
+    from source import _lib
+    return _lib.to_dev(np.ascontiguousarray(a))
+
+
+def test_kron_ell_randomised_shapes(stk):
+    """stk_kron_ell_apply / stk_kron_ell_ghost_apply on random ragged matrices,
+    slab lengths 1..21, one to three terms, with and without ghost rows, beta
+    0 or not, identity time factors: against dense NumPy.  Walks through the
+    K / NPF / overflow / wide-row instances of the kernel."""
+    from source.linop import EllMatrices
+    rng = np.random.RandomState(2024)
+    for case in range(40):
+        M = int(rng.randint(3, 400))
+        n_loc = int(rng.randint(1, 22))
+        ld = n_loc + (n_loc & 1)
+        nt = int(rng.randint(1, 4))
+        width = int(rng.choice([3, 6, 9, 14, 20]))  # 20 > 16: overflow rows
+        dens = min(1.0, width / M)
+        base = sp.random(M, M, density=dens, random_state=rng, format='csr')
+        base = sp.csr_matrix(base + sp.eye(M))
+        mats = []
+        for k in range(nt):
+            m = base.copy()
+            m.data = rng.rand(m.nnz)
+            mats.append(m)
+        ell = EllMatrices(mats)
+        shared = bool(rng.randint(2))
+        xs = [rng.rand(M, n_loc) for _ in range(1 if shared else nt)]
+        lo = rng.rand(M) if rng.randint(2) else None
+        hi = rng.rand(M) if rng.randint(2) else None
+        beta = float(rng.choice([0.0, 0.5]))
+        y0 = rng.rand(M, n_loc)
+        specs, want = [], beta * y0
+        for k in range(nt):
+            X = xs[0] if shared else xs[k]
+            if rng.randint(4) == 0:
+                tri, T = None, np.eye(n_loc)
+                sub0 = sup1 = 0.0
+            else:
+                t = rng.rand(3, n_loc)
+                T = np.diag(t[1]) + np.diag(t[0, 1:], -1) + np.diag(t[2, :-1], 1)
+                tri, sub0, sup1 = _lib_dev(t), t[0, 0], t[2, -1]
+            Z = mats[k] @ X  # (M, n_loc): space factor on every time column
+            want = want + Z @ T.T
+            if tri is not None and lo is not None:
+                want[:, 0] += sub0 * (mats[k] @ lo)
+            if tri is not None and hi is not None:
+                want[:, -1] += sup1 * (mats[k] @ hi)
+            specs.append((tri, k, X, lo, hi))
+        dev = {}
+
+        def slab(a):
+            key = id(a)
+            if key not in dev:
+                s_ = torch.zeros((M, ld), dtype=torch.float64, device='cuda')
+                s_[:, :n_loc] = torch.from_numpy(a).cuda()
+                dev[key] = s_
+            return dev[key]
+
+        glo = None if lo is None else torch.from_numpy(lo).cuda()
+        ghi = None if hi is None else torch.from_numpy(hi).cuda()
+        dspecs = [(tri, k, slab(X), glo, ghi) for tri, k, X, _, _ in specs]
+        y = slab(y0.copy())
+        ell.apply(dspecs, n_loc, ld, beta, y)
+        got = y[:, :n_loc].cpu().numpy()
+        assert relerr(got, want) < 1e-13, (case, M, n_loc, nt, width, shared)
+        if ld > n_loc:
+            assert float(y[:, n_loc:].abs().max()) == 0.0  # padding stays zero
+
+
+def test_row_engine_randomised_shapes(stk):
+    """stk_ell_spmm on random rectangular matrices: y = alpha (ca A + cm[t] M) x
+    + beta z for every slot count, with and without the second value array,
+    z absent / separate / aliasing y, odd slab lengths padded to even."""
+    import ctypes
+    from source.linop import EllRowsMatrix, union_pattern
+    rng = np.random.RandomState(7)
+    lib = stk.lib()
+    done = 0
+    for case in range(60):
+        rows, cols = int(rng.randint(1, 300)), int(rng.randint(1, 300))
+        n_loc = int(rng.randint(1, 20))
+        ld = n_loc + (n_loc & 1)
+        width = int(rng.choice([1, 2, 4, 6, 8, 11, 15, 19]))
+        A = sp.random(rows, cols, density=min(1.0, width / cols),
+                      random_state=rng, format='csr')
+        Mm = A.copy()
+        Mm.data = rng.rand(Mm.nnz)
+        has_m = bool(rng.randint(2))
+        indptr, indices, vals = union_pattern([A, Mm])
+        e = EllRowsMatrix(indptr, indices, vals[0], vals[1] if has_m else None,
+                          rng.permutation(rows))
+        if not e.ok:  # a random row came out wider than the widest slot count
+            continue
+        done += 1
+        ca, alpha = float(rng.rand() + 0.5), float(rng.rand() + 0.5)
+        cm = rng.rand(n_loc)
+        X, Z = rng.rand(cols, n_loc), rng.rand(rows, n_loc)
+        mode = int(rng.randint(3))  # 0: no z, 1: separate z, 2: z aliases y
+        beta = 0.0 if mode == 0 else float(rng.rand() + 0.5)
+        want = np.empty((rows, n_loc))
+        for t in range(n_loc):
+            mat = ca * A + (cm[t] * Mm if has_m else 0 * Mm)
+            want[:, t] = alpha * (mat @ X[:, t]) + beta * Z[:, t]
+
+        def slab(a, n):
+            s_ = torch.zeros((n, ld), dtype=torch.float64, device='cuda')
+            s_[:, :n_loc] = torch.from_numpy(a).cuda()
+            return s_
+
+        x, z = slab(X, cols), slab(Z, rows)
+        y = z if mode == 2 else torch.full((rows, ld), np.nan,
+                                           dtype=torch.float64, device='cuda')
+        cmd = _lib_dev(cm) if has_m else None
+        stk.check(lib.stk_ell_spmm(stk.stream(), ctypes.byref(e.struct), n_loc,
+                                   ld, cols, ca, stk.ptr(cmd), stk.ptr(x), alpha,
+                                   beta, stk.ptr(z) if mode else None,
+                                   stk.ptr(y)))
+        got = y[:, :n_loc].cpu().numpy()
+        assert relerr(got, want) < 1e-13, (case, rows, cols, n_loc, width, has_m, mode)
+        if ld > n_loc:
+            assert float(y[:, n_loc:].abs().max()) == 0.0
+    assert done >= 30
