@@ -847,3 +847,38 @@ def test_row_engine_randomised_shapes(stk):
         if ld > n_loc:
             assert float(y[:, n_loc:].abs().max()) == 0.0
     assert done >= 30
+
+
+def test_multigrid_on_random_algebraic_hierarchies(stk):
+    """MultiGrid on hierarchies that come from no mesh: random SPD matrices in
+    random order (deep Gauss-Seidel dependency chains, rows wider than the ELL
+    slots on some levels) and random aggregation-type prolongations, two or
+    three levels, on slabs with several time columns: against the oracle."""
+    from oracle.multigrid import MultiGrid as OracleMG
+    from source.multigrid import MeshHierarchy, MultiGrid
+    rng = np.random.RandomState(99)
+    for case in range(12):
+        sizes = [int(rng.randint(2, 6))]
+        for _ in range(int(rng.randint(1, 3))):
+            sizes.append(sizes[-1] * int(rng.randint(2, 5)) + int(rng.randint(0, 4)))
+        n = sizes[-1]
+        B = sp.random(n, n, density=min(1.0, rng.choice([2, 5, 12]) / n),
+                      random_state=rng, format='csr')
+        A = sp.csr_matrix(B @ B.T + sp.diags(rng.rand(n) + 1.0))
+        P_mats = []
+        for nc, nf in zip(sizes[:-1], sizes[1:]):
+            r = np.arange(nf)
+            c1, c2 = rng.randint(0, nc, nf), rng.randint(0, nc, nf)
+            # every coarse dof is the first parent of at least one fine dof:
+            # P has full column rank, the Galerkin matrices stay SPD
+            c1[rng.permutation(nf)[:nc]] = np.arange(nc)
+            P = sp.csr_matrix((np.concatenate([np.ones(nf), 0.5 * rng.rand(nf)]),
+                               (np.concatenate([r, r]), np.concatenate([c1, c2]))),
+                              shape=(nf, nc))
+            P_mats.append(P)
+        ss, vc = int(rng.randint(1, 4)), int(rng.randint(1, 3))
+        mg = MultiGrid(A, MeshHierarchy(P_mats=P_mats), smoothsteps=ss, vcycles=vc)
+        omg = OracleMG(A, P_mats, ss, vc)
+        k = int(rng.randint(1, 8))
+        Bv = rng.rand(n, k)
+        assert relerr(mg @ Bv, omg @ Bv) < 1e-11, (case, sizes, ss, vc, k)
