@@ -250,6 +250,13 @@ typedef struct {
     const stk_ell_rows *ell_a, *ell_fwd, *ell_bwd, *ell_p, *ell_r;
     const int32_t *fwd_pos_host, *bwd_pos_host;
     const stk_ell_rows *ell_ra;
+    /* ell_fwd0 (optional): n_fwd matrices, one per group of the forward
+     * schedule, for the first sweep of a level visit, which starts from u = 0:
+     * group g keeps only the entries whose column lies in a group < g (the
+     * other products are exact zeros), unused slots point at a row of group 0.
+     * With it the plan neither zeroes u before that sweep nor gathers the
+     * zeros. */
+    const stk_ell_rows *ell_fwd0;
 } stk_mg_level;
 
 typedef struct stk_mg stk_mg;

@@ -84,11 +84,7 @@ __global__ __launch_bounds__(GBS) void coarse_kernel(int32_t n0, int32_t n_loc, 
 
 }  // namespace
 
-// rows_ell.hip
-int stk_rows_ell_launch(hipStream_t st, int mode, const stk_ell_rows *e, int32_t pos_begin, int32_t pos_end,
-                        int32_t n_loc, int32_t ld, int64_t x_rows, int64_t y_rows, double ca, const double *cm,
-                        const double *x, double alpha, double beta, const double *z, double *y);
-
+int g_mg_zero_start = 1;        // 0: zero u in memory and run the first sweep like the others
 int g_mg_fuse_restrict = 1;     // 0: residual and restriction as two steps
 int g_mg_fuse_coarse = 1;       // 0 disables the fused coarse sub-V-cycle
 int g_mg_coarse_max_rows = 1024;  // levels up to this many rows are fused (larger ones fill the GPU by themselves)
@@ -96,6 +92,7 @@ int g_mg_coarse_max_rows = 1024;  // levels up to this many rows are fused (larg
 struct EllLevel {
     bool has_a = false, has_gs = false, has_p = false, has_r = false, has_ra = false;
     stk_ell_rows a, fwd, bwd, p, r, ra;
+    std::vector<stk_ell_rows> fwd0;  // per forward group: entries towards earlier groups only
     std::vector<int32_t> fwd_pos, bwd_pos;
 };
 
@@ -118,15 +115,38 @@ static inline bool ell_slab_ok(int64_t rows, int ld)
     return (ld & 1) == 0 && rows * ld * 8 < ((int64_t)1 << 36);
 }
 
+// A level visit starts from u = 0 (multigrid.py:176, 187).  With the per-group
+// matrices of stk_mg_level.ell_fwd0 the first forward sweep neither needs u
+// zeroed in memory nor gathers the zeros.
+static bool can_zero_start(const stk_mg *mg, int level, int ld)
+{
+    const EllLevel &E = mg->ell[level];
+    return g_mg_zero_start && level >= 1 && mg->smoothsteps >= 1 && E.has_gs && !E.fwd0.empty() &&
+           E.fwd0.size() + 1 == E.fwd_pos.size() && ell_slab_ok(mg->lv[level].n, ld);
+}
+
 static int smooth_level(stk_mg *mg, hipStream_t st, int level, int n_loc, int ld, double ca, const double *cm,
-                        int its, bool backward, const double *f, double *u)
+                        int its, bool backward, const double *f, double *u, bool zero_start = false)
 {
     const stk_mg_level &L = mg->lv[level];
     const EllLevel &E = mg->ell[level];
     if (E.has_gs && ell_slab_ok(L.n, ld)) {
         const stk_ell_rows &e = backward ? E.bwd : E.fwd;
         const std::vector<int32_t> &pos = backward ? E.bwd_pos : E.fwd_pos;
-        for (int it = 0; it < its; ++it)
+        int first = 0;
+        if (zero_start && !backward && its >= 1) {
+            // u is NOT initialised: group 0 has no entries left and gathers its
+            // (zero-weighted) padding slots from f; later groups only read rows
+            // of earlier groups, which this sweep has written
+            for (size_t g = 0; g < E.fwd0.size(); ++g) {
+                const stk_ell_rows &e0 = E.fwd0[g];
+                int rc = stk_rows_ell_launch(st, 1, &e0, 0, e0.n_pos, n_loc, ld, L.n, L.n, ca, cm, g == 0 ? f : u,
+                                             0.0, 0.0, f, u, /*zero_own=*/1);
+                if (rc) return rc;
+            }
+            first = 1;
+        }
+        for (int it = first; it < its; ++it)
             for (size_t g = 0; g + 1 < pos.size(); ++g) {
                 int rc = stk_rows_ell_launch(st, 1, &e, pos[g], pos[g + 1], n_loc, ld, L.n, L.n, ca, cm, u, 0.0, 0.0,
                                              f, u);
@@ -152,12 +172,19 @@ static int smooth_level(stk_mg *mg, hipStream_t st, int level, int n_loc, int ld
 }
 
 // multigrid.py:168-182
+// u_zero: u_j is zero by definition but its memory has NOT been written.
 static int mgm(stk_mg *mg, hipStream_t st, int j, int n_loc, int ld, double ca, const double *cm,
-               const int32_t *kind, const double *f_j, double *u_j)
+               const int32_t *kind, const double *f_j, double *u_j, bool u_zero)
 {
     const stk_mg_level &L = mg->lv[j];
-    if (g_mg_fuse_coarse && mg->coarse && j == mg->Lc && (ld & 1) == 0 && f_j == mg->f[j] && u_j == mg->u[j])
+    if (g_mg_fuse_coarse && mg->coarse && j == mg->Lc && (ld & 1) == 0 && f_j == mg->f[j] && u_j == mg->u[j]) {
+        // (the job list starts from zero itself when its vectors live in LDS;
+        // the global-memory variant reads u)
+        if (u_zero) STK_HIP(hipMemsetAsync(u_j, 0, sizeof(double) * (size_t)L.n * ld, st));
         return stk_coarse_plan_run(mg->coarse, st, n_loc, ld, ca, cm, kind, mg->coarse_inv);
+    }
+    const bool zero_start = u_zero && j >= 1 && can_zero_start(mg, j, ld);
+    if (u_zero && j >= 1 && !zero_start) STK_HIP(hipMemsetAsync(u_j, 0, sizeof(double) * (size_t)L.n * ld, st));
     if (j == 0) {
         const int total = L.n * n_loc;
         // the stored inverses are those of (vals_a + cm*vals_m) for cm != NULL,
@@ -167,7 +194,7 @@ static int mgm(stk_mg *mg, hipStream_t st, int j, int n_loc, int ld, double ca, 
         STK_LAUNCH_CHECK();
         return 0;
     }
-    int rc = smooth_level(mg, st, j, n_loc, ld, ca, cm, mg->smoothsteps, false, f_j, u_j);
+    int rc = smooth_level(mg, st, j, n_loc, ld, ca, cm, mg->smoothsteps, false, f_j, u_j, zero_start);
     if (rc) return rc;
     const stk_mg_level &C = mg->lv[j - 1];
     double *r_j = mg->r[j], *d_c = mg->f[j - 1], *u_c = mg->u[j - 1];
@@ -198,8 +225,7 @@ static int mgm(stk_mg *mg, hipStream_t st, int j, int n_loc, int ld, double ca, 
                               1.0, 0.0, nullptr, d_c);
         if (rc) return rc;
     }
-    STK_HIP(hipMemsetAsync(u_c, 0, sizeof(double) * (size_t)C.n * ld, st));
-    rc = mgm(mg, st, j - 1, n_loc, ld, ca, cm, kind, d_c, u_c);
+    rc = mgm(mg, st, j - 1, n_loc, ld, ca, cm, kind, d_c, u_c, /*u_zero=*/true);
     if (rc) return rc;
     // u_j -= P u_c
     if (E.has_p && even)
@@ -235,6 +261,7 @@ extern "C" int stk_mg_create(int32_t n_levels, const stk_mg_level *levels, int32
         if (L.ell_p) { E.p = *L.ell_p; E.has_p = true; }
         if (L.ell_r) { E.r = *L.ell_r; E.has_r = true; }
         if (L.ell_ra) { E.ra = *L.ell_ra; E.has_ra = true; }
+        if (L.ell_fwd0 && L.n_fwd > 0) E.fwd0.assign(L.ell_fwd0, L.ell_fwd0 + L.n_fwd);
         if (L.ell_fwd && L.ell_bwd && L.fwd_pos_host && L.bwd_pos_host) {
             E.fwd = *L.ell_fwd;
             E.bwd = *L.ell_bwd;
@@ -243,7 +270,7 @@ extern "C" int stk_mg_create(int32_t n_levels, const stk_mg_level *levels, int32
             E.has_gs = true;
         }
         mg->lv[j].ell_a = mg->lv[j].ell_fwd = mg->lv[j].ell_bwd = mg->lv[j].ell_p = mg->lv[j].ell_r = nullptr;
-        mg->lv[j].ell_ra = nullptr;
+        mg->lv[j].ell_ra = mg->lv[j].ell_fwd0 = nullptr;
     }
     mg->u.assign(n_levels, nullptr);
     mg->f.assign(n_levels, nullptr);
@@ -336,9 +363,8 @@ extern "C" int stk_mg_apply(stk_mg *mg, void *stream, int32_t n_loc, int32_t ld,
     STK_REQUIRE(ca != 0.0 || cm, "stk_mg_apply: zero matrix");
     hipStream_t st = stk_stream(stream);
     const int J = (int)mg->lv.size() - 1;
-    STK_HIP(hipMemsetAsync(u, 0, sizeof(double) * (size_t)mg->lv[J].n * ld, st));  // multigrid.py:187
     for (int v = 0; v < mg->vcycles; ++v) {
-        int rc = mgm(mg, st, J, n_loc, ld, ca, cm, kind, f, u);
+        int rc = mgm(mg, st, J, n_loc, ld, ca, cm, kind, f, u, /*u_zero=*/v == 0);  // multigrid.py:187
         if (rc) return rc;
     }
     return 0;

@@ -36,6 +36,7 @@ struct RowsArgs {
     int32_t n_loc, ld, P, R;
     int32_t ngroups, chunk;
     int32_t reverse;  // walk the row groups of every XCD chunk backwards
+    int32_t zero_own;  // GS: the rows' own values are zero (first sweep from u = 0)
     uint32_t x_bytes, y_bytes;
     int32_t wide;  // a slab of 4 GiB or more: 64-bit addressing
 };
@@ -155,9 +156,11 @@ __global__ __launch_bounds__(BS, K >= 12 ? 4 : 6) void rows_ell_kernel(const Row
                 zv = sz.load(yo, t0_bytes);
                 // the row's own value is one of the K gathers (every row of a
                 // Gauss-Seidel matrix has its diagonal entry): no extra load
+                if (!a.zero_own) {
 #pragma unroll
-                for (int u = 0; u < K; ++u)
-                    if (so[u] == yo) own = xv[u];
+                    for (int u = 0; u < K; ++u)
+                        if (so[u] == yo) own = xv[u];
+                }
             } else if (a.beta != 0.0) {
                 zv = sz.load(yo, t0_bytes);
             }
@@ -265,7 +268,7 @@ int stk_rows_ell_set_tuning(const char *key, int32_t value)
 // Shared launcher (also used by mg.hip).  mode: 0 = SPMM, 1 = GS.
 int stk_rows_ell_launch(hipStream_t st, int mode, const stk_ell_rows *e, int32_t pos_begin, int32_t pos_end,
                         int32_t n_loc, int32_t ld, int64_t x_rows, int64_t y_rows, double ca, const double *cm,
-                        const double *x, double alpha, double beta, const double *z, double *y)
+                        const double *x, double alpha, double beta, const double *z, double *y, int zero_own)
 {
     if (pos_end <= pos_begin) return 0;
     STK_REQUIRE(e && e->idx && e->va, "rows_ell: incomplete matrix");
@@ -300,6 +303,7 @@ int stk_rows_ell_launch(hipStream_t st, int mode, const stk_ell_rows *e, int32_t
     a.ngroups = (pos_end - pos_begin + a.R - 1) / a.R;
     a.chunk = (a.ngroups + 7) / 8;
     a.reverse = g_rows_alternate ? (int)(g_rows_launch_count++ & 1u) : 0;
+    a.zero_own = zero_own;
     a.wide = g_rows_force_wide || x_rows * ld * 8 >= ((int64_t)1 << 32) || y_rows * ld * 8 >= ((int64_t)1 << 32);
     a.x_bytes = a.wide ? 0u : (uint32_t)(x_rows * ld * 8);
     a.y_bytes = a.wide ? 0u : (uint32_t)(y_rows * ld * 8);

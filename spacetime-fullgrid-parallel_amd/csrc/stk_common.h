@@ -63,7 +63,7 @@ int stk_coarse_plan_run(const stk_coarse_plan *p, hipStream_t st, int n_loc, int
 // Row-gather engine launcher of rows_ell.hip (mode 0 = SPMM, 1 = Gauss-Seidel group).
 int stk_rows_ell_launch(hipStream_t st, int mode, const stk_ell_rows *e, int32_t pos_begin, int32_t pos_end,
                         int32_t n_loc, int32_t ld, int64_t x_rows, int64_t y_rows, double ca, const double *cm,
-                        const double *x, double alpha, double beta, const double *z, double *y);
+                        const double *x, double alpha, double beta, const double *z, double *y, int zero_own = 0);
 
 // ---- slab access from device code (kron_ell.hip, rows_ell.hip, mg_coarse.hip) -----
 #if defined(__HIPCC__)

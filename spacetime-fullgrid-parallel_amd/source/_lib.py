@@ -59,7 +59,8 @@ class MGLevel(ctypes.Structure):
                 ('ell_p', ctypes.POINTER(EllRows)),
                 ('ell_r', ctypes.POINTER(EllRows)),
                 ('fwd_pos_host', c_p), ('bwd_pos_host', c_p),
-                ('ell_ra', ctypes.POINTER(EllRows))]
+                ('ell_ra', ctypes.POINTER(EllRows)),
+                ('ell_fwd0', ctypes.POINTER(EllRows))]
 
 
 _PROTOTYPES = {

@@ -214,7 +214,7 @@ class EllRowsMatrix:
     SLOTS = (2, 5, 7, 9, 12, 16, 20)
 
     def __init__(self, indptr, indices, va, vm=None, order=None, n_cols=None,
-                 diag=False):
+                 diag=False, pad_col=0, dia_values=None):
         n = len(indptr) - 1
         counts_all = np.diff(indptr)
         kmax = int(counts_all.max()) if n else 1
@@ -232,7 +232,8 @@ class EllRowsMatrix:
                 np.concatenate([[0], np.cumsum(counts)[:-1]]), counts))
         slot = np.arange(counts.sum()) - np.repeat(
             np.concatenate([[0], np.cumsum(counts)[:-1]]), counts)
-        idx = np.zeros((npos, K), dtype=np.int32)
+        # unused slots: value 0 and a column the caller knows to be readable
+        idx = np.full((npos, K), pad_col, dtype=np.int32)
         idx[pos, slot] = indices[src]
         ea = np.zeros((npos, K))
         ea[pos, slot] = va[src]
@@ -246,7 +247,11 @@ class EllRowsMatrix:
             self.vm = _lib.to_dev(em)
         self.row_ids = _lib.to_dev(order.astype(np.int32))
         self.dia_a = self.dia_m = None
-        if diag:
+        if dia_values is not None:  # per-row diagonal given (rows in index order)
+            self.dia_a = _lib.to_dev(np.asarray(dia_values[0])[order])
+            if dia_values[1] is not None:
+                self.dia_m = _lib.to_dev(np.asarray(dia_values[1])[order])
+        elif diag:
             rows_of = np.repeat(np.arange(n), counts_all)
             on = np.flatnonzero(indices == rows_of)
             dpos = np.full(n, -1, dtype=np.int64)

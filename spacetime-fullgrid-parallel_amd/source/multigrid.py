@@ -163,6 +163,9 @@ class _DeviceHierarchy:
                 host[name + '_pos'] = ptr  # group g = positions ptr[g]:ptr[g+1]
                 setattr(L, name + '_pos_host',
                         ptr.ctypes.data_as(ctypes.c_void_p))
+                if not bw:
+                    fwd_groups = [tile[np.sort(rank[rows[ptr[g]:ptr[g + 1]]])]
+                                  for g in range(len(ptr) - 1)]
             P = sp.csr_matrix(hierarchy.P_mats[j - 1])
             R = sp.csr_matrix(hierarchy.R_mats[j - 1])
             nc = P.shape[1]
@@ -189,11 +192,44 @@ class _DeviceHierarchy:
                 for name, e in ells.items():
                     setattr(L, 'ell_' + name, ctypes.pointer(e.struct))
                 host['ells'] = ells
+                self._zero_start_ells(L, host, indptr, indices, vals[0], vm,
+                                      diag, fwd_groups)
         for name, t in dev.items():
             setattr(L, name, _lib.ptr(t))
         self._keep.append((dev, host))
         if j == self.J:
             self.groups_fwd = len(host['fwd_ptr']) - 1 if j > 0 else 0
+
+    def _zero_start_ells(self, L, host, indptr, indices, va, vm, diag,
+                         groups):
+        """The first forward sweep of a level visit starts from u = 0
+        (reference multigrid.py:176, 187): every product with a not yet
+        updated neighbour is an exact zero.  Per dependency group, an ELL copy
+        that keeps only the entries whose column lies in an EARLIER group --
+        narrower rows, fewer gathers, and no need to zero u beforehand.  Unused
+        slots point at a row of group 0 (already written when groups >= 1 run;
+        group 0 itself gathers from f instead of u, see mg.hip)."""
+        n = len(indptr) - 1
+        if not groups or any(len(g) == 0 for g in groups):
+            return
+        grp = np.empty(n, dtype=np.int64)
+        for g, rows in enumerate(groups):
+            grp[rows] = g
+        rows_of = np.repeat(np.arange(n), np.diff(indptr))
+        keep = grp[indices] < grp[rows_of]
+        counts = np.bincount(rows_of[keep], minlength=n)
+        f_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        f_idx, f_va = indices[keep], va[keep]
+        f_vm = vm[keep] if vm is not None else None
+        dia = (va[diag], vm[diag] if vm is not None else None)
+        safe = int(groups[0][0])
+        ells = [EllRowsMatrix(f_ptr, f_idx, f_va, f_vm, rows, pad_col=safe,
+                              dia_values=dia) for rows in groups]
+        if not all(e.ok for e in ells):
+            return
+        arr = (_lib.EllRows * len(ells))(*[e.struct for e in ells])
+        host['fwd0'] = (ells, arr)
+        L.ell_fwd0 = ctypes.cast(arr, ctypes.POINTER(_lib.EllRows))
 
     def ensure_plan(self, ld):
         if self.plan is not None and ld <= self.plan_ld:

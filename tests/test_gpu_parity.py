@@ -882,3 +882,27 @@ def test_multigrid_on_random_algebraic_hierarchies(stk):
         k = int(rng.randint(1, 8))
         Bv = rng.rand(n, k)
         assert relerr(mg @ Bv, omg @ Bv) < 1e-11, (case, sizes, ss, vc, k)
+
+
+def test_zero_start_first_sweep_is_exact(stk):
+    """The first forward sweep of a level visit, run on the per-group matrices
+    that drop the products with not yet updated (zero) neighbours and without
+    zeroing u first (stk_mg_level.ell_fwd0), gives bitwise the same V-cycle."""
+    import heateq_mpi as hm
+    for problem, J_space in (('square', 5), ('lshape', 4), ('cube', 2)):
+        h = hm.HeatEquationMPI(J_space=J_space, J_time=3, problem=problem)
+        x = _vec(h.dofs_distr, np.random.RandomState(13).rand(h.N, h.M))
+        res = []
+        try:
+            for zs in (0, 1):
+                stk.check(stk.lib().stk_set_tuning(b'mg_zero_start', zs))
+                # poison the allocator's free blocks: the zero-start path must
+                # not depend on what the output buffers contain
+                junk = torch.full((h.M, 2 * h.N + 8), float('nan'),
+                                  dtype=torch.float64, device='cuda')
+                del junk
+                res.append((_np(h.P @ x), _np(h.S @ x)))
+        finally:
+            stk.check(stk.lib().stk_set_tuning(b'mg_zero_start', 1))
+        assert np.array_equal(res[0][0], res[1][0])
+        assert np.array_equal(res[0][1], res[1][1])
