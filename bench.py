@@ -89,7 +89,7 @@ def main():
     ap.add_argument('--J_time', type=int, default=6)
     ap.add_argument('--J_space', type=int, default=9)
     ap.add_argument('--problem', default='square')
-    ap.add_argument('--solve-iters', type=int, default=3,
+    ap.add_argument('--solve-iters', type=int, default=10,
                     help='PCG iterations to time for iters/s (0 = skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
