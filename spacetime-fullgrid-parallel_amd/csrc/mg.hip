@@ -87,7 +87,7 @@ __global__ __launch_bounds__(GBS) void coarse_kernel(int32_t n0, int32_t n_loc, 
 int g_mg_zero_start = 1;        // 0: zero u in memory and run the first sweep like the others
 int g_mg_fuse_restrict = 1;     // 0: residual and restriction as two steps
 int g_mg_fuse_coarse = 1;       // 0 disables the fused coarse sub-V-cycle
-int g_mg_coarse_max_rows = 1024;  // levels up to this many rows are fused (larger ones fill the GPU by themselves)
+int g_mg_coarse_max_rows = 4096;  // levels up to this many rows may be fused (larger ones fill the GPU by themselves)
 
 struct EllLevel {
     bool has_a = false, has_gs = false, has_p = false, has_r = false, has_ra = false;
@@ -307,10 +307,16 @@ extern "C" int stk_mg_create(int32_t n_levels, const stk_mg_level *levels, int32
     }
     // fuse the coarse end of the V-cycle when every level there has its ELL pieces
     {
+        // as many levels as keep all their vectors (u, f, residual: one double per
+        // row and time step) in the 144 KiB LDS arena of mg_coarse.hip
         int Lc = -1;
+        int64_t arena_rows = 3 * (int64_t)mg->lv[0].n;
         for (int j = 1; j < n_levels - 1; ++j) {
             const EllLevel &E = mg->ell[j];
-            if (mg->lv[j].n > g_mg_coarse_max_rows || !(E.has_a && E.has_gs && E.has_p && E.has_r)) break;
+            arena_rows += 3 * (int64_t)mg->lv[j].n;
+            if (mg->lv[j].n > g_mg_coarse_max_rows || arena_rows * (int64_t)sizeof(double) > 144 * 1024 ||
+                !(E.has_a && E.has_gs && E.has_p && E.has_r))
+                break;
             Lc = j;
         }
         if (Lc >= 1) {

@@ -120,16 +120,37 @@ __device__ inline void run_rows_job(const Job &j, const CoarseArgs &a, int p0, i
     }
 }
 
-// LDS variant of run_rows_job: one time pair per workgroup, every vector of the
-// sub-V-cycle lives in the LDS arena sv (one double2 per row).
-template <int K, bool HAS_M>
-__device__ inline void run_rows_job_lds(const Job &j, const CoarseArgs &a, double2 *sv, double cm0, double cm1,
-                                        bool has1)
+// LDS variant of run_rows_job: every vector of the sub-V-cycle lives in the LDS
+// arena sv, one element per row.  PAIR: a workgroup owns a pair of time steps
+// (double2 elements); otherwise a single time step (double elements), which
+// halves the arena and lets one more level fit.
+template <bool PAIR>
+struct TimeElem;
+template <>
+struct TimeElem<true> {
+    typedef double2 type;
+    __device__ static inline double2 make(double a, double b) { return make_double2(a, b); }
+    __device__ static inline double lo(double2 v) { return v.x; }
+    __device__ static inline double hi(double2 v) { return v.y; }
+};
+template <>
+struct TimeElem<false> {
+    typedef double type;
+    __device__ static inline double make(double a, double) { return a; }
+    __device__ static inline double lo(double v) { return v; }
+    __device__ static inline double hi(double) { return 0.0; }
+};
+
+template <int K, bool HAS_M, bool PAIR>
+__device__ inline void run_rows_job_lds(const Job &j, const CoarseArgs &a, typename TimeElem<PAIR>::type *sv,
+                                        double cm0, double cm1, bool has1)
 {
+    typedef TimeElem<PAIR> E;
+    typedef typename E::type V;
     const int nrows = j.pos_end - j.pos_begin;
     const bool use_m = HAS_M && j.use_m;
     const double ca = j.use_m ? a.ca : 1.0;
-    const double2 *vx = sv + j.lx;
+    const V *vx = sv + j.lx;
     for (int r = threadIdx.x; r < nrows; r += CBS) {
         const int pos = j.pos_begin + r;
         const size_t e0 = (size_t)pos * K;
@@ -149,10 +170,10 @@ __device__ inline void run_rows_job_lds(const Job &j, const CoarseArgs &a, doubl
             da = j.dia_a[pos];
             if (use_m) dm = j.dia_m[pos];
         }
-        double2 xv[K];
+        V xv[K];
 #pragma unroll
         for (int u = 0; u < K; ++u) xv[u] = vx[col[u]];
-        double2 zv = make_double2(0.0, 0.0), own = make_double2(0.0, 0.0);
+        V zv = E::make(0.0, 0.0), own = E::make(0.0, 0.0);
         if (j.kind == JOB_GS) {
             zv = sv[j.lz + row];
             own = vx[row];
@@ -165,53 +186,62 @@ __device__ inline void run_rows_job_lds(const Job &j, const CoarseArgs &a, doubl
             double v0 = ca * va[u], v1 = v0;
             if (use_m) {
                 v0 = fma(cm0, vm[u], v0);
-                v1 = fma(cm1, vm[u], v1);
+                if (PAIR) v1 = fma(cm1, vm[u], v1);
             }
-            s0 = fma(v0, xv[u].x, s0);
-            s1 = fma(v1, xv[u].y, s1);
+            s0 = fma(v0, E::lo(xv[u]), s0);
+            if (PAIR) s1 = fma(v1, E::hi(xv[u]), s1);
         }
-        double o0, o1;
+        double o0, o1 = 0.0;
         if (j.kind == JOB_GS) {
             double d0 = ca * da, d1 = d0;
             if (use_m) {
                 d0 = fma(cm0, dm, d0);
-                d1 = fma(cm1, dm, d1);
+                if (PAIR) d1 = fma(cm1, dm, d1);
             }
-            o0 = own.x + (1.0 / d0) * (zv.x - s0);
-            o1 = own.y + (1.0 / d1) * (zv.y - s1);
+            o0 = E::lo(own) + (1.0 / d0) * (E::lo(zv) - s0);
+            if (PAIR) o1 = E::hi(own) + (1.0 / d1) * (E::hi(zv) - s1);
         } else {
             o0 = j.alpha * s0;
-            o1 = j.alpha * s1;
+            if (PAIR) o1 = j.alpha * s1;
             if (j.beta != 0.0) {
-                o0 = fma(j.beta, zv.x, o0);
-                o1 = fma(j.beta, zv.y, o1);
+                o0 = fma(j.beta, E::lo(zv), o0);
+                if (PAIR) o1 = fma(j.beta, E::hi(zv), o1);
             }
         }
         if (!has1) o1 = 0.0;  // padding slot stays zero
-        sv[j.ly + row] = make_double2(o0, o1);
+        sv[j.ly + row] = E::make(o0, o1);
     }
 }
 
-template <bool HAS_M>
+template <bool HAS_M, bool PAIR>
 __global__ __launch_bounds__(CBS) void mg_coarse_lds_kernel(const CoarseArgs a)
 {
-    extern __shared__ double2 sv[];
-    const int t0 = 2 * (int)blockIdx.x;
-    const bool has1 = t0 + 1 < a.n_loc;
+    typedef TimeElem<PAIR> E;
+    typedef typename E::type V;
+    extern __shared__ double sm_raw[];
+    V *sv = reinterpret_cast<V *>(sm_raw);
+    const int t0 = (PAIR ? 2 : 1) * (int)blockIdx.x;
+    const bool has1 = PAIR && t0 + 1 < a.n_loc;
     double cm0 = 0.0, cm1 = 0.0;
     if (HAS_M) {
         cm0 = a.cm[t0];
         if (has1) cm1 = a.cm[t0 + 1];
     }
+    auto gload = [&](const double *p) -> V {
+        if constexpr (PAIR)
+            return *reinterpret_cast<const double2 *>(p);
+        else
+            return *p;
+    };
     for (int r = threadIdx.x; r < a.top_n; r += CBS) {
-        sv[a.top_lf + r] = *reinterpret_cast<const double2 *>(a.top_f + (size_t)r * a.ld + t0);
-        sv[a.top_lu + r] = make_double2(0.0, 0.0);  // MGM starts from zero (multigrid.py:176)
+        sv[a.top_lf + r] = gload(a.top_f + (size_t)r * a.ld + t0);
+        sv[a.top_lu + r] = E::make(0.0, 0.0);  // MGM starts from zero (multigrid.py:176)
     }
     __syncthreads();
     for (int jn = 0; jn < a.n_jobs; ++jn) {
         const Job j = a.jobs[jn];
         if (j.kind == JOB_ZERO) {
-            for (int r = threadIdx.x; r < j.pos_end; r += CBS) sv[j.ly + r] = make_double2(0.0, 0.0);
+            for (int r = threadIdx.x; r < j.pos_end; r += CBS) sv[j.ly + r] = E::make(0.0, 0.0);
         } else if (j.kind == JOB_COARSE) {
             const int n0 = j.pos_end;
             for (int i = threadIdx.x; i < n0; i += CBS) {
@@ -220,27 +250,35 @@ __global__ __launch_bounds__(CBS) void mg_coarse_lds_kernel(const CoarseArgs a)
                     a.coarse_inv + (size_t)((a.kind && has1) ? a.kind[t0 + 1] : 0) * n0 * n0 + (size_t)i * n0;
                 double s0 = 0.0, s1 = 0.0;
                 for (int c = 0; c < n0; ++c) {
-                    const double2 fv = sv[j.lz + c];
-                    s0 = fma(A0[c], fv.x, s0);
-                    s1 = fma(A1[c], fv.y, s1);
+                    const V fv = sv[j.lz + c];
+                    s0 = fma(A0[c], E::lo(fv), s0);
+                    if (PAIR) s1 = fma(A1[c], E::hi(fv), s1);
                 }
-                sv[j.ly + i] = make_double2(a.coarse_scale * s0, has1 ? a.coarse_scale * s1 : 0.0);
+                sv[j.ly + i] = E::make(a.coarse_scale * s0, has1 ? a.coarse_scale * s1 : 0.0);
             }
         } else {
             switch (j.K) {
-                case 2: run_rows_job_lds<2, HAS_M>(j, a, sv, cm0, cm1, has1); break;
-                case 5: run_rows_job_lds<5, HAS_M>(j, a, sv, cm0, cm1, has1); break;
-                case 7: run_rows_job_lds<7, HAS_M>(j, a, sv, cm0, cm1, has1); break;
-                case 9: run_rows_job_lds<9, HAS_M>(j, a, sv, cm0, cm1, has1); break;
-                case 12: run_rows_job_lds<12, HAS_M>(j, a, sv, cm0, cm1, has1); break;
-                case 16: run_rows_job_lds<16, HAS_M>(j, a, sv, cm0, cm1, has1); break;
-                default: run_rows_job_lds<20, HAS_M>(j, a, sv, cm0, cm1, has1); break;
+                case 2: run_rows_job_lds<2, HAS_M, PAIR>(j, a, sv, cm0, cm1, has1); break;
+                case 5: run_rows_job_lds<5, HAS_M, PAIR>(j, a, sv, cm0, cm1, has1); break;
+                case 7: run_rows_job_lds<7, HAS_M, PAIR>(j, a, sv, cm0, cm1, has1); break;
+                case 9: run_rows_job_lds<9, HAS_M, PAIR>(j, a, sv, cm0, cm1, has1); break;
+                case 12: run_rows_job_lds<12, HAS_M, PAIR>(j, a, sv, cm0, cm1, has1); break;
+                case 16: run_rows_job_lds<16, HAS_M, PAIR>(j, a, sv, cm0, cm1, has1); break;
+                default: run_rows_job_lds<20, HAS_M, PAIR>(j, a, sv, cm0, cm1, has1); break;
             }
         }
         __syncthreads();
     }
-    for (int r = threadIdx.x; r < a.top_n; r += CBS)
-        *reinterpret_cast<double2 *>(a.top_u + (size_t)r * a.ld + t0) = sv[a.top_lu + r];
+    for (int r = threadIdx.x; r < a.top_n; r += CBS) {
+        double *dst = a.top_u + (size_t)r * a.ld + t0;
+        if constexpr (PAIR)
+            *reinterpret_cast<double2 *>(dst) = sv[a.top_lu + r];
+        else
+            *dst = sv[a.top_lu + r];
+    }
+    // single steps: the padding column of an odd slab stays zero
+    if (!PAIR && blockIdx.x == 0 && (a.n_loc & 1))
+        for (int r = threadIdx.x; r < a.top_n; r += CBS) a.top_u[(size_t)r * a.ld + a.n_loc] = 0.0;
 }
 
 template <bool HAS_M>
@@ -450,20 +488,34 @@ int stk_coarse_plan_run(const stk_coarse_plan *p, hipStream_t st, int n_loc, int
     a.top_lf = p->top_lf;
     a.top_f = p->top_f;
     a.top_u = p->top_u;
-    const size_t lds = sizeof(double2) * (size_t)p->lds_rows;
-    if (g_mg_coarse_lds && g_mg_coarse_pairs <= 1 && lds <= 144 * 1024) {
+    // level vectors in LDS: pairs of time steps per workgroup if the arena fits,
+    // else single time steps (half the arena)
+    const size_t lds_pair = sizeof(double2) * (size_t)p->lds_rows, lds_one = sizeof(double) * (size_t)p->lds_rows;
+    const size_t lds_max = 144 * 1024;
+    if (g_mg_coarse_lds && g_mg_coarse_pairs <= 1 && lds_one <= lds_max) {
         static bool attr_set = false;
         if (!attr_set) {
-            STK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mg_coarse_lds_kernel<true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-            STK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mg_coarse_lds_kernel<false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+            STK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mg_coarse_lds_kernel<true, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            STK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mg_coarse_lds_kernel<false, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            STK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mg_coarse_lds_kernel<true, false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            STK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mg_coarse_lds_kernel<false, false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
             attr_set = true;
         }
-        if (cm)
-            hipLaunchKernelGGL(mg_coarse_lds_kernel<true>, dim3(all_pairs), dim3(CBS), lds, st, a);
+        const bool pair = lds_pair <= lds_max;
+        const dim3 grid(pair ? all_pairs : n_loc);
+        const size_t lds = pair ? lds_pair : lds_one;
+        if (cm && pair)
+            hipLaunchKernelGGL((mg_coarse_lds_kernel<true, true>), grid, dim3(CBS), lds, st, a);
+        else if (cm)
+            hipLaunchKernelGGL((mg_coarse_lds_kernel<true, false>), grid, dim3(CBS), lds, st, a);
+        else if (pair)
+            hipLaunchKernelGGL((mg_coarse_lds_kernel<false, true>), grid, dim3(CBS), lds, st, a);
         else
-            hipLaunchKernelGGL(mg_coarse_lds_kernel<false>, dim3(all_pairs), dim3(CBS), lds, st, a);
+            hipLaunchKernelGGL((mg_coarse_lds_kernel<false, false>), grid, dim3(CBS), lds, st, a);
         STK_LAUNCH_CHECK();
         return 0;
     }
