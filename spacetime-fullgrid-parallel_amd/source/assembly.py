@@ -87,18 +87,32 @@ def time_matrices_test_space(mesh_time):
 # Space: P1 on a triangulation (d = 2) or a tetrahedral mesh (d = 3).
 # ----------------------------------------------------------------------------
 def _simplex_geometry(mesh):
-    """Volumes and the gradients of the barycentric coordinates per cell."""
+    """Volumes and the gradients of the barycentric coordinates per cell
+    (closed-form inverse of the d x d edge matrix; cached on the mesh)."""
+    cached = getattr(mesh, '_stk_geometry', None)
+    if cached is not None and cached[0] == len(mesh.cells):
+        return cached[1], cached[2]
     p = mesh.points
     c = mesh.cells
     d = c.shape[1] - 1
     E = p[c[:, 1:]] - p[c[:, :1]]  # (nc, d, d): rows = edge vectors
-    det = np.linalg.det(E)
-    fact = 2.0 if d == 2 else 6.0
-    vol = np.abs(det) / fact
-    Einv = np.linalg.inv(E)  # columns = gradients of lambda_1..lambda_d
+    adj = np.empty_like(E)  # adjugate: E^{-1} = adj / det
+    if d == 2:
+        adj[:, 0, 0], adj[:, 0, 1] = E[:, 1, 1], -E[:, 0, 1]
+        adj[:, 1, 0], adj[:, 1, 1] = -E[:, 1, 0], E[:, 0, 0]
+        det = E[:, 0, 0] * E[:, 1, 1] - E[:, 0, 1] * E[:, 1, 0]
+    else:
+        r0, r1, r2 = E[:, 0], E[:, 1], E[:, 2]
+        adj[:, :, 0] = np.cross(r1, r2)
+        adj[:, :, 1] = np.cross(r2, r0)
+        adj[:, :, 2] = np.cross(r0, r1)
+        det = np.einsum('td,td->t', r0, adj[:, :, 0])
+    vol = np.abs(det) / (2.0 if d == 2 else 6.0)
     g = np.empty((len(c), d + 1, d))
-    g[:, 1:] = np.swapaxes(Einv, 1, 2)
+    # column k of E^{-1} is the gradient of lambda_{k+1}
+    g[:, 1:] = np.swapaxes(adj, 1, 2) / det[:, None, None]
     g[:, 0] = -g[:, 1:].sum(axis=1)
+    mesh._stk_geometry = (len(c), vol, g)
     return vol, g
 
 
@@ -203,11 +217,10 @@ def space_load(mesh, fn):
     p = mesh.points
     c = mesh.cells
     qw, ql = (_QW, _QL) if c.shape[1] == 3 else (_QW3, _QL3)
-    X = np.einsum('ql,tld->tqd', ql, p[c])  # quadrature points
+    X = np.matmul(ql, p[c])  # quadrature points (nt, nq, d)
     f = fn(*(X[..., k] for k in range(X.shape[-1])))  # (nt, nq)
-    loc = np.einsum('tq,q,ql->tl', f, qw, ql) * vol[:, None]
-    vec = np.zeros(mesh.nv)
-    np.add.at(vec, c.reshape(-1), loc.reshape(-1))
+    loc = np.matmul(f * qw, ql) * vol[:, None]  # (nt, nl)
+    vec = np.bincount(c.reshape(-1), weights=loc.reshape(-1), minlength=mesh.nv)
     return vec[free_dofs(mesh)]
 
 

@@ -212,39 +212,50 @@ class EllRowsMatrix:
     the diagonal arrays the Gauss-Seidel mode needs.  `ok` is False when a row
     has more entries than the largest instantiated slot count."""
     SLOTS = (2, 5, 7, 9, 12, 16, 20)
+    _base_key = _base = _base_refs = None
 
     def __init__(self, indptr, indices, va, vm=None, order=None, n_cols=None,
                  diag=False, pad_col=0, dia_values=None):
         n = len(indptr) - 1
         counts_all = np.diff(indptr)
-        kmax = int(counts_all.max()) if n else 1
+        order = np.arange(n, dtype=np.int64) if order is None else np.asarray(
+            order, dtype=np.int64)
+        # slot count of THIS copy: widest of the rows it lists
+        kmax = int(counts_all[order].max()) if len(order) else 1
+        kmax_all = int(counts_all.max()) if n else 1
         self.ok = kmax <= self.SLOTS[-1]
         if not self.ok:
             return
         K = next(k for k in self.SLOTS if k >= kmax)
-        order = np.arange(n, dtype=np.int64) if order is None else np.asarray(
-            order, dtype=np.int64)
-        counts = counts_all[order]
+        K_base = max(K, min(kmax_all, self.SLOTS[-1]))
+        # the (n, K) arrays in index order are built once per matrix and shared
+        # by all copies that only differ in the row order (a, fwd, bwd, ...)
+        key = (id(indptr), id(indices), id(va), id(vm), K_base, pad_col)
+        base = EllRowsMatrix._base if EllRowsMatrix._base_key == key else None
+        if base is None:
+            pos = np.repeat(np.arange(n), counts_all)
+            slot = np.arange(len(indices)) - np.repeat(indptr[:-1], counts_all)
+            keep = slot < K_base  # wider rows are not listed by any copy sharing this base
+            pos, slot = pos[keep], slot[keep]
+            # unused slots: value 0 and a column the caller knows to be readable
+            idx0 = np.full((n, K_base), pad_col, dtype=np.int32)
+            idx0[pos, slot] = indices[keep]
+            ea0 = np.zeros((n, K_base))
+            ea0[pos, slot] = va[keep]
+            em0 = None
+            if vm is not None:
+                em0 = np.zeros((n, K_base))
+                em0[pos, slot] = vm[keep]
+            base = (idx0, ea0, em0)
+            # the key holds ids: keep the arrays alive so they cannot be reused
+            EllRowsMatrix._base_key, EllRowsMatrix._base = key, base
+            EllRowsMatrix._base_refs = (indptr, indices, va, vm)
+        idx0, ea0, em0 = base
         npos = len(order)
-        pos = np.repeat(np.arange(npos), counts)
-        src = np.repeat(indptr[:-1][order], counts) + (
-            np.arange(counts.sum()) - np.repeat(
-                np.concatenate([[0], np.cumsum(counts)[:-1]]), counts))
-        slot = np.arange(counts.sum()) - np.repeat(
-            np.concatenate([[0], np.cumsum(counts)[:-1]]), counts)
-        # unused slots: value 0 and a column the caller knows to be readable
-        idx = np.full((npos, K), pad_col, dtype=np.int32)
-        idx[pos, slot] = indices[src]
-        ea = np.zeros((npos, K))
-        ea[pos, slot] = va[src]
         self.K, self.n_pos, self.n_rows = K, npos, n
-        self.idx = _lib.to_dev(idx)
-        self.va = _lib.to_dev(ea)
-        self.vm = None
-        if vm is not None:
-            em = np.zeros((npos, K))
-            em[pos, slot] = vm[src]
-            self.vm = _lib.to_dev(em)
+        self.idx = _lib.to_dev(idx0[order][:, :K])
+        self.va = _lib.to_dev(ea0[order][:, :K])
+        self.vm = None if em0 is None else _lib.to_dev(em0[order][:, :K])
         self.row_ids = _lib.to_dev(order.astype(np.int32))
         self.dia_a = self.dia_m = None
         if dia_values is not None:  # per-row diagonal given (rows in index order)
