@@ -342,3 +342,67 @@ def test_c_partition_matches_reference_tables():
             assert [d * M for d in displs] == list(g['displs_' + tag])
     assert lib.stk_partition(3, 4, 0, None, None, None, None) != 0
     assert b'more ranks' in lib.stk_last_error()
+
+
+# ---- property tests (hypothesis) ---------------------------------------------------
+def test_properties_partition_schedule_staging():
+    """Random inputs for three pieces of host logic: the slab partition, the
+    Gauss-Seidel dependency schedule (groups reproduce the sequential sweep on
+    arbitrary sparse matrices, forward and backward) and the zero-start entry
+    filter (entries towards earlier groups only)."""
+    from hypothesis import given, settings, strategies as st
+    from oracle.multigrid import Smoother
+    from source.comm import Comm
+    from source.mpi_vector import DofDistributionMPI
+    from source.multigrid import gauss_seidel_schedule
+
+    class FakeComm(Comm):
+        def __init__(self, rank, size):
+            self.rank, self.size = rank, size
+            self.group, self.distributed = None, False
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.integers(1, 300), st.integers(1, 16))
+    def partition(N, size):
+        size = min(size, N)
+        spans = [DofDistributionMPI(FakeComm(r, size), N, 3) for r in range(size)]
+        assert spans[0].t_begin == 0 and spans[-1].t_end == N
+        lens = [d.t_end - d.t_begin for d in spans]
+        assert all(a.t_end == b.t_begin for a, b in zip(spans, spans[1:]))
+        assert max(lens) - min(lens) <= 1 and lens == sorted(lens)  # extras go last
+        assert all(d.dof2proc[t] == r for r, d in enumerate(spans)
+                   for t in range(d.t_begin, d.t_end))
+
+    @settings(max_examples=40, deadline=None)
+    @given(st.integers(2, 60), st.floats(0.02, 0.5), st.integers(0, 2**31 - 1),
+           st.booleans())
+    def schedule(n, density, seed, backward):
+        rng = np.random.RandomState(seed)
+        B = sp.random(n, n, density=density, random_state=rng, format='csr')
+        A = sp.csr_matrix(B + B.T + sp.diags(np.abs(B + B.T).sum(axis=1).A1 + 1.0))
+        A.sort_indices()
+        ptr, rows = gauss_seidel_schedule(A.indptr, A.indices, backward)
+        assert sorted(rows) == list(range(n))
+        f, u0 = rng.rand(n), rng.rand(n)
+        ref = u0.copy()
+        sm = Smoother(A, its=1, use_c=False)
+        (sm.PostSmooth if backward else sm.PreSmooth)(ref, f)
+        assert relerr(_scheduled_sweep(A, u0.copy(), f, ptr, rows), ref) < 1e-13
+        # zero start (forward): only entries towards earlier groups matter
+        if not backward:
+            grp = np.empty(n, dtype=int)
+            for g in range(len(ptr) - 1):
+                grp[rows[ptr[g]:ptr[g + 1]]] = g
+            u = np.zeros(n)
+            coo = A.tocoo()
+            early = sp.csr_matrix((coo.data * (grp[coo.col] < grp[coo.row]),
+                                   (coo.row, coo.col)), shape=A.shape)
+            for g in range(len(ptr) - 1):
+                idx = rows[ptr[g]:ptr[g + 1]]
+                u[idx] = (f[idx] - early[idx] @ u) / A.diagonal()[idx]
+            zero = np.zeros(n)
+            sm.PreSmooth(zero, f)
+            assert relerr(u, zero) < 1e-13
+
+    partition()
+    schedule()
