@@ -121,15 +121,6 @@ typedef struct {
     const int32_t *row_ids;     /* M or NULL */
     const int32_t *ovf_indptr;  /* M+1 or NULL */
     const int32_t *ovf_indices;
-    /* Optional staging lists (NULL / 0 if absent) for groups of tile_R
-     * consecutive rows: the distinct columns of group g are
-     * tile_uniq[g*tile_U .. g*tile_U + tile_nu[g]) and slot e of row pos refers
-     * to list position tile_slot[pos*K + e].  Used when tile_R equals the
-     * kernel's rows per group, 512 / ((n_loc + 1) / 2). */
-    int32_t tile_R, tile_U;
-    const int32_t *tile_uniq;
-    const int32_t *tile_nu;
-    const uint16_t *tile_slot;
 } stk_ell_pattern;
 
 typedef struct {

@@ -54,12 +54,6 @@ struct EllArgs {
     int32_t ngroups, chunk;  // groups in total / per XCD
     uint32_t vec_bytes;      // M * ld * 8 (0 when wide)
     int32_t wide;            // slab of 4 GiB or more: 64-bit addressing
-    // staged variant (kron_stage_kernel): per group of R rows the list of distinct
-    // columns and, per ELL slot, its position in that list
-    const int32_t *tile_uniq;   // [ngroups][U]
-    const int32_t *tile_nu;     // [ngroups] number of distinct columns
-    const uint16_t *tile_slot;  // [M][K]
-    int32_t U;
 };
 
 // K: slots per row (compile time).  NPF: ELL elements each thread prefetches
@@ -290,196 +284,6 @@ __global__ __launch_bounds__(BS, K >= 12 ? 4 : 6) void kron_ell_kernel(const Ell
     }
 }
 
-// ---------------------------------------------------------------------------
-// Staged variant of the fast path: the U distinct columns a group of R rows
-// refers to (neighbouring rows share neighbours: U is about R*K/2.5) are copied
-// to LDS once, by LDS-DMA loads that are coalesced over whole time columns, and
-// the K gathers of every lane read LDS.  Half the global load instructions of
-// the gather kernel above for the same bytes from HBM.
-template <int NT, int K, int NPF, int XPT>
-__global__ __launch_bounds__(BS, 6) void kron_stage_kernel(const EllArgs<NT> a)
-{
-    constexpr int KS = (K + 3) & ~3;
-    extern __shared__ double sm[];
-    const int W = a.P, R = a.R, SW = a.n_loc + 3, U = a.U;
-    double2 *xs = reinterpret_cast<double2 *>(sm);                        // [U][P] staged time columns
-    double *s_w = sm + 2 * (size_t)((XPT * R * W + 63) & ~63);            // [NT][R][SW]
-    double *s_val = s_w + (a.any_tri ? NT * R * SW : 0);                  // [NT][R][KS]
-    uint32_t *s_slot = reinterpret_cast<uint32_t *>(s_val + NT * R * KS); // [R][KS] element offset into xs
-    uint32_t *s_row = s_slot + R * KS;                                    // [R] byte offset of the output row
-    uint32_t *s_uniq = s_row + ((R + 3) & ~3);                            // [U] byte offset of the column
-    const int LT = (a.n_loc + 2) & ~1;
-    double *s_tri = reinterpret_cast<double *>(s_uniq + ((U + 3) & ~3));
-
-    const int tid = threadIdx.x;
-    const int r = tid / W;
-    const int p = tid - r * W;
-    const bool is_pair = r < R;
-    const int t0 = 2 * p;
-    const bool has1 = t0 + 1 < a.n_loc;
-    const uint32_t ld_bytes = (uint32_t)a.ld * 8u;
-    const uint32_t t0_bytes = (uint32_t)t0 * 8u;
-    const stk_slab<false> sy(a.y, a.vec_bytes);
-    const char *xbase = reinterpret_cast<const char *>(a.x[0]);
-
-    if (a.any_tri) {
-        for (int i = threadIdx.x; i < NT * 3 * LT; i += BS) {
-            const int k = i / (3 * LT), rem = i - k * 3 * LT;
-            const int d = rem / LT, t = rem - d * LT;
-            s_tri[i] = (a.tri[k] != nullptr && t < a.n_loc) ? a.tri[k][d * a.n_loc + t] : 0.0;
-        }
-    }
-    int st_lds[NPF];
-#pragma unroll
-    for (int q = 0; q < NPF; ++q) {
-        const int i = tid + q * BS;
-        st_lds[q] = (i / K) * KS + (i % K);
-    }
-    // staging role = compute role: in pass j lane (r, p) copies pair p of listed column r + j*R
-
-    const int xcd = blockIdx.x & 7;
-    const int step = gridDim.x >> 3;
-    const int gend = min((xcd + 1) * a.chunk, a.ngroups);
-    int g = xcd * a.chunk + (int)(blockIdx.x >> 3);
-    if (g >= gend) return;
-
-    int32_t pslot[NPF];
-    double pval[NT][NPF];
-    int32_t prow = 0;
-    uint32_t puniq = 0;
-#pragma unroll
-    for (int q = 0; q < NPF; ++q) {
-        pslot[q] = 0;
-#pragma unroll
-        for (int k = 0; k < NT; ++k) pval[k][q] = 0.0;
-    }
-    auto load_entries = [&](int gg) {
-        const int rows = min(R, a.M - gg * R);
-        const size_t base = (size_t)gg * R * K;
-#pragma unroll
-        for (int q = 0; q < NPF; ++q) {
-            const int i = tid + q * BS;
-            if (i < rows * K) {
-                pslot[q] = a.tile_slot[base + i];
-#pragma unroll
-                for (int k = 0; k < NT; ++k) pval[k][q] = a.ell_vals[k][base + i];
-            }
-        }
-        if (tid < rows) prow = a.row_ids ? a.row_ids[gg * R + tid] : gg * R + tid;
-        if (tid < U) puniq = (uint32_t)a.tile_uniq[(size_t)gg * U + tid] * ld_bytes;
-    };
-    load_entries(g);
-
-    for (; g < gend; g += step) {
-        const int rows = min(R, a.M - g * R);
-        const int nu = a.tile_nu[g];
-        // ---- registers -> LDS: this group's entries and column list
-#pragma unroll
-        for (int q = 0; q < NPF; ++q) {
-            const int i = tid + q * BS;
-            if (i < rows * K) {
-                s_slot[st_lds[q]] = (uint32_t)pslot[q] * (uint32_t)W;
-#pragma unroll
-                for (int k = 0; k < NT; ++k) s_val[k * R * KS + st_lds[q]] = pval[k][q];
-            }
-        }
-        if (tid < rows) s_row[tid] = (uint32_t)prow * ld_bytes;
-        if (tid < U) s_uniq[tid] = puniq;
-        __syncthreads();  // also: every wave is done reading xs of the previous group
-
-        // ---- the group's columns: global -> LDS, one 16-byte piece per lane and instruction
-#pragma unroll
-        for (int j = 0; j < XPT; ++j) {
-            const int cu = r + j * R;
-            if (is_pair && cu < nu) {
-                const char *src = xbase + s_uniq[cu] + t0_bytes;
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)src,
-                    (__attribute__((address_space(3))) void *)(xs + (j * R * W + (tid & ~63))), 16, 0, 0);
-            }
-        }
-        if (g + step < gend) load_entries(g + step);  // next group's entries ride behind
-        __builtin_amdgcn_s_waitcnt(0);                // vmcnt(0): the DMA has landed
-        __syncthreads();
-
-        const bool act = is_pair && r < rows;
-        const uint32_t yo = act ? s_row[r] : 0u;
-        double acc0[NT], acc1[NT];
-#pragma unroll
-        for (int k = 0; k < NT; ++k) acc0[k] = acc1[k] = 0.0;
-        if (act) {
-            const uint32_t *so = s_slot + r * KS;
-            double2 xv[K];
-#pragma unroll
-            for (int u = 0; u < K; ++u) xv[u] = xs[so[u] + p];
-#pragma unroll
-            for (int k = 0; k < NT; ++k) {
-                const double *sv = s_val + (k * R + r) * KS;
-#pragma unroll
-                for (int u = 0; u < K; ++u) {
-                    const double v = sv[u];
-                    acc0[k] = fma(v, xv[u].x, acc0[k]);
-                    acc1[k] = fma(v, xv[u].y, acc1[k]);
-                }
-            }
-        }
-        double y0 = 0.0, y1 = 0.0;
-        if (a.any_tri) {
-            if (act) {
-#pragma unroll
-                for (int k = 0; k < NT; ++k) {
-                    double *w = s_w + (k * R + r) * SW;
-                    w[t0 + 1] = acc0[k];
-                    if (has1) w[t0 + 2] = acc1[k];
-                }
-            }
-            __syncthreads();
-            if (act) {
-#pragma unroll
-                for (int k = 0; k < NT; ++k) {
-                    if (a.tri[k] != nullptr) {
-                        const double *w = s_w + (k * R + r) * SW + t0 + 1;
-                        const double *c = s_tri + k * 3 * LT + t0;
-                        const double2 sub = *reinterpret_cast<const double2 *>(c);
-                        const double2 dia = *reinterpret_cast<const double2 *>(c + LT);
-                        const double2 sup = *reinterpret_cast<const double2 *>(c + 2 * LT);
-                        double v0 = dia.x * acc0[k];
-                        if (t0 > 0) v0 = fma(sub.x, w[-1], v0);
-                        if (has1) v0 = fma(sup.x, acc1[k], v0);
-                        y0 += v0;
-                        if (has1) {
-                            double v1 = dia.y * acc1[k];
-                            v1 = fma(sub.y, acc0[k], v1);
-                            if (t0 + 2 < a.n_loc) v1 = fma(sup.y, w[2], v1);
-                            y1 += v1;
-                        }
-                    } else {
-                        y0 += acc0[k];
-                        y1 += acc1[k];
-                    }
-                }
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < NT; ++k) {
-                y0 += acc0[k];
-                y1 += acc1[k];
-            }
-            __syncthreads();
-        }
-        if (act) {
-            if (!has1) y1 = 0.0;
-            if (a.beta != 0.0) {
-                const double2 old = sy.load(yo, t0_bytes);
-                y0 = fma(a.beta, old.x, y0);
-                if (has1) y1 = fma(a.beta, old.y, y1);
-            }
-            sy.store(yo, t0_bytes, make_double2(y0, y1));
-        }
-    }
-}
-
-int g_ell_stage = 1;  // staged variant where the pattern carries the column lists
 int g_ell_wg_per_cu = 0;
 int g_ell_force_wide = 0;     // testing: 64-bit addressing on small slabs
 int g_ell_force_generic = 0;  // benchmarking: run the generic kernel even when the fast path applies
@@ -502,59 +306,9 @@ int launch4(hipStream_t st, const EllArgs<NT> &a, unsigned grid, size_t lds)
     return 0;
 }
 
-template <int NT, int K, int NPF>
-int launch_stage_x(hipStream_t st, const EllArgs<NT> &a, unsigned grid, size_t lds)
-{
-    const int xpt = (a.U + a.R - 1) / a.R;
-    if (xpt <= 1)
-        hipLaunchKernelGGL((kron_stage_kernel<NT, K, NPF, 1>), dim3(grid), dim3(BS), lds, st, a);
-    else if (xpt <= 2)
-        hipLaunchKernelGGL((kron_stage_kernel<NT, K, NPF, 2>), dim3(grid), dim3(BS), lds, st, a);
-    else if (xpt <= 3)
-        hipLaunchKernelGGL((kron_stage_kernel<NT, K, NPF, 3>), dim3(grid), dim3(BS), lds, st, a);
-    else if (xpt <= 4)
-        hipLaunchKernelGGL((kron_stage_kernel<NT, K, NPF, 4>), dim3(grid), dim3(BS), lds, st, a);
-    else
-        return -1;
-    STK_LAUNCH_CHECK();
-    return 0;
-}
-
-// returns -1 when the staged kernel does not apply
-template <int NT, int K>
-int launch_stage(hipStream_t st, const EllArgs<NT> &a, int per_cu_hint)
-{
-    const int KS = (K + 3) & ~3;
-    const int xpt_ = (a.U + a.R - 1) / a.R;
-    const size_t lds = 16 * (size_t)((xpt_ * a.R * a.P + 63) & ~63) +
-                       sizeof(double) * ((a.any_tri ? (size_t)NT * a.R * (a.n_loc + 3) : 0) +
-                                         (size_t)NT * a.R * KS) +
-                       sizeof(int32_t) * ((size_t)a.R * KS + a.R + 4 + a.U + 4) +
-                       sizeof(double) * (size_t)NT * 3 * (a.n_loc + 2) + 32;
-    if (lds > 64 * 1024 || a.U > BS) return -1;
-    const int n_cu = stk_cu_count();
-    int per_cu = per_cu_hint > 0 ? per_cu_hint : 3;
-    const int by_lds = (int)(160 * 1024 / (lds + 256));
-    if (per_cu > by_lds) per_cu = by_lds > 0 ? by_lds : 1;
-    int per_xcd = (n_cu / 8) * per_cu;
-    if (per_xcd > a.chunk) per_xcd = a.chunk;
-    if (per_xcd < 1) per_xcd = 1;
-    const unsigned grid = (unsigned)per_xcd * 8;
-    const int npf = (a.R * K + BS - 1) / BS;
-    if (npf <= 1) return launch_stage_x<NT, K, 1>(st, a, grid, lds);
-    if (npf <= 2) return launch_stage_x<NT, K, 2>(st, a, grid, lds);
-    return -1;
-}
-
 template <int NT, bool SHARED_IN, int K>
 int launch3(hipStream_t st, const EllArgs<NT> &a, unsigned grid, size_t lds)
 {
-    if constexpr (SHARED_IN && K <= 9) {
-        if (g_ell_stage && a.tile_slot && !a.wide && a.ovf_indptr == nullptr && !g_ell_force_generic) {
-            const int rc = launch_stage<NT, K>(st, a, g_ell_wg_per_cu);
-            if (rc >= 0) return rc;
-        }
-    }
     if (a.wide) return launch4<NT, SHARED_IN, K, true, true>(st, a, grid, lds);
     const bool generic = a.ovf_indptr != nullptr || g_ell_force_generic;
     return generic ? launch4<NT, SHARED_IN, K, true>(st, a, grid, lds)
@@ -727,16 +481,6 @@ int dispatch(hipStream_t st, const stk_ell_pattern *pat, int32_t n_loc, int32_t 
         if (t[k].x != t[0].x) shared = false;
     }
     a.P = (n_loc + 1) / 2;
-    a.tile_uniq = nullptr;
-    a.tile_nu = nullptr;
-    a.tile_slot = nullptr;
-    a.U = 0;
-    if (pat->tile_slot && pat->tile_R == BS / a.P && pat->tile_R * pat->K <= 2 * BS) {
-        a.tile_uniq = pat->tile_uniq;
-        a.tile_nu = pat->tile_nu;
-        a.tile_slot = pat->tile_slot;
-        a.U = pat->tile_U;
-    }
     int rc = shared ? launch2<NT, true>(st, a, pat->K) : launch2<NT, false>(st, a, pat->K);
     if (rc) return rc;
     return ghost_dispatch<NT>(st, pat, n_loc, ld, t, y);
@@ -752,10 +496,6 @@ int stk_kron_ell_set_tuning(const char *key, int32_t value)
     }
     if (std::strcmp(key, "ell_force_generic") == 0) {
         g_ell_force_generic = value;
-        return 0;
-    }
-    if (std::strcmp(key, "ell_stage") == 0) {
-        g_ell_stage = value;
         return 0;
     }
     if (std::strcmp(key, "ell_wg_per_cu") == 0) {

@@ -32,9 +32,7 @@ ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p,
 
 class EllPattern(ctypes.Structure):
     _fields_ = [('M', c_i32), ('K', c_i32), ('ell_idx', c_p),
-                ('row_ids', c_p), ('ovf_indptr', c_p), ('ovf_indices', c_p),
-                ('tile_R', c_i32), ('tile_U', c_i32), ('tile_uniq', c_p),
-                ('tile_nu', c_p), ('tile_slot', c_p)]
+                ('row_ids', c_p), ('ovf_indptr', c_p), ('ovf_indices', c_p)]
 
 
 class KronEllTerm(ctypes.Structure):

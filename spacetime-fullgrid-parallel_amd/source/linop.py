@@ -277,33 +277,6 @@ class EllRowsMatrix:
                                    _lib.ptr(self.dia_a), _lib.ptr(self.dia_m))
 
 
-def staging_lists(ell_idx, R):
-    """For groups of R consecutive ELL rows: the sorted distinct columns of
-    every group (uniq (G, U) int32, padded with the group's first column;
-    nu (G,) their number) and for every slot its position in its group's list
-    (slot (M, K) uint16), so that uniq[pos // R, slot[pos, e]] == ell_idx[pos, e]."""
-    M, K = ell_idx.shape
-    G = (M + R - 1) // R
-    blk = np.empty((G * R, K), dtype=np.int64)
-    blk[:M] = ell_idx
-    blk[M:] = ell_idx[M - 1, 0]  # rows beyond the last group repeat one of its columns
-    blk = blk.reshape(G, R * K)
-    order = np.argsort(blk, axis=1, kind='stable')
-    srt = np.take_along_axis(blk, order, axis=1)
-    new = np.ones(srt.shape, dtype=bool)
-    new[:, 1:] = srt[:, 1:] != srt[:, :-1]
-    rank = np.cumsum(new, axis=1) - 1
-    nu = (rank[:, -1] + 1).astype(np.int32)
-    U = (int(nu.max()) + 3) & ~3
-    slot = np.empty_like(rank)
-    np.put_along_axis(slot, order, rank, axis=1)
-    uniq = np.repeat(srt[:, :1], U, axis=1)
-    rows = np.repeat(np.arange(G), R * K).reshape(G, R * K)
-    uniq[rows, rank] = srt
-    return (uniq.astype(np.int32), nu,
-            slot.reshape(G * R, K)[:M].astype(np.uint16))
-
-
 class EllMatrices:
     """Several matrices on one shared pattern in the sliced-ELL form of
     ``stk_kron_ell_apply`` (include/stk.h), resident on the device: K slots per
@@ -349,34 +322,7 @@ class EllMatrices:
         self.pattern = _lib.EllPattern(M, K, _lib.ptr(self.ell_idx),
                                        _lib.ptr(self.row_ids),
                                        _lib.ptr(self.ovf_indptr),
-                                       _lib.ptr(self.ovf_indices), 0, 0, None,
-                                       None, None)
-        self._ell_idx_host = ell_idx if self.ovf_indptr is None else None
-        self._tiles = {}
-
-    MAX_STAGED = 512  # distinct columns per group the staged kernel accepts
-
-    def _pattern_for(self, n_loc):
-        """The pattern with the staging lists of the staged kernel
-        (stk_ell_pattern.tile_*) for the row-group size of this n_loc, built
-        once per group size."""
-        R = 512 // ((n_loc + 1) // 2)
-        if self._ell_idx_host is None or R < 1 or R * self.K > 1024:
-            return self.pattern
-        if R not in self._tiles:
-            M, K = self._ell_idx_host.shape
-            uniq, nu, slot = staging_lists(self._ell_idx_host, R)
-            tile = None
-            if uniq.shape[1] <= self.MAX_STAGED:
-                tile = {'uniq': _lib.to_dev(uniq), 'nu': _lib.to_dev(nu),
-                        'slot': _lib.to_dev(slot)}
-                tile['pattern'] = _lib.EllPattern(
-                    M, K, _lib.ptr(self.ell_idx), _lib.ptr(self.row_ids), None,
-                    None, R, uniq.shape[1], _lib.ptr(tile['uniq']),
-                    _lib.ptr(tile['nu']), _lib.ptr(tile['slot']))
-            self._tiles[R] = tile
-        tile = self._tiles[R]
-        return self.pattern if tile is None else tile['pattern']
+                                       _lib.ptr(self.ovf_indices))
 
     def _terms(self, specs, ghosts):
         terms = (_lib.KronEllTerm * len(specs))()
@@ -391,15 +337,15 @@ class EllMatrices:
     def apply(self, specs, n_loc, ld, beta, out):
         """y = beta*y + sum over specs (tri, matrix index, x, x_lo, x_hi)."""
         _lib.check(_lib.lib().stk_kron_ell_apply(
-            _lib.stream(), ctypes.byref(self._pattern_for(n_loc)), n_loc, ld,
-            len(specs), self._terms(specs, True), beta, _lib.ptr(out)))
+            _lib.stream(), ctypes.byref(self.pattern), n_loc, ld, len(specs),
+            self._terms(specs, True), beta, _lib.ptr(out)))
 
     def apply_local(self, specs, n_loc, ld, beta, out):
         """The part of `apply` that needs no ghost rows (x_lo, x_hi ignored):
         can run while the halo exchange is in flight."""
         _lib.check(_lib.lib().stk_kron_ell_apply(
-            _lib.stream(), ctypes.byref(self._pattern_for(n_loc)), n_loc, ld,
-            len(specs), self._terms(specs, False), beta, _lib.ptr(out)))
+            _lib.stream(), ctypes.byref(self.pattern), n_loc, ld, len(specs),
+            self._terms(specs, False), beta, _lib.ptr(out)))
 
     def apply_ghost(self, specs, n_loc, ld, out):
         """Adds what the ghost rows contribute: apply = apply_local, then
