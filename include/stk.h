@@ -165,7 +165,7 @@ int stk_csr_spmm(void *stream, int32_t rows, int32_t n_loc, int32_t ld,
                  const double *z, double *y);
 
 /* The same on a sliced-ELL copy (fast path; slot count K one of 2, 5, 7, 9,
- * 12, 16; padding slots: any valid column, value 0).  ELL row `pos` produces
+ * 12, 16, 20; padding slots: any valid column, value 0).  ELL row `pos` produces
  * output row row_ids[pos]; dia_a / dia_m hold the diagonal entry of that row
  * (Gauss-Seidel only). */
 typedef struct {
