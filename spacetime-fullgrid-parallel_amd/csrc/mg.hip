@@ -12,7 +12,12 @@
 //     u_i += (1 / a_ii) * (f_i - sum_j a_ij u_j)        (CSR order, j = i included)
 // on exactly the same inputs, so the sweep is the reference's sweep, not a
 // re-coloured variant.  With the build's vertex numbering (source/mesh.py)
-// the DAG has 4 groups on the square.
+// the DAG has 4 groups for the 7-point matrices of the square and 3 for its
+// stiffness matrix alone.  Around that: the restricted residual is formed as
+// (R A) u - R f from precomputed products, the first sweep of a level visit
+// (u = 0) runs on per-group matrices without the zero products and without
+// zeroing u, and the coarsest levels run as one job-list launch
+// (mg_coarse.hip).
 //
 // Matrix entries may depend on the time slice: a(t) = ca*vals_a + cm[t]*vals_m.
 // That is how the block-diagonal preconditioner's matrices 2^j M_x + alpha A_x

@@ -12,7 +12,10 @@
 // compile-time slot count K, all K gathers of a lane issued back to back
 // through a buffer descriptor, ELL entries of the next row group prefetched
 // into registers and handed over through double-buffered LDS (one barrier per
-// group).  HBM-bound: every slab row and matrix entry is read once per pass.
+// group).  What a pass costs is its wave-level VMEM instructions: K gathers, the
+// right-hand side and the store per lane; in GS mode the row's own value is
+// taken from the diagonal gather (every such row has its diagonal entry among
+// the K slots) rather than loaded again.
 #include <cstring>
 
 #include "stk_common.h"
