@@ -185,13 +185,17 @@ class HeatEquationMPI:
         hierarchy = MeshHierarchy(mesh_space)
         self.hierarchy = hierarchy
         if precond == 'multigrid':
-            self.Kinv_x = MultiGrid(self.A_x, hierarchy,
-                                    smoothsteps=smoothsteps, vcycles=vcycles)
-            # C_j = multigrid for 2^j M_x + alpha A_x, all in one family
-            self.C_family = MultiGridFamily(
-                self.A_x, self.M_x, hierarchy, ca=alpha,
-                cms=[2**j for j in range(self.J_time + 1)],
-                smoothsteps=smoothsteps, vcycles=vcycles)
+            # the two hierarchies (A_x alone; 2^j M_x + alpha A_x, all j in one
+            # family) are independent host work (SciPy / NumPy release the GIL)
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=2) as pool:
+                kinv = pool.submit(MultiGrid, self.A_x, hierarchy,
+                                   smoothsteps=smoothsteps, vcycles=vcycles)
+                family = pool.submit(
+                    MultiGridFamily, self.A_x, self.M_x, hierarchy, ca=alpha,
+                    cms=[2**j for j in range(self.J_time + 1)],
+                    smoothsteps=smoothsteps, vcycles=vcycles)
+                self.Kinv_x, self.C_family = kinv.result(), family.result()
             self.C_j = self.C_family.members
         else:
             assert (precond == 'direct')

@@ -14,6 +14,7 @@ KronLinOp / BlockDiagLinOp are the serial (single-rank, flat NumPy vector in /
 out) operators of reference linop.py:6-15, 29-44, run on the device.
 """
 import ctypes
+import threading
 import weakref
 
 import numpy as np
@@ -212,7 +213,7 @@ class EllRowsMatrix:
     the diagonal arrays the Gauss-Seidel mode needs.  `ok` is False when a row
     has more entries than the largest instantiated slot count."""
     SLOTS = (2, 5, 7, 9, 12, 16, 20)
-    _base_key = _base = _base_refs = None
+    _tls = threading.local()  # per-thread (key, base arrays, referents)
 
     def __init__(self, indptr, indices, va, vm=None, order=None, n_cols=None,
                  diag=False, pad_col=0, dia_values=None):
@@ -231,7 +232,8 @@ class EllRowsMatrix:
         # the (n, K) arrays in index order are built once per matrix and shared
         # by all copies that only differ in the row order (a, fwd, bwd, ...)
         key = (id(indptr), id(indices), id(va), id(vm), K_base, pad_col)
-        base = EllRowsMatrix._base if EllRowsMatrix._base_key == key else None
+        cache = getattr(EllRowsMatrix._tls, 'cache', None)  # threads build hierarchies side by side
+        base = cache[1] if cache is not None and cache[0] == key else None
         if base is None:
             pos = np.repeat(np.arange(n), counts_all)
             slot = np.arange(len(indices)) - np.repeat(indptr[:-1], counts_all)
@@ -247,9 +249,8 @@ class EllRowsMatrix:
                 em0 = np.zeros((n, K_base))
                 em0[pos, slot] = vm[keep]
             base = (idx0, ea0, em0)
-            # the key holds ids: keep the arrays alive so they cannot be reused
-            EllRowsMatrix._base_key, EllRowsMatrix._base = key, base
-            EllRowsMatrix._base_refs = (indptr, indices, va, vm)
+            # the key holds ids: the referents are kept alive with it
+            EllRowsMatrix._tls.cache = (key, base, (indptr, indices, va, vm))
         idx0, ea0, em0 = base
         npos = len(order)
         self.K, self.n_pos, self.n_rows = K, npos, n
