@@ -8,8 +8,11 @@ Launch one process per GPU:
         heateq_mpi.py --J_time=6 --J_space=9
 """
 import argparse
+import base64
 import os
+import pickle
 import sys
+import zlib
 
 import numpy as np
 import torch
@@ -291,7 +294,12 @@ def main(argv=None):
                                   alpha=args.alpha,
                                   wavelettransform=args.wavelettransform,
                                   schur=args.schur)
+    # per-rank record, gathered and printed as one blob at the end
+    # (reference heateq_mpi.py:237, 259-312)
+    data = {'rank': rank, 'mem_after_construction': mem()}
     if rank == 0:
+        data['args'] = vars(args)
+        data['N'], data['M'] = heat_eq_mpi.N, heat_eq_mpi.M
         print('N = {}. M = {}.'.format(heat_eq_mpi.N, heat_eq_mpi.M))
         print('Constructed bilinear forms in {} s.'.format(
             heat_eq_mpi.setup_time))
@@ -309,6 +317,18 @@ def main(argv=None):
                          callback=cb, history=hist)
     comm.Barrier()
     solve_time = MPI.Wtime() - solve_time
+    data['solve_time'] = solve_time
+    data['mem_after_solve'] = mem()
+    data['iters'] = iters
+    data['r_dot_Pr'] = list(hist)
+    for name, op in [('W', heat_eq_mpi.W), ('S', heat_eq_mpi.S),
+                     ('WT', heat_eq_mpi.WT), ('P', heat_eq_mpi.P),
+                     ('WT_S_W', heat_eq_mpi.WT_S_W)]:
+        data[name] = {
+            'time_applies': op.time_applies,
+            'time_communication': op.time_communication,
+            'num_applies': op.num_applies
+        }
     if rank == 0:
         print('')
         print('Completed in {} PCG steps.'.format(iters))
@@ -316,6 +336,10 @@ def main(argv=None):
         print('Final r.Pr: {}'.format(hist[-1]))
         heat_eq_mpi.print_time_per_apply()
         print('Device memory after solve: {}mb.'.format(mem()))
+    data = comm.gather(data, root=0)
+    if rank == 0:
+        print('\ndata: {}'.format(
+            str(base64.b64encode(zlib.compress(pickle.dumps(data))), 'ascii')))
     return heat_eq_mpi, u_mpi_P, iters, hist
 
 

@@ -7,8 +7,11 @@ random vector, vec._invalidate() before each so the halo is re-exchanged).
         heateq_mpi_timing.py --J_time=6 --J_space=9
 """
 import argparse
+import base64
 import os
+import pickle
 import sys
+import zlib
 
 import numpy as np
 import torch
@@ -66,27 +69,44 @@ def main(argv=None):
         vec.X_loc[t - dd.t_begin] = torch.from_numpy(
             np.random.RandomState(128 + t).rand(heat_eq_mpi.M)).to(
                 vec.buf.device)
-    data = {}
+    data = {'rank': rank}
     for name, op in [('W', heat_eq_mpi.W), ('S', heat_eq_mpi.S),
                      ('WT', heat_eq_mpi.WT), ('P', heat_eq_mpi.P)]:
         op @ vec  # warm-up (plans, workspaces); not counted
         op.num_applies, op.time_applies, op.time_communication = 0, 0, 0
-        per_iter = []
+        time_total_op = MPI.Wtime()
+        time_applies_iter, time_communication_iter = [], []
         for _ in range(args.iters):
-            t_a = op.time_applies
+            t_a, t_c = op.time_applies, op.time_communication
             vec._invalidate()
             op @ vec
-            per_iter.append(op.time_applies - t_a)
+            time_applies_iter.append(op.time_applies - t_a)
+            time_communication_iter.append(op.time_communication - t_c)
             comm.Barrier()
-        data[name] = per_iter
+        # the per-operator record of reference heateq_mpi_timing.py:104-111
+        data[name] = {
+            'time_applies': op.time_applies,
+            'time_communication': op.time_communication,
+            'time_applies_iter': time_applies_iter,
+            'time_communication_iter': time_communication_iter,
+            'num_applies': op.num_applies,
+            'time_total': MPI.Wtime() - time_total_op
+        }
     comm.Barrier()
+    data['time_total'] = MPI.Wtime() - time_total
+    data['mem_after_timing'] = mem()
     if rank == 0:
         print('')
         print('Completed {} iters steps.'.format(args.iters))
-        print('Total time: {}s.'.format(MPI.Wtime() - time_total))
+        print('Total time: {}s.'.format(data['time_total']))
         print('      apply      communication   (seconds per apply)')
         heat_eq_mpi.print_time_per_apply()
         print('Device memory after timing: {}mb.'.format(mem()))
+    gathered = comm.gather(data, root=0)
+    if rank == 0:
+        print('\ndata: {}'.format(
+            str(base64.b64encode(zlib.compress(pickle.dumps(gathered))),
+                'ascii')))
     return data
 
 
