@@ -400,3 +400,27 @@ def BlockDiagLinOp(linops):
         return y
 
     return LinearOperator(matvec=matvec, shape=(height, width))
+
+
+def BlockLinOp(linops):
+    """A rectangular grid of operators as one operator: row i of `linops`
+    produces the i-th slice of the output from the slices of the input that its
+    blocks multiply (reference linop.py:47-65; unused by the drivers).  Blocks
+    may be space operators, matrices or LinearOperators."""
+    rows = [[as_space_op(b) if sp.issparse(b) or isinstance(b, np.ndarray)
+             else b for b in row] for row in linops]
+    heights = [row[0].shape[0] for row in rows]
+    widths = [b.shape[1] for b in rows[0]]
+
+    def matvec(x):
+        x = np.asarray(x, dtype=np.float64).reshape(-1)
+        col_edges = np.concatenate([[0], np.cumsum(widths)])
+        pieces = []
+        for row, h in zip(rows, heights):
+            acc = np.zeros(h)
+            for b, lo, hi in zip(row, col_edges[:-1], col_edges[1:]):
+                acc += b @ x[lo:hi]
+            pieces.append(acc)
+        return np.concatenate(pieces)
+
+    return LinearOperator(matvec=matvec, shape=(sum(heights), sum(widths)))

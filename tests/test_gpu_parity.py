@@ -618,6 +618,17 @@ def test_serial_kron_linop_rectangular_and_operator_factors(stk):
         op = BlockDiagLinOp(blocks)
         x = rng.rand(op.shape[1])
         assert relerr(op @ x, sp.block_diag(blocks) @ x) < 1e-14
+    # BlockLinOp (linop.py:47-65): a 2 x 3 grid of rectangular blocks
+    from source.linop import BlockLinOp
+    grid = [[sp.random(5, 4, density=0.6, random_state=rng, format='csr'),
+             sp.random(5, 7, density=0.6, random_state=rng, format='csr'),
+             sp.random(5, 3, density=0.6, random_state=rng, format='csr')],
+            [sp.random(8, 4, density=0.6, random_state=rng, format='csr'),
+             sp.random(8, 7, density=0.6, random_state=rng, format='csr'),
+             sp.random(8, 3, density=0.6, random_state=rng, format='csr')]]
+    op = BlockLinOp(grid)
+    x = rng.rand(op.shape[1])
+    assert relerr(op @ x, sp.bmat(grid) @ x) < 1e-14
 
 
 @pytest.mark.parametrize('precond', ['multigrid', 'direct'])
