@@ -102,11 +102,14 @@ def _simplex_geometry(mesh):
         adj[:, 1, 0], adj[:, 1, 1] = -E[:, 1, 0], E[:, 0, 0]
         det = E[:, 0, 0] * E[:, 1, 1] - E[:, 0, 1] * E[:, 1, 0]
     else:
-        r0, r1, r2 = E[:, 0], E[:, 1], E[:, 2]
-        adj[:, :, 0] = np.cross(r1, r2)
-        adj[:, :, 1] = np.cross(r2, r0)
-        adj[:, :, 2] = np.cross(r0, r1)
-        det = np.einsum('td,td->t', r0, adj[:, :, 0])
+        a, b, c3 = (E[:, 0, k] for k in range(3))  # components of the rows, by column
+        d_, e_, f_ = (E[:, 1, k] for k in range(3))
+        g_, h_, i_ = (E[:, 2, k] for k in range(3))
+        # cofactors written out (np.cross on (n, 3) arrays is several times slower)
+        adj[:, 0, 0], adj[:, 1, 0], adj[:, 2, 0] = e_ * i_ - f_ * h_, f_ * g_ - d_ * i_, d_ * h_ - e_ * g_
+        adj[:, 0, 1], adj[:, 1, 1], adj[:, 2, 1] = c3 * h_ - b * i_, a * i_ - c3 * g_, b * g_ - a * h_
+        adj[:, 0, 2], adj[:, 1, 2], adj[:, 2, 2] = b * f_ - c3 * e_, c3 * d_ - a * f_, a * e_ - b * d_
+        det = a * adj[:, 0, 0] + b * adj[:, 1, 0] + c3 * adj[:, 2, 0]
     vol = np.abs(det) / (2.0 if d == 2 else 6.0)
     g = np.empty((len(c), d + 1, d))
     # column k of E^{-1} is the gradient of lambda_{k+1}
@@ -166,7 +169,7 @@ def space_matrices(mesh):
     nv = mesh.nv
     rows = np.repeat(c, nl, axis=1).reshape(-1)
     cols = np.tile(c, (1, nl)).reshape(-1)
-    K = np.einsum('tid,tjd->tij', g, g) * vol[:, None, None]
+    K = np.matmul(g, np.swapaxes(g, 1, 2)) * vol[:, None, None]
     Mloc = (np.ones((nl, nl)) + np.eye(nl)) / (nl * (nl + 1.0))
     Mv = vol[:, None, None] * Mloc[None]
     A = sp.coo_matrix((K.reshape(-1), (rows, cols)), shape=(nv, nv)).tocsr()
