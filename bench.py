@@ -92,6 +92,8 @@ def main():
     ap.add_argument('--solve-iters', type=int, default=10,
                     help='PCG iterations to time for iters/s (0 = skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--preheat', type=float, default=0.5,
+                    help='seconds of untimed applies before the warm-up steps')
     args = ap.parse_args()
 
     import torch
@@ -125,6 +127,14 @@ def main():
         x._invalidate()  # forces the halo exchange, as heateq_mpi_timing.py:94
         op._matvec(x, y)
 
+    # bring the device to its steady clocks first: a cold GPU runs the first few
+    # milliseconds of work measurably slower (the same kernel: 0.40 ms in the
+    # first 10 ms after start-up, 0.37 ms later)
+    t_hot = time.perf_counter() + args.preheat
+    while time.perf_counter() < t_hot:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     comm.Barrier()
@@ -175,7 +185,7 @@ def main():
         from source.linalg import PCG
         h = hm.HeatEquationMPI(J_space=args.J_space, J_time=args.J_time,
                                problem=args.problem)
-        PCG(h.WT_S_W, h.P, h.rhs, kmax=2)  # warm-up (plans, workspaces)
+        PCG(h.WT_S_W, h.P, h.rhs, kmax=8)  # warm-up: plans, workspaces, steady clocks
         comm.Barrier()
         hist, stamps = [], []
 
