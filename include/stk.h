@@ -257,6 +257,17 @@ typedef struct {
      * With it the plan neither zeroes u before that sweep nor gathers the
      * zeros. */
     const stk_ell_rows *ell_fwd0;
+    /* Optional (0 / NULL if absent): the rows of ell_fwd / ell_bwd are listed in
+     * an order that follows the geometry; *_tile_row_host[pos] is the index of
+     * the tile row (0 .. n_tile_rows-1, ascending inside every group) position
+     * pos lies in, and rows in tile row r only couple to tile rows r-1 .. r+1.
+     * With it a sweep on a large level runs strip by strip -- all groups on one
+     * strip of tile rows before the next strip, each group shifted by one tile
+     * row against the previous one so that the order of updates is unchanged --
+     * and the strip's vectors stay in the Infinity Cache between the group
+     * passes. */
+    int32_t n_tile_rows;
+    const int32_t *fwd_tile_row_host, *bwd_tile_row_host;
 } stk_mg_level;
 
 typedef struct stk_mg stk_mg;

@@ -23,6 +23,8 @@
 // That is how the block-diagonal preconditioner's matrices 2^j M_x + alpha A_x
 // (reference heateq_mpi.py:97-98) share one stored hierarchy: Galerkin
 // coarsening is linear, so R(2^j M + alpha A)P = 2^j RMP + alpha RAP.
+#include <algorithm>
+#include <map>
 #include <vector>
 
 #include "stk_common.h"
@@ -89,6 +91,7 @@ __global__ __launch_bounds__(GBS) void coarse_kernel(int32_t n0, int32_t n_loc, 
 
 }  // namespace
 
+int g_mg_strip_mb = 400;        // strip-wise sweeps: working set (u and f) of a strip in MB; 0 = off
 int g_mg_zero_start = 1;        // 0: zero u in memory and run the first sweep like the others
 int g_mg_fuse_restrict = 1;     // 0: residual and restriction as two steps
 int g_mg_fuse_coarse = 1;       // 0 disables the fused coarse sub-V-cycle
@@ -99,6 +102,11 @@ struct EllLevel {
     stk_ell_rows a, fwd, bwd, p, r, ra;
     std::vector<stk_ell_rows> fwd0;  // per forward group: entries towards earlier groups only
     std::vector<int32_t> fwd_pos, bwd_pos;
+    // strip-wise sweeps: tile row of every position, and per strip count S the
+    // position ranges [S][groups][2] (built on first use)
+    std::vector<int32_t> fwd_trow, bwd_trow;
+    int n_tile_rows = 0;
+    mutable std::map<int, std::vector<int32_t>> fwd_strips, bwd_strips;
 };
 
 struct stk_mg {
@@ -130,6 +138,43 @@ static bool can_zero_start(const stk_mg *mg, int level, int ld)
            E.fwd0.size() + 1 == E.fwd_pos.size() && ell_slab_ok(mg->lv[level].n, ld);
 }
 
+// Strip-wise sweep.  On a large level one group pass streams the whole level
+// through the caches, so the next group finds nothing of it there.  The rows are
+// listed in a geometric order, tile row by tile row, and a row only couples to
+// the tile rows next to its own; so the level is cut into S strips of tile rows
+// and ALL groups run on strip s before strip s+1, group g shifted down by g tile
+// rows against group 0: group g then still finds every row of the groups < g it
+// reads already updated, and no row of a group > g that it reads has been
+// touched -- the order of updates, and with it the result, is unchanged, but the
+// strip (u and f: `strip_mb` MB) stays in the 256 MB Infinity Cache between the
+// group passes.  Returns the [S][groups][2] position table, or NULL.
+static const std::vector<int32_t> *strip_table(const EllLevel &E, bool backward, int64_t rows, int ld)
+{
+    if (g_mg_strip_mb <= 0 || E.n_tile_rows < 2) return nullptr;
+    const double level_mb = 2.0 * (double)rows * ld * 8.0 / 1.0e6;  // u and f
+    int S = (int)(level_mb / g_mg_strip_mb + 0.999);
+    const std::vector<int32_t> &pos = backward ? E.bwd_pos : E.fwd_pos;
+    const int ng = (int)pos.size() - 1;
+    if (S > (E.n_tile_rows - ng) / 2) S = (E.n_tile_rows - ng) / 2;  // strips of at least 2 tile rows
+    if (S < 2) return nullptr;
+    auto &cache = backward ? E.bwd_strips : E.fwd_strips;
+    auto it = cache.find(S);
+    if (it != cache.end()) return &it->second;
+    const std::vector<int32_t> &tr = backward ? E.bwd_trow : E.fwd_trow;
+    std::vector<int32_t> tab((size_t)S * ng * 2);
+    const int T = E.n_tile_rows;
+    for (int s = 0; s < S; ++s)
+        for (int g = 0; g < ng; ++g) {
+            const int32_t *b = tr.data() + pos[g], *e = tr.data() + pos[g + 1];
+            const int lo_row = (int)((int64_t)s * T / S) - g, hi_row = (int)((int64_t)(s + 1) * T / S) - g;
+            const int32_t *lo = (s == 0) ? b : std::lower_bound(b, e, lo_row);
+            const int32_t *hi = (s == S - 1) ? e : std::lower_bound(b, e, hi_row);
+            tab[((size_t)s * ng + g) * 2] = (int32_t)(lo - tr.data());
+            tab[((size_t)s * ng + g) * 2 + 1] = (int32_t)(hi - tr.data());
+        }
+    return &cache.emplace(S, std::move(tab)).first->second;
+}
+
 static int smooth_level(stk_mg *mg, hipStream_t st, int level, int n_loc, int ld, double ca, const double *cm,
                         int its, bool backward, const double *f, double *u, bool zero_start = false)
 {
@@ -138,25 +183,34 @@ static int smooth_level(stk_mg *mg, hipStream_t st, int level, int n_loc, int ld
     if (E.has_gs && ell_slab_ok(L.n, ld)) {
         const stk_ell_rows &e = backward ? E.bwd : E.fwd;
         const std::vector<int32_t> &pos = backward ? E.bwd_pos : E.fwd_pos;
+        const int ng = (int)pos.size() - 1;
+        const std::vector<int32_t> *strips = strip_table(E, backward, L.n, ld);
+        const int S = strips ? (int)(strips->size() / (2 * (size_t)ng)) : 1;
         int first = 0;
         if (zero_start && !backward && its >= 1) {
             // u is NOT initialised: group 0 has no entries left and gathers its
             // (zero-weighted) padding slots from f; later groups only read rows
             // of earlier groups, which this sweep has written
-            for (size_t g = 0; g < E.fwd0.size(); ++g) {
-                const stk_ell_rows &e0 = E.fwd0[g];
-                int rc = stk_rows_ell_launch(st, 1, &e0, 0, e0.n_pos, n_loc, ld, L.n, L.n, ca, cm, g == 0 ? f : u,
-                                             0.0, 0.0, f, u, /*zero_own=*/1);
-                if (rc) return rc;
-            }
+            for (int s = 0; s < S; ++s)
+                for (int g = 0; g < ng; ++g) {
+                    const stk_ell_rows &e0 = E.fwd0[g];
+                    // positions of a per-group matrix count from the start of its group
+                    const int p0 = strips ? (*strips)[((size_t)s * ng + g) * 2] - pos[g] : 0;
+                    const int p1 = strips ? (*strips)[((size_t)s * ng + g) * 2 + 1] - pos[g] : e0.n_pos;
+                    int rc = stk_rows_ell_launch(st, 1, &e0, p0, p1, n_loc, ld, L.n, L.n, ca, cm, g == 0 ? f : u, 0.0,
+                                                 0.0, f, u, /*zero_own=*/1);
+                    if (rc) return rc;
+                }
             first = 1;
         }
         for (int it = first; it < its; ++it)
-            for (size_t g = 0; g + 1 < pos.size(); ++g) {
-                int rc = stk_rows_ell_launch(st, 1, &e, pos[g], pos[g + 1], n_loc, ld, L.n, L.n, ca, cm, u, 0.0, 0.0,
-                                             f, u);
-                if (rc) return rc;
-            }
+            for (int s = 0; s < S; ++s)
+                for (int g = 0; g < ng; ++g) {
+                    const int p0 = strips ? (*strips)[((size_t)s * ng + g) * 2] : pos[g];
+                    const int p1 = strips ? (*strips)[((size_t)s * ng + g) * 2 + 1] : pos[g + 1];
+                    int rc = stk_rows_ell_launch(st, 1, &e, p0, p1, n_loc, ld, L.n, L.n, ca, cm, u, 0.0, 0.0, f, u);
+                    if (rc) return rc;
+                }
         return 0;
     }
     const std::vector<int32_t> &ptr = backward ? mg->bwd_ptr[level] : mg->fwd_ptr[level];
@@ -273,6 +327,11 @@ extern "C" int stk_mg_create(int32_t n_levels, const stk_mg_level *levels, int32
             E.fwd_pos.assign(L.fwd_pos_host, L.fwd_pos_host + L.n_fwd + 1);
             E.bwd_pos.assign(L.bwd_pos_host, L.bwd_pos_host + L.n_bwd + 1);
             E.has_gs = true;
+        }
+        if (E.has_gs && L.n_tile_rows > 1 && L.fwd_tile_row_host && L.bwd_tile_row_host) {
+            E.fwd_trow.assign(L.fwd_tile_row_host, L.fwd_tile_row_host + E.fwd.n_pos);
+            E.bwd_trow.assign(L.bwd_tile_row_host, L.bwd_tile_row_host + E.bwd.n_pos);
+            E.n_tile_rows = L.n_tile_rows;
         }
         mg->lv[j].ell_a = mg->lv[j].ell_fwd = mg->lv[j].ell_bwd = mg->lv[j].ell_p = mg->lv[j].ell_r = nullptr;
         mg->lv[j].ell_ra = mg->lv[j].ell_fwd0 = nullptr;

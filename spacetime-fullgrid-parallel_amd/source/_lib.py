@@ -60,7 +60,9 @@ class MGLevel(ctypes.Structure):
                 ('ell_r', ctypes.POINTER(EllRows)),
                 ('fwd_pos_host', c_p), ('bwd_pos_host', c_p),
                 ('ell_ra', ctypes.POINTER(EllRows)),
-                ('ell_fwd0', ctypes.POINTER(EllRows))]
+                ('ell_fwd0', ctypes.POINTER(EllRows)),
+                ('n_tile_rows', c_i32), ('fwd_tile_row_host', c_p),
+                ('bwd_tile_row_host', c_p)]
 
 
 _PROTOTYPES = {

@@ -127,10 +127,18 @@ def _restrict(mat, fd):
     return _finish(sp.csr_matrix(mat)[fd, :].tocsc()[:, fd].tocsr())
 
 
-def tile_order_from_coords(coords, rows_per_tile=2048, small_lexsort=True):
+def _rows_per_tile(rows_per_tile):
+    import os
+    if rows_per_tile is None:
+        rows_per_tile = int(os.environ.get('STK_ROWS_PER_TILE', '2048'))
+    return rows_per_tile
+
+
+def tile_order_from_coords(coords, rows_per_tile=None, small_lexsort=True):
     """A processing order that follows the geometry: the bounding box is cut
     into square (cubic) tiles of about `rows_per_tile` vertices, tiles are
     visited lexicographically and so are the vertices inside a tile."""
+    rows_per_tile = _rows_per_tile(rows_per_tile)
     p = np.asarray(coords)
     d = p.shape[1]
     lex = tuple(p[:, k] for k in range(d))
@@ -145,6 +153,21 @@ def tile_order_from_coords(coords, rows_per_tile=2048, small_lexsort=True):
     return np.lexsort(lex + tiles).astype(np.int32)
 
 
+def tile_rows_from_coords(coords, rows_per_tile=None):
+    """Index of the tile ROW (the slowest key of tile_order_from_coords) every
+    point falls into; all zero when the points fit one tile."""
+    rows_per_tile = _rows_per_tile(rows_per_tile)
+    p = np.asarray(coords)
+    d = p.shape[1]
+    if len(p) <= rows_per_tile:
+        return np.zeros(len(p), dtype=np.int32)
+    lo, hi = p.min(axis=0), p.max(axis=0)
+    ext = np.maximum(hi - lo, 1e-30)
+    ntiles = max(1.0, len(p) / float(rows_per_tile))
+    side = (np.prod(ext) / ntiles)**(1.0 / d)
+    return np.floor((p[:, d - 1] - lo[d - 1]) / side).astype(np.int32)
+
+
 def tile_row_order(mesh, rows_per_tile=None):
     """A processing order for the free dofs that follows the geometry: the
     bounding box is cut into square tiles of about `rows_per_tile` vertices,
@@ -154,9 +177,6 @@ def tile_row_order(mesh, rows_per_tile=None):
     gathers of consecutive workgroups inside the same few hundred KB, i.e. in
     the L2 of the XCD that runs them.  Purely a performance hint
     (stk_kron_sum_apply's row_ids); results do not depend on it."""
-    import os
-    if rows_per_tile is None:
-        rows_per_tile = int(os.environ.get('STK_ROWS_PER_TILE', '2048'))
     return tile_order_from_coords(mesh.points[free_dofs(mesh)], rows_per_tile,
                                   small_lexsort=False)
 

@@ -23,7 +23,8 @@ import torch
 from scipy.sparse.linalg import LinearOperator
 
 from . import _lib
-from .assembly import tile_order_from_coords  # noqa: F401 (re-exported)
+from .assembly import (tile_order_from_coords,  # noqa: F401 (re-exported)
+                       tile_rows_from_coords)
 
 
 class SpaceOp:

@@ -25,6 +25,7 @@ import torch
 from . import _lib
 from .assembly import prolongation_matrices
 from .linop import (EllRowsMatrix, SpaceOp, tile_order_from_coords,
+                    tile_rows_from_coords,
                     union_pattern)
 
 
@@ -144,6 +145,8 @@ class _DeviceHierarchy:
                 tile = np.arange(n, dtype=np.int32)
             rank = np.empty(n, dtype=np.int64)
             rank[tile] = np.arange(n)
+            trow = (tile_rows_from_coords(hierarchy.coords[:n])
+                    if hierarchy.coords is not None else None)
             vm = vals[1] if self.has_m else None
             ells = {'a': EllRowsMatrix(indptr, indices, vals[0], vm, tile)}
             for name, bw in (('fwd', False), ('bwd', True)):
@@ -160,6 +163,14 @@ class _DeviceHierarchy:
                 ]) if n else np.zeros(0, dtype=np.int64)
                 ells[name] = EllRowsMatrix(indptr, indices, vals[0], vm,
                                            tile[order], diag=True)
+                if trow is not None and trow.max() > 0:
+                    # tile row of every ELL position (ascending inside a group):
+                    # lets the plan run a sweep strip by strip (mg.hip)
+                    host[name + '_trow'] = np.ascontiguousarray(
+                        trow[tile[order]], dtype=np.int32)
+                    setattr(L, name + '_tile_row_host',
+                            host[name + '_trow'].ctypes.data_as(ctypes.c_void_p))
+                    L.n_tile_rows = int(trow.max()) + 1
                 host[name + '_pos'] = ptr  # group g = positions ptr[g]:ptr[g+1]
                 setattr(L, name + '_pos_host',
                         ptr.ctypes.data_as(ctypes.c_void_p))

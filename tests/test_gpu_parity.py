@@ -917,3 +917,26 @@ def test_zero_start_first_sweep_is_exact(stk):
             stk.check(stk.lib().stk_set_tuning(b'mg_zero_start', 1))
         assert np.array_equal(res[0][0], res[1][0])
         assert np.array_equal(res[0][1], res[1][1])
+
+
+def test_strip_wise_sweeps_are_exact(stk, monkeypatch):
+    """Gauss-Seidel sweeps run strip by strip (all dependency groups on one strip
+    of tile rows before the next, each group shifted by one tile row: mg.hip)
+    update every row from exactly the same values as level-wide group passes:
+    bitwise the same V-cycle.  Small tiles so that small levels have many tile
+    rows; strip sizes from 2 strips to as many as fit."""
+    import heateq_mpi as hm
+    monkeypatch.setenv('STK_ROWS_PER_TILE', '48')
+    for problem, J_space in (('square', 6), ('lshape', 5), ('cube', 3)):
+        h = hm.HeatEquationMPI(J_space=J_space, J_time=3, problem=problem)
+        x = _vec(h.dofs_distr, np.random.RandomState(14).rand(h.N, h.M))
+        res = []
+        try:
+            # level working set here is a few MB: strip_mb = 1 gives many strips
+            for strip_mb in (0, 1, 2):
+                stk.check(stk.lib().stk_set_tuning(b'mg_strip_mb', strip_mb))
+                res.append((_np(h.P @ x), _np(h.S @ x)))
+        finally:
+            stk.check(stk.lib().stk_set_tuning(b'mg_strip_mb', 400))
+        for Pv, Sv in res[1:]:
+            assert np.array_equal(Pv, res[0][0]) and np.array_equal(Sv, res[0][1])
