@@ -152,6 +152,47 @@ int stk_kron_ell_ghost_apply(void *stream, const stk_ell_pattern *pattern_host,
                              int32_t n_loc, int32_t ld, int32_t n_terms,
                              const stk_kron_ell_term *terms_host, double *y);
 
+/* The same operator with the matrix stream PACKED and the ghost time steps
+ * fused into the one pass (the fast path of the metric's operator,
+ * SumMPI([TridiagKronMatMPI, TridiagKronMatMPI])._matvec, mpi_kron.py:77-90,
+ * with the halo of TridiagKronIdentityMPI._matvec, :186-201).
+ * slots[pos*K + e] = code << col_bits | column; `code` indexes the dictionary of
+ * distinct value tuples of the union pattern: matrix m has the value
+ * dict[m*n_codes + code] in that slot.  Unused slots hold the row's own column
+ * and a code whose values are all zero.  Exact: the dictionary holds the
+ * doubles themselves.  Every term reads the same x; term k multiplies with
+ * matrix t[k].mat.  `ghosts` (NULL on a slab without neighbours) holds the
+ * ghost time steps interleaved: ghosts[2*j] = x[j, t = -1] (X_loc_bdr[0],
+ * mpi_vector.py:148-175), ghosts[2*j + 1] = x[j, t = n_loc] (X_loc_bdr[-1]);
+ * a side without a neighbour is zero-filled.  K one of 5, 7, 9, 12, 16; at most
+ * 3 terms; slabs of any size (64-bit addressing).
+ * Tuning keys: "pack_wg_per_cu", "pack_flags" (bit 0: non-temporal stores of y,
+ * bit 1: non-temporal loads of the slot stream). */
+typedef struct {
+    int32_t M, K;
+    int32_t col_bits; /* 2^col_bits >= M */
+    int32_t n_codes;  /* <= 2^(32 - col_bits) */
+    int32_t n_mats;
+    const uint32_t *slots;  /* M*K */
+    const int32_t *row_ids; /* M or NULL */
+    const double *dict;     /* n_mats*n_codes */
+} stk_pack_pattern;
+
+typedef struct {
+    const double *tri; /* as in stk_kron_term */
+    int32_t mat;       /* which matrix of the pattern */
+} stk_kron_pack_term;
+
+int stk_kron_pack_apply(void *stream, const stk_pack_pattern *pattern_host,
+                        int32_t n_loc, int32_t ld, int32_t n_terms,
+                        const stk_kron_pack_term *terms_host, const double *x,
+                        const double *ghosts, double beta, double *y);
+
+/* ghosts[2*j] = lo[j], ghosts[2*j + 1] = hi[j] (a NULL side is written as
+ * zero): brings the two received time rows into the layout above. */
+int stk_interleave_ghosts(void *stream, int32_t M, const double *lo,
+                          const double *hi, double *ghosts);
+
 /* ---- (I_t kron A) for a general, possibly rectangular CSR A ---------------
  * y = alpha * A x + beta * z  on `rows` x n_loc outputs (IdentityKronMatMPI,
  * mpi_kron.py:143-150; residual / restriction / prolongation steps of

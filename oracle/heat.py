@@ -75,9 +75,19 @@ class HeatEquationOracle:
         """Block diagonal of C_j A_x C_j with j = wavelet level of the time
         index (heateq_mpi.py:159-162, 183-184)."""
         out = np.empty_like(X)
-        for t, j in enumerate(self.levels):
-            C = self.C_j[j]
+
+        def one(t):
+            C = self.C_j[self.levels[t]]
             out[t] = C @ (self.A_x @ (C @ X[t]))
+
+        from . import multigrid
+        if multigrid.THREADS > 1:  # slices are independent (fixture generation)
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(multigrid.THREADS) as ex:
+                list(ex.map(one, range(len(self.levels))))
+        else:
+            for t in range(len(self.levels)):
+                one(t)
         return out
 
     def rhs(self):  # heateq_mpi.py:189-191

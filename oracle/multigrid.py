@@ -13,6 +13,11 @@ from scipy.sparse.linalg import splu
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+# Fixture generation at BASELINE sizes (tests/golden/make_oracle_vectors.py)
+# sets this > 1: the right-hand sides of a batch are independent, so a batch is
+# cut into row chunks that run side by side.  Every right-hand side still sees
+# exactly the sequential arithmetic above; the result does not depend on it.
+THREADS = 1
 
 
 def build_c():
@@ -126,12 +131,15 @@ class MultiGrid:
                                   options={"SymmetricMode": True},
                                   permc_spec="MMD_AT_PLUS_A")
         self.shape = self.mats[-1].shape
+        import threading
+        self._coarse_lock = threading.Lock()
 
     def MGM(self, j, u_j, f_j):
         """multigrid.py:168-182; u_j, f_j of shape (n_j,) or (k, n_j)."""
         if j == 0:
-            u_j[...] = self.coarse_solver.solve(
-                np.ascontiguousarray(f_j.T)).T
+            with self._coarse_lock:  # SuperLU solve objects are not re-entrant
+                u_j[...] = self.coarse_solver.solve(
+                    np.ascontiguousarray(f_j.T)).T
             return
         self.smoothers[j].PreSmooth(u_j, f_j)
         A, R, P = self.mats[j], self.R_mats[j - 1], self.P_mats[j - 1]
@@ -144,6 +152,18 @@ class MultiGrid:
     def apply(self, b):
         b = np.ascontiguousarray(b, dtype=np.float64)
         x = np.zeros_like(b)
+        if THREADS > 1 and b.ndim == 2 and b.shape[0] > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            cuts = np.linspace(0, b.shape[0], min(THREADS, b.shape[0]) + 1).astype(int)
+
+            def chunk(k):
+                xs, bs = x[cuts[k]:cuts[k + 1]], b[cuts[k]:cuts[k + 1]]
+                for _ in range(self.vcycles):
+                    self.MGM(self.J, xs, bs)
+
+            with ThreadPoolExecutor(len(cuts) - 1) as ex:
+                list(ex.map(chunk, range(len(cuts) - 1)))
+            return x
         for _ in range(self.vcycles):
             self.MGM(self.J, x, b)
         return x

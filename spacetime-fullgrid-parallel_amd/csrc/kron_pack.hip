@@ -1,0 +1,409 @@
+// Kronecker-sum apply on a PACKED sliced-ELL pattern:
+//     y = beta*y + sum_k (T_k kron X_k) x          (all terms read the same x)
+//
+// Same operator as stk_kron_ell_apply (reference source/mpi_kron.py:77-90,
+// 186-201, 214-219), same walk over the rows (persistent workgroups, XCD-
+// interleaved row groups in a mesh-tile order, one lane per pair of time steps,
+// all K gathers of a lane issued back to back, next group's entries prefetched
+// into registers).  What differs is what the kernel streams and how it sees the
+// halo:
+//
+//  * Matrix stream: ONE 32-bit word per slot, `code << col_bits | col`.  `code`
+//    indexes a dictionary of the distinct value tuples (X_0[i,j], X_1[i,j], ..)
+//    of the union pattern, kept in LDS.  P1 matrices on uniformly refined meshes
+//    have a handful of distinct entries (3 tuples for (M_x, A_x) on the square
+//    and the L-shape, 11 on the cube), so the 20 bytes per slot of the plain
+//    form (index + two doubles) shrink to 4: at J_space = 9 the matrix stream of
+//    one apply is 29 MB instead of 146 MB.  The values are the exact doubles, so
+//    results are bit-identical with the plain form.  The host falls back to
+//    stk_kron_ell_apply when the tuples do not fit the code bits (general
+//    unstructured meshes) or a row is longer than K.
+//  * Ghost time rows (a slab with neighbour ranks; the reference's X_loc_bdr[0]
+//    and X_loc_bdr[-1], mpi_vector.py:148-175) arrive interleaved, gh[j] =
+//    (x_lo[j], x_hi[j]), and every row gets ONE extra lane that runs the very
+//    same instruction stream on them (its gathers are 16 bytes like everyone
+//    else's, from `gh + col*16` instead of `x + col*ld*8 + t0*8`): the space
+//    factors of the two ghost steps come out of the same pass over the matrix,
+//    and the time stencil picks them up from LDS like any other step.  No second
+//    kernel, no second pass over the matrices, no read-modify-write of y.
+//    (Lanes that took a different BRANCH for the ghost rows doubled the time of
+//    an earlier version; here the lanes differ only in a base and a stride.)
+//  * Addresses are 64-bit (`base_lane + col * stride_lane`, one v_mad_u64_u32 per
+//    gather), so slabs of 4 GiB and more need no separate instantiation.
+#include <cstring>
+
+#include "stk_common.h"
+
+namespace {
+
+constexpr int BS = 512;
+
+template <int NT>
+struct PackArgs {
+    const uint32_t *slots;   // [M][K]
+    const int32_t *row_ids;  // [M] or NULL
+    const double *dict[NT];  // [n_codes] values of term k's matrix per code
+    const double *tri[NT];   // [3][n_loc] or NULL
+    const double *x;
+    const double *gh;  // [M][2] interleaved ghost steps (t = -1, t = n_loc) or NULL
+    double *y;
+    double beta;
+    int32_t M, n_loc, ld;
+    int32_t any_tri;
+    int32_t P, W, R;         // own lanes per row, lanes per row, rows per group
+    int32_t ngroups, chunk;  // groups in total / per XCD
+    int32_t col_bits, n_codes;
+    int32_t flags;  // bit 0: non-temporal y stores, bit 1: non-temporal slot loads
+};
+
+typedef double stk_v2d __attribute__((ext_vector_type(2)));
+
+__device__ inline double2 load2(const char *p) { return *reinterpret_cast<const double2 *>(p); }
+
+template <int NT, int K, int NPF, bool GHOST>
+__global__ __launch_bounds__(BS, K >= 12 ? 4 : 6) void kron_pack_kernel(const PackArgs<NT> a)
+{
+    constexpr int KS = (K + 3) & ~3;  // LDS stride of a row's slots (16-byte vectors)
+    extern __shared__ double sm[];
+    const int W = a.W, R = a.R, SW = a.n_loc + 3;
+    // slot words first: their rows are read as 16-byte vectors
+    uint32_t *s_slot = reinterpret_cast<uint32_t *>(sm);  // [R][KS]
+    uint32_t *s_row = s_slot + R * KS;                    // [R]
+    const int LT = (a.n_loc + 2) & ~1;
+    double *s_tri = reinterpret_cast<double *>(s_row + ((R + 3) & ~3));  // [NT][3][LT], 16-byte aligned rows
+    double *s_dict = s_tri + NT * 3 * LT;                                // [n_codes][NT]
+    // s_w[k][r][q], q = t + 1: the space-factor results z_k[row][t], t = -1 .. n_loc
+    double *s_w = s_dict + a.n_codes * NT;
+
+    const int tid = threadIdx.x;
+    const int r = tid / W;
+    const int p = tid - r * W;
+    const bool in_row = r < R;
+    const bool ghost_lane = GHOST && p == a.P;
+    const int t0 = 2 * p;  // own lanes: first time step of the pair
+    const bool has1 = t0 + 1 < a.n_loc;
+    // what distinguishes the lanes of a row: where their 16 bytes of a column start
+    const char *base_lane = ghost_lane ? reinterpret_cast<const char *>(a.gh)
+                                       : reinterpret_cast<const char *>(a.x) + (size_t)t0 * 8;
+    const uint32_t stride_lane = ghost_lane ? 16u : (uint32_t)a.ld * 8u;
+    const uint32_t col_mask = (1u << a.col_bits) - 1u;
+    // where a lane leaves its two sums in s_w (index q = t + 1)
+    const int wq0 = ghost_lane ? 0 : t0 + 1;
+    const int wdq = ghost_lane ? a.n_loc + 1 : 1;
+    const bool wr1 = ghost_lane || has1;
+
+    for (int i = tid; i < a.n_codes * NT; i += BS) {
+        const int c = i / NT, k = i - c * NT;
+        s_dict[i] = a.dict[k][c];
+    }
+    if (a.any_tri) {
+        for (int i = tid; i < NT * 3 * LT; i += BS) {
+            const int k = i / (3 * LT), rem = i - k * 3 * LT;
+            const int d = rem / LT, t = rem - d * LT;
+            s_tri[i] = (a.tri[k] != nullptr && t < a.n_loc) ? a.tri[k][d * a.n_loc + t] : 0.0;
+        }
+        if (!GHOST) {  // z[-1] and z[n_loc] of every row: zero, never rewritten
+            for (int i = tid; i < NT * R; i += BS) {
+                s_w[i * SW] = 0.0;
+                s_w[i * SW + a.n_loc + 1] = 0.0;
+            }
+        }
+    }
+
+    // groups of this workgroup: interleaved with the other workgroups of its XCD
+    const int xcd = blockIdx.x & 7;
+    const int step = gridDim.x >> 3;
+    const int gend = min((xcd + 1) * a.chunk, a.ngroups);
+    int g = xcd * a.chunk + (int)(blockIdx.x >> 3);
+
+    uint32_t pslot[NPF];
+    int32_t prow = 0;
+#pragma unroll
+    for (int q = 0; q < NPF; ++q) pslot[q] = 0;
+    auto fetch = [&](int gq) {
+        const int rows = min(R, a.M - gq * R);
+        const uint32_t *src = a.slots + (size_t)gq * R * K;
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) {
+            const int i = tid + q * BS;
+            if (i < rows * K) pslot[q] = (a.flags & 2) ? __builtin_nontemporal_load(src + i) : src[i];
+        }
+        if (tid < rows) prow = a.row_ids ? a.row_ids[gq * R + tid] : gq * R + tid;
+    };
+    if (g < gend) fetch(g);
+
+    for (; g < gend; g += step) {
+        const int rows = min(R, a.M - g * R);
+        // ---- publish this group's entries ----------------------------------
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) {
+            const int i = tid + q * BS;
+            // element i of the group's flat [rows][K] chunk -> LDS [row][KS]
+            if (i < rows * K) s_slot[i + (i / K) * (KS - K)] = pslot[q];
+        }
+        if (tid < rows) s_row[tid] = (uint32_t)prow;
+        __syncthreads();
+        if (g + step < gend) fetch(g + step);  // in flight behind the gathers
+
+        const bool active = in_row && r < rows;
+        // read now: s_row is rewritten at the top of the next iteration, which a
+        // fast wave reaches while a slow one is still storing
+        const uint32_t yrow = active ? s_row[r] : 0u;
+        double acc0[NT], acc1[NT];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) acc0[k] = acc1[k] = 0.0;
+
+        if (active) {
+            int ro = r * KS;
+            double2 xv[K];
+            {
+                uint32_t sl[KS];
+                const uint4 *so = reinterpret_cast<const uint4 *>(s_slot + ro);
+#pragma unroll
+                for (int u = 0; u < KS / 4; ++u) {
+                    const uint4 v = so[u];
+                    sl[4 * u] = v.x, sl[4 * u + 1] = v.y, sl[4 * u + 2] = v.z, sl[4 * u + 3] = v.w;
+                }
+#pragma unroll
+                for (int u = 0; u < K; ++u) xv[u] = load2(base_lane + (size_t)(sl[u] & col_mask) * stride_lane);
+            }
+            // The slot words are read a second time for their codes rather than
+            // kept in registers across the gathers (the offset is made opaque so
+            // that the compiler does not merge the two reads): 8 VGPRs less while
+            // all K loads are in flight.
+            asm volatile("" : "+v"(ro));
+            uint32_t sl[KS];
+            const uint4 *so = reinterpret_cast<const uint4 *>(s_slot + ro);
+#pragma unroll
+            for (int u = 0; u < KS / 4; ++u) {
+                const uint4 v = so[u];
+                sl[4 * u] = v.x, sl[4 * u + 1] = v.y, sl[4 * u + 2] = v.z, sl[4 * u + 3] = v.w;
+            }
+#pragma unroll
+            for (int u = 0; u < K; ++u) {
+                const double *dv = s_dict + (sl[u] >> a.col_bits) * NT;
+                double v[NT];
+                if constexpr (NT == 2) {  // one 16-byte read (s_dict is 16-byte aligned)
+                    const double2 vv = *reinterpret_cast<const double2 *>(dv);
+                    v[0] = vv.x, v[1] = vv.y;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NT; ++k) v[k] = dv[k];
+                }
+#pragma unroll
+                for (int k = 0; k < NT; ++k) {
+                    acc0[k] = fma(v[k], xv[u].x, acc0[k]);
+                    acc1[k] = fma(v[k], xv[u].y, acc1[k]);
+                }
+            }
+        }
+
+        // ---- time stencil through LDS, store ---------------------------------
+        double y0 = 0.0, y1 = 0.0;
+        if (a.any_tri) {
+            if (active) {
+                // own lanes: z[t0], z[t0 + 1]; the ghost lane: z[-1], z[n_loc]
+                double *w = s_w + r * SW + wq0;
+#pragma unroll
+                for (int k = 0; k < NT; ++k, w += R * SW) {
+                    w[0] = acc0[k];
+                    if (wr1) w[wdq] = acc1[k];
+                }
+            }
+            __syncthreads();
+            if (active && !ghost_lane) {
+#pragma unroll
+                for (int k = 0; k < NT; ++k) {
+                    if (a.tri[k] != nullptr) {
+                        const double *w = s_w + (k * R + r) * SW + t0;  // w[q]: z at step t0 - 1 + q
+                        const double *c = s_tri + k * 3 * LT + t0;
+                        const double2 sub = *reinterpret_cast<const double2 *>(c);
+                        const double2 dia = *reinterpret_cast<const double2 *>(c + LT);
+                        const double2 sup = *reinterpret_cast<const double2 *>(c + 2 * LT);
+                        double v0 = dia.x * acc0[k];
+                        v0 = fma(sub.x, w[0], v0);
+                        v0 = fma(sup.x, has1 ? acc1[k] : w[2], v0);
+                        y0 += v0;
+                        if (has1) {
+                            double v1 = dia.y * acc1[k];
+                            v1 = fma(sub.y, acc0[k], v1);
+                            v1 = fma(sup.y, w[3], v1);
+                            y1 += v1;
+                        }
+                    } else {
+                        y0 += acc0[k];
+                        y1 += acc1[k];
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                y0 += acc0[k];
+                y1 += acc1[k];
+            }
+            __syncthreads();  // the LDS entries are rewritten at the top of the loop
+        }
+        if (active && !ghost_lane) {
+            if (!has1) y1 = 0.0;  // padding slot stays zero
+            double2 *dst = reinterpret_cast<double2 *>(reinterpret_cast<char *>(a.y) +
+                                                        (size_t)yrow * ((size_t)a.ld * 8) + (size_t)t0 * 8);
+            if (a.beta != 0.0) {
+                const double2 old = *dst;
+                y0 = fma(a.beta, old.x, y0);
+                if (has1) y1 = fma(a.beta, old.y, y1);
+            }
+            if (a.flags & 1) {
+                stk_v2d out;
+                out.x = y0, out.y = y1;
+                __builtin_nontemporal_store(out, reinterpret_cast<stk_v2d *>(dst));
+            } else {
+                *dst = make_double2(y0, y1);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void interleave_ghosts_kernel(int32_t M, const double *__restrict__ lo,
+                                                                const double *__restrict__ hi,
+                                                                double2 *__restrict__ gh)
+{
+    const int stride = gridDim.x * 256;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < M; j += stride)
+        gh[j] = make_double2(lo ? lo[j] : 0.0, hi ? hi[j] : 0.0);
+}
+
+int g_pack_wg_per_cu = 0;
+int g_pack_flags = 0;
+
+template <int NT, int K, bool GHOST>
+int launch_npf(hipStream_t st, const PackArgs<NT> &a, unsigned grid, size_t lds)
+{
+    const int npf = (a.R * K + BS - 1) / BS;
+    if (npf <= 1)
+        hipLaunchKernelGGL((kron_pack_kernel<NT, K, 1, GHOST>), dim3(grid), dim3(BS), lds, st, a);
+    else if (npf <= 2)
+        hipLaunchKernelGGL((kron_pack_kernel<NT, K, 2, GHOST>), dim3(grid), dim3(BS), lds, st, a);
+    else
+        hipLaunchKernelGGL((kron_pack_kernel<NT, K, 4, GHOST>), dim3(grid), dim3(BS), lds, st, a);
+    STK_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int NT>
+int launch(hipStream_t st, PackArgs<NT> a, int K)
+{
+    const bool ghost = a.gh != nullptr;
+    a.W = a.P + (ghost ? 1 : 0);
+    a.R = BS / a.W;
+    if (a.R * K > 4 * BS) a.R = 4 * BS / K;  // at most 4 prefetched words per thread
+    a.ngroups = (a.M + a.R - 1) / a.R;
+    a.chunk = (a.ngroups + 7) / 8;
+    a.flags = g_pack_flags;
+    const int KS = (K + 3) & ~3;
+    const size_t lds = sizeof(double) * ((a.any_tri ? (size_t)NT * a.R * (a.n_loc + 3) : 0) +
+                                          (size_t)a.n_codes * NT + (size_t)NT * 3 * (a.n_loc + 2)) +
+                       sizeof(uint32_t) * ((size_t)a.R * KS + a.R + 4) + 32;
+    STK_REQUIRE(lds <= 64 * 1024, "stk_kron_pack_apply: %zu bytes of LDS per workgroup (dictionary too large?)", lds);
+    const int n_cu = stk_cu_count();
+    int per_cu = g_pack_wg_per_cu > 0 ? g_pack_wg_per_cu : (K >= 12 ? 2 : 3);
+    const int by_lds = (int)(160 * 1024 / (lds + 256));
+    if (per_cu > by_lds) per_cu = by_lds > 0 ? by_lds : 1;
+    int per_xcd = (n_cu / 8) * per_cu;
+    if (per_xcd > a.chunk) per_xcd = a.chunk;
+    if (per_xcd < 1) per_xcd = 1;
+    const unsigned grid = (unsigned)per_xcd * 8;
+#define STK_PACK_CASE(KK)                                                   \
+    case KK:                                                                \
+        return ghost ? launch_npf<NT, KK, true>(st, a, grid, lds)           \
+                     : launch_npf<NT, KK, false>(st, a, grid, lds);
+    switch (K) {
+        STK_PACK_CASE(5)
+        STK_PACK_CASE(7)
+        STK_PACK_CASE(9)
+        STK_PACK_CASE(12)
+        STK_PACK_CASE(16)
+    }
+#undef STK_PACK_CASE
+    stk_set_error("stk_kron_pack_apply: K=%d is not one of 5, 7, 9, 12, 16", K);
+    return 2;
+}
+
+template <int NT>
+int dispatch(hipStream_t st, const stk_pack_pattern *pat, int32_t n_loc, int32_t ld, const stk_kron_pack_term *t,
+             const double *x, const double *gh, double beta, double *y)
+{
+    PackArgs<NT> a;
+    a.slots = pat->slots;
+    a.row_ids = pat->row_ids;
+    a.x = x;
+    a.gh = gh;
+    a.y = y;
+    a.beta = beta;
+    a.M = pat->M;
+    a.n_loc = n_loc;
+    a.ld = ld;
+    a.col_bits = pat->col_bits;
+    a.n_codes = pat->n_codes;
+    a.any_tri = 0;
+    for (int k = 0; k < NT; ++k) {
+        a.dict[k] = pat->dict + (size_t)t[k].mat * pat->n_codes;
+        a.tri[k] = t[k].tri;
+        if (t[k].tri) a.any_tri = 1;
+    }
+    a.P = (n_loc + 1) / 2;
+    return launch<NT>(st, a, pat->K);
+}
+
+}  // namespace
+
+int stk_kron_pack_set_tuning(const char *key, int32_t value)
+{
+    if (std::strcmp(key, "pack_wg_per_cu") == 0) {
+        g_pack_wg_per_cu = value;
+        return 0;
+    }
+    if (std::strcmp(key, "pack_flags") == 0) {
+        g_pack_flags = value;
+        return 0;
+    }
+    return 1;
+}
+
+extern "C" int stk_kron_pack_apply(void *stream, const stk_pack_pattern *pat, int32_t n_loc, int32_t ld,
+                                   int32_t n_terms, const stk_kron_pack_term *t, const double *x,
+                                   const double *ghosts, double beta, double *y)
+{
+    STK_REQUIRE(pat && t && x && y, "stk_kron_pack_apply: null pointer");
+    STK_REQUIRE(pat->M > 0 && pat->K >= 1 && pat->slots && pat->dict, "stk_kron_pack_apply: bad pattern");
+    STK_REQUIRE(pat->col_bits >= 1 && pat->col_bits <= 31 && ((int64_t)1 << pat->col_bits) >= pat->M,
+                "stk_kron_pack_apply: col_bits=%d cannot address %d columns", pat->col_bits, pat->M);
+    STK_REQUIRE(pat->n_codes >= 1 && (int64_t)pat->n_codes <= ((int64_t)1 << (32 - pat->col_bits)),
+                "stk_kron_pack_apply: %d codes do not fit %d bits", pat->n_codes, 32 - pat->col_bits);
+    STK_REQUIRE(n_loc > 0 && ld >= n_loc && (ld & 1) == 0,
+                "stk_kron_pack_apply: bad sizes n_loc=%d ld=%d (ld must be even)", n_loc, ld);
+    STK_REQUIRE(n_terms >= 1 && n_terms <= 3, "stk_kron_pack_apply: n_terms=%d not in 1..3", n_terms);
+    STK_REQUIRE((n_loc + 1) / 2 + 2 <= BS, "stk_kron_pack_apply: n_loc=%d too large", n_loc);
+    STK_REQUIRE(x != y, "stk_kron_pack_apply: input aliases output");
+    STK_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)ghosts) & 15) == 0,
+                "stk_kron_pack_apply: x, y and ghosts must be 16-byte aligned");
+    for (int k = 0; k < n_terms; ++k)
+        STK_REQUIRE(t[k].mat >= 0 && t[k].mat < pat->n_mats, "stk_kron_pack_apply: term %d names matrix %d of %d", k,
+                    t[k].mat, pat->n_mats);
+    hipStream_t st = stk_stream(stream);
+    switch (n_terms) {
+        case 1: return dispatch<1>(st, pat, n_loc, ld, t, x, ghosts, beta, y);
+        case 2: return dispatch<2>(st, pat, n_loc, ld, t, x, ghosts, beta, y);
+        default: return dispatch<3>(st, pat, n_loc, ld, t, x, ghosts, beta, y);
+    }
+}
+
+extern "C" int stk_interleave_ghosts(void *stream, int32_t M, const double *lo, const double *hi, double *ghosts)
+{
+    STK_REQUIRE(M > 0 && ghosts, "stk_interleave_ghosts: bad arguments");
+    STK_REQUIRE(((uintptr_t)ghosts & 15) == 0, "stk_interleave_ghosts: ghosts must be 16-byte aligned");
+    hipLaunchKernelGGL(interleave_ghosts_kernel, dim3(stk_flat_grid(M, 256)), dim3(256), 0, stk_stream(stream), M, lo,
+                       hi, reinterpret_cast<double2 *>(ghosts));
+    STK_LAUNCH_CHECK();
+    return 0;
+}

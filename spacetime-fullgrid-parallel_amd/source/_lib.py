@@ -40,6 +40,16 @@ class KronEllTerm(ctypes.Structure):
                 ('x', c_p), ('x_lo', c_p), ('x_hi', c_p)]
 
 
+class PackPattern(ctypes.Structure):
+    _fields_ = [('M', c_i32), ('K', c_i32), ('col_bits', c_i32),
+                ('n_codes', c_i32), ('n_mats', c_i32), ('slots', c_p),
+                ('row_ids', c_p), ('dict', c_p)]
+
+
+class KronPackTerm(ctypes.Structure):
+    _fields_ = [('tri', c_p), ('mat', c_i32)]
+
+
 class EllRows(ctypes.Structure):
     _fields_ = [('n_pos', c_i32), ('n_rows', c_i32), ('K', c_i32),
                 ('idx', c_p), ('va', c_p), ('vm', c_p), ('row_ids', c_p),
@@ -92,6 +102,11 @@ _PROTOTYPES = {
         c_p, ctypes.POINTER(EllPattern), c_i32, c_i32, c_i32,
         ctypes.POINTER(KronEllTerm), c_p
     ]),
+    'stk_kron_pack_apply': (ctypes.c_int, [
+        c_p, ctypes.POINTER(PackPattern), c_i32, c_i32, c_i32,
+        ctypes.POINTER(KronPackTerm), c_p, c_p, c_f64, c_p
+    ]),
+    'stk_interleave_ghosts': (ctypes.c_int, [c_p, c_i32, c_p, c_p, c_p]),
     'stk_ell_spmm': (ctypes.c_int, [
         c_p, ctypes.POINTER(EllRows), c_i32, c_i32, c_i32, c_f64, c_p, c_p,
         c_f64, c_f64, c_p, c_p

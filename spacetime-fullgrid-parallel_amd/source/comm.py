@@ -19,7 +19,12 @@ import torch.distributed as dist
 
 class Comm:
     """Communicator over a torch.distributed process group (None = a single
-    process without torch.distributed)."""
+    process without torch.distributed).
+
+    A one-rank group normally short-cuts every collective.  With
+    STK_FORCE_COLLECTIVES=1 it does not: the scalar all-reduce, barrier and
+    object broadcast / gather then run on the backend (RCCL) even at world size
+    1 -- the transport can be executed on a one-GPU box."""
     def __init__(self, group=None, distributed=None):
         self.group = group
         self.distributed = dist.is_initialized() if distributed is None else distributed
@@ -28,6 +33,8 @@ class Comm:
             self.size = dist.get_world_size(group)
         else:
             self.rank, self.size = 0, 1
+        self.collective = self.size > 1 or (
+            self.distributed and os.environ.get('STK_FORCE_COLLECTIVES') == '1')
 
     def Get_rank(self):
         return self.rank
@@ -38,7 +45,7 @@ class Comm:
     # -- collectives ---------------------------------------------------------
     def allreduce(self, value):
         """Sum of a Python float over the ranks (reference mpi_vector.py:209)."""
-        if self.size == 1:
+        if not self.collective:
             return value
         t = torch.tensor([value], dtype=torch.float64, device=self._device())
         dist.all_reduce(t, group=self.group)
@@ -47,7 +54,7 @@ class Comm:
     def allreduce_tensor_(self, t):
         """In-place sum of a small tensor that already lives on the compute
         device (keeps the dot result on the GPU until the single D2H read)."""
-        if self.size > 1:
+        if self.collective:
             if t.is_cuda and self._device().type == 'cpu':
                 host = t.cpu()  # gloo: stage through the host
                 dist.all_reduce(host, group=self.group)
@@ -57,14 +64,14 @@ class Comm:
         return t
 
     def bcast(self, obj, root=0):
-        if self.size == 1:
+        if not self.collective:
             return obj
         box = [obj]
         dist.broadcast_object_list(box, src=root, group=self.group)
         return box[0]
 
     def gather(self, obj, root=0):
-        if self.size == 1:
+        if not self.collective:
             return [obj]
         out = [None] * self.size if self.rank == root else None
         dist.gather_object(obj, out, dst=root, group=self.group)
@@ -73,7 +80,7 @@ class Comm:
     def Barrier(self):
         if torch.cuda.is_available():
             torch.cuda.synchronize()
-        if self.size > 1:
+        if self.collective:
             dist.barrier(group=self.group)
 
     # -- point to point --------------------------------------------------------
@@ -136,7 +143,8 @@ def init_from_env():
         # several ranks may share one GPU in tests (STK_BACKEND=gloo)
         torch.cuda.set_device(
             int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count())
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get('STK_FORCE_COLLECTIVES') == '1' and 'RANK' in os.environ
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         backend = os.environ.get(

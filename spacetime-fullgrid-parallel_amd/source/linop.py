@@ -325,6 +325,8 @@ class EllMatrices:
                                        _lib.ptr(self.row_ids),
                                        _lib.ptr(self.ovf_indptr),
                                        _lib.ptr(self.ovf_indices))
+        self.packed = PackedEllMatrices(M, K, ell_idx, ell_vals, self.row_ids,
+                                        not main.all())
 
     def _terms(self, specs, ghosts):
         terms = (_lib.KronEllTerm * len(specs))()
@@ -356,6 +358,58 @@ class EllMatrices:
             _lib.check(_lib.lib().stk_kron_ell_ghost_apply(
                 _lib.stream(), ctypes.byref(self.pattern), n_loc, ld,
                 len(specs), self._terms(specs, True), _lib.ptr(out)))
+
+
+class PackedEllMatrices:
+    """The matrices of an EllMatrices plan in the packed form of
+    ``stk_kron_pack_apply`` (include/stk.h): one 32-bit word per slot,
+    ``code << col_bits | column``, plus the dictionary of the distinct value
+    tuples of the union pattern.  ``ok`` is False when the plan does not fit
+    (overflow rows, or more distinct tuples than the free bits can name); the
+    caller then keeps the plain form."""
+    def __init__(self, M, K, ell_idx, ell_vals, row_ids, has_overflow):
+        self.ok = False
+        if has_overflow or M < 1:
+            return
+        col_bits = max(1, int(M - 1).bit_length())
+        # distinct value tuples, by bit pattern (+0.0 and -0.0 stay distinct):
+        # one 1-D unique per matrix, then one over the combined codes
+        codes, table = np.zeros(M * K, dtype=np.int64), None
+        for e in ell_vals:
+            u, inv = np.unique(e.reshape(-1).view(np.int64), return_inverse=True)
+            if len(u) > 2048:
+                return
+            uc, codes = np.unique(codes * len(u) + inv, return_inverse=True)
+            if len(uc) > 2048:
+                return
+            col = u[uc % len(u)][:, None]
+            table = col if table is None else np.hstack(
+                [table[uc // len(u)], col])
+        uniq = table
+        if len(uniq) > (1 << (32 - col_bits)):
+            return
+        self.ok = True
+        self.M, self.K, self.col_bits, self.n_codes = M, K, col_bits, len(uniq)
+        slots = (codes.reshape(-1).astype(np.uint32) << np.uint32(col_bits)
+                 ) | ell_idx.reshape(-1).astype(np.uint32)
+        self.slots = _lib.to_dev(slots.view(np.int32).reshape(M, K))
+        # dict[m][code]
+        self.dict = _lib.to_dev(
+            np.ascontiguousarray(uniq.view(np.float64).T.copy()))
+        self.row_ids = row_ids
+        self.pattern = _lib.PackPattern(M, K, col_bits, self.n_codes,
+                                        len(ell_vals), _lib.ptr(self.slots),
+                                        _lib.ptr(row_ids), _lib.ptr(self.dict))
+
+    def apply(self, specs, x, ghosts, n_loc, ld, beta, out):
+        """y = beta*y + sum over specs (tri, matrix index) applied to x;
+        `ghosts`: (M, 2) interleaved ghost time steps or None."""
+        terms = (_lib.KronPackTerm * len(specs))()
+        for t, (tri, k) in zip(terms, specs):
+            t.tri, t.mat = _lib.ptr(tri), k
+        _lib.check(_lib.lib().stk_kron_pack_apply(
+            _lib.stream(), ctypes.byref(self.pattern), n_loc, ld, len(specs),
+            terms, _lib.ptr(x), _lib.ptr(ghosts), beta, _lib.ptr(out)))
 
 
 # ----------------------------------------------------------------------------

@@ -370,6 +370,7 @@ class _FusedKronSum:
     with plain CSR space factors: shared pattern, one launch.  use_ell selects
     the persistent sliced-ELL kernel (default) or the plain CSR one."""
     use_ell = True
+    use_pack = True  # packed matrix stream + fused ghost steps when the plan fits
 
     @classmethod
     def max_terms(cls):
@@ -404,6 +405,17 @@ class _FusedKronSum:
 
     def apply(self, vec_in, vec_out, beta=0.0):
         time_comm = 0.0
+        if self.use_ell and type(self).use_pack and self.ell.packed.ok:
+            # one pass: matrix stream packed, ghost time steps handled by an extra
+            # lane per row (csrc/kron_pack.hip); the halo has to be there first
+            ghosts = None
+            if self.dofs_distr.size > 1 and (self.needs_lo or self.needs_hi):
+                time_comm = vec_in.communicate_bdr()
+                ghosts = vec_in.ghost_interleaved()
+            self.ell.packed.apply([(self.tri[k], k) for k in range(self.n_terms)],
+                                  vec_in.buf, ghosts, vec_in.n_loc, vec_in.ld,
+                                  beta, vec_out.buf)
+            return time_comm
         if self.use_ell:
             # the slab-local part runs while the halo exchange is in flight
             # (the reference overlaps the interior rows, mpi_kron.py:193-196)

@@ -98,7 +98,7 @@ class KronVectorMPI:
     def reset(self, initial_data=None):
         self.communicated_bdr = False
         # ghost time rows (the reference's X_loc_bdr[0] and X_loc_bdr[-1])
-        self.X_lo = self.X_hi = self._ghost = None
+        self.X_lo = self.X_hi = self._ghost = self._ghost_il = None
         self._notify_pending()
         dev = _lib.compute_device()
         if initial_data is None:
@@ -120,7 +120,7 @@ class KronVectorMPI:
         cpy.__dict__.update(self.__dict__)
         cpy._pending = None
         cpy.communicated_bdr = False
-        cpy.X_lo = cpy.X_hi = cpy._ghost = None
+        cpy.X_lo = cpy.X_hi = cpy._ghost = cpy._ghost_il = None
         cpy._buf = self.buf.clone()
         return cpy
 
@@ -129,7 +129,7 @@ class KronVectorMPI:
         out.__dict__.update(self.__dict__)
         out._pending = None
         out.communicated_bdr = False
-        out.X_lo = out.X_hi = out._ghost = None
+        out.X_lo = out.X_hi = out._ghost = out._ghost_il = None
         out._buf = torch.empty_like(self.buf)
         return out
 
@@ -310,11 +310,28 @@ class KronVectorMPI:
         comm.wait_all(reqs)
         time_communication = MPI.Wtime() - start_time
         self.communicated_bdr = True
+        self._ghost_il_stale = True
         return time_communication
 
     def ghost_pair(self):
         """(2, M) buffer [X_lo; X_hi] filled by communicate_bdr."""
         return self._ghost
+
+    def ghost_interleaved(self):
+        """(M, 2) buffer with row j = (X_lo[j], X_hi[j]) -- the layout in which
+        stk_kron_pack_apply gathers both ghost time steps with one 16-byte
+        load; a side without a neighbour is zero.  Valid after
+        communicate_bdr, rebuilt when the halo is."""
+        assert self.communicated_bdr
+        if getattr(self, '_ghost_il', None) is None or self._ghost_il_stale:
+            if getattr(self, '_ghost_il', None) is None:
+                self._ghost_il = torch.empty((self.M, 2), dtype=torch.float64,
+                                             device=self.buf.device)
+            _lib.check(_lib.lib().stk_interleave_ghosts(
+                _lib.stream(), self.M, _lib.ptr(self.X_lo), _lib.ptr(self.X_hi),
+                _lib.ptr(self._ghost_il)))
+            self._ghost_il_stale = False
+        return self._ghost_il
 
     def communicate_dofs(self, comm_dofs):
         """Fetches arbitrary remote time rows.  `comm_dofs` = (local row,

@@ -1,11 +1,20 @@
 #!/usr/bin/env python3
-"""Mid-size PCG trajectory from the CPU ORACLE (not the reference: the
-reference's pure-Python smoother would need hours at this size).  The oracle
-is pinned to the reference by tests/test_oracle_golden.py; this fixture extends
-the GPU parity check to N = 33, M = 16 129.
+"""PCG trajectories of the CPU ORACLE at the sizes of the BASELINE configs
+(not from the reference: its pure-Python smoother would need days at these
+sizes, and NGSolve is absent).  The oracle is pinned to the reference by
+tests/test_oracle_golden.py; these fixtures extend the GPU parity check of the
+whole solve -- iteration count, r.Pr history, sampled solution, as the
+reference's integration test compares them (heateq_mpi_test.py:138-189) -- to
+full size.
 
-    python tests/golden/make_oracle_vectors.py
+    python tests/golden/make_oracle_vectors.py --J_time 5 --J_space 8
+    python tests/golden/make_oracle_vectors.py --J_time 6 --J_space 9 --threads 7
+    python tests/golden/make_oracle_vectors.py --J_time 5 --J_space 8 --problem lshape
+
+Time slices are independent in every space operator, so --threads only cuts
+batches of slices into chunks; the numbers do not depend on it.
 """
+import argparse
 import os
 import sys
 import time
@@ -17,6 +26,7 @@ REPO = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, 'spacetime-fullgrid-parallel_amd'))
 
+from oracle import multigrid as omg  # noqa: E402
 from oracle.heat import HeatEquationOracle  # noqa: E402
 from oracle.krylov import pcg  # noqa: E402
 from source.assembly import (prolongation_matrices, space_load,  # noqa: E402
@@ -24,25 +34,60 @@ from source.assembly import (prolongation_matrices, space_load,  # noqa: E402
 from source.problem import problem_helper  # noqa: E402
 
 
-def main():
-    J_time, J_space = 5, 6
-    mesh, _, tmesh, data, _ = problem_helper('square', J_space, J_time)
+def fixture_name(problem, J_time, J_space):
+    return 'o1_pcg_%s_J%d_J%d.npz' % (problem, J_time, J_space)
+
+
+def sample_strides(N, M):
+    """Sub-sampling of an (N, M) array kept in the fixture: about 8 time rows
+    by about 200 space dofs (always including row 0 and the last row)."""
+    return max(1, (N - 1) // 8), max(1, M // 199)
+
+
+def build_oracle(problem, J_time, J_space):
+    mesh, _, tmesh, data, _ = problem_helper(problem, J_space, J_time)
     A_t, L_t, M_t, G_t, u0_t = time_matrices(tmesh)
     M_x, A_x = space_matrices(mesh)
     mats = dict(A_t=A_t, L_t=L_t, M_t=M_t, G_t=G_t, M_x=M_x, A_x=A_x,
                 P_mats=prolongation_matrices(mesh), u0_t=u0_t,
                 u0_x=space_load(mesh, data['u0']))
-    o = HeatEquationOracle(mats, J_time)
+    return HeatEquationOracle(mats, J_time)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--J_time', type=int, default=5)
+    ap.add_argument('--J_space', type=int, default=6)
+    ap.add_argument('--problem', default='square')
+    ap.add_argument('--threads', type=int, default=1)
+    ap.add_argument('--kmax', type=int, default=100000)
+    ap.add_argument('--no-ops', action='store_true',
+                    help='skip the S(X), P(X) samples (memory at the largest sizes)')
+    args = ap.parse_args()
+    omg.THREADS = args.threads
+    o = build_oracle(args.problem, args.J_time, args.J_space)
     t0 = time.time()
-    w, iters, hist = pcg(o.WT_S_W, o.P, o.rhs())
+
+    def cb(w, r, k):
+        print('  iteration %d  (%.0f s)' % (k, time.time() - t0), flush=True)
+
+    w, iters, hist = pcg(o.WT_S_W, o.P, o.rhs(), kmax=args.kmax, callback=cb)
     print('oracle PCG: %d iterations in %.1f s' % (iters, time.time() - t0))
-    X = np.random.RandomState(128).rand(o.N, o.M)
-    np.savez_compressed(os.path.join(HERE, 'o1_pcg_J5_J6.npz'), J_time=J_time,
-                        J_space=J_space, iters=iters, hist=np.array(hist),
-                        w_norm=np.linalg.norm(w),
-                        w_sample=w[::4, ::97].copy(),
-                        SX_sample=o.S(X)[::4, ::97].copy(),
-                        PX_sample=o.P(X)[::4, ::97].copy())
+    st, sx = sample_strides(o.N, o.M)
+    out = dict(J_time=args.J_time, J_space=args.J_space, problem=args.problem,
+               iters=iters, kmax=args.kmax, hist=np.array(hist),
+               w_norm=np.linalg.norm(w), w_sample=w[::st, ::sx].copy(),
+               sample_strides=np.array([st, sx]))
+    if not args.no_ops:
+        X = np.empty((o.N, o.M))
+        for t in range(o.N):  # the bench's vector: one seeded row per time step
+            X[t] = np.random.RandomState(128 + t).rand(o.M)
+        out['SX_sample'] = o.S(X)[::st, ::sx].copy()
+        out['PX_sample'] = o.P(X)[::st, ::sx].copy()
+        out['WX_sample'] = o.W(X)[::st, ::sx].copy()
+    np.savez_compressed(
+        os.path.join(HERE, fixture_name(args.problem, args.J_time, args.J_space)),
+        **out)
 
 
 if __name__ == '__main__':

@@ -52,9 +52,41 @@ def test_distributed_solve_ranks_sharing_one_gpu(nproc, problem):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('nproc', [2, 3])
-def test_reference_unit_tests_on_several_ranks(nproc):
-    """The reference runs its unit tests under mpirun; the mirrored suite
-    (test_reference_suite.py) likewise on 2 and 3 ranks sharing the GPU."""
-    out = _run('mp_refsuite_worker.py', nproc, {'STK_BACKEND': 'gloo'})
-    assert 'mp_refsuite_worker ok' in out
+@pytest.mark.parametrize('nproc', [1, 2, 3])
+def test_every_operator_class_on_several_ranks(nproc):
+    """Every operator class and the vector algebra against dense NumPy ground
+    truth on 1, 2 and 3 ranks sharing the GPU (the reference runs its unit
+    tests under mpirun the same way)."""
+    out = _run('mp_ops_worker.py', nproc, {'STK_BACKEND': 'gloo'})
+    assert 'mp_ops_worker ok' in out
+
+
+@pytest.mark.gpu
+def test_rccl_backend_executes_on_one_rank():
+    """The shipped transport (backend nccl = RCCL) initialised and used for real
+    on the one GPU of the test box: see mp_nccl_worker.py for what that can and
+    cannot show."""
+    out = _run('mp_nccl_worker.py', 1, {'STK_BACKEND': 'nccl',
+                                        'STK_FORCE_COLLECTIVES': '1'})
+    assert 'mp_nccl_worker ok' in out
+
+
+@pytest.mark.gpu
+def test_bench_runs_on_rccl_group_of_one():
+    """bench.py itself (kron steps + a short solve) through the RCCL-backed
+    communicator, launched as the driver launches it."""
+    import json
+    env = dict(os.environ, STK_BACKEND='nccl', STK_FORCE_COLLECTIVES='1',
+               OMP_NUM_THREADS='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()),
+           os.path.join(os.path.dirname(HERE), 'bench.py'), '--gpus', '1',
+           '--steps', '2', '--warmup', '1', '--J_time', '4', '--J_space', '5',
+           '--solve-iters', '2', '--no-cpu-baseline', '--preheat', '0']
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith('{')][-1]
+    rec = json.loads(line)
+    assert rec['n_gpus'] == 1 and rec['value'] > 0 and rec['pcg']['iters_timed'] >= 1

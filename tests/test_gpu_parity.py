@@ -805,6 +805,94 @@ def test_kron_ell_randomised_shapes(stk):
             assert float(y[:, n_loc:].abs().max()) == 0.0  # padding stays zero
 
 
+def test_kron_pack_randomised_shapes(stk):
+    """stk_kron_pack_apply (packed slot stream, dictionary of value tuples,
+    ghost time steps fused) on random matrices whose entries come from a small
+    set of values: against dense NumPy, and bit for bit against the plain ELL
+    form (stk_kron_ell_apply + stk_kron_ell_ghost_apply) on the same inputs.
+    Slab lengths 1..40 walk through the lanes-per-row / rows-per-group / NPF
+    instances; matrices with too many distinct values must be refused by the
+    planner (it keeps the plain form)."""
+    from source.linop import EllMatrices
+    rng = np.random.RandomState(77)
+    for case in range(40):
+        M = int(rng.randint(3, 600))
+        n_loc = int(rng.choice([1, 2, 3, 8, 9, 16, 17, 33, 40]))
+        ld = n_loc + (n_loc & 1)
+        nt = int(rng.randint(1, 4))
+        width = int(rng.choice([3, 6, 9, 14]))
+        base = sp.random(M, M, density=min(1.0, width / M), random_state=rng,
+                         format='csr')
+        base = sp.csr_matrix(base + sp.eye(M))
+        palette = rng.randn(int(rng.randint(1, 9)))
+        mats = []
+        for k in range(nt):
+            m = base.copy()
+            m.data = palette[rng.randint(len(palette), size=m.nnz)]
+            mats.append(m)
+        ell = EllMatrices(mats)
+        if ell.ovf_indptr is not None:
+            assert not ell.packed.ok
+            continue
+        assert ell.packed.ok and ell.packed.n_codes <= len(palette)**nt + 1
+        X = rng.rand(M, n_loc)
+        lo = rng.rand(M) if rng.randint(2) else None
+        hi = rng.rand(M) if rng.randint(2) else None
+        beta = float(rng.choice([0.0, 0.5]))
+        y0 = rng.rand(M, n_loc)
+        want, tris = beta * y0, []
+        for k in range(nt):
+            if rng.randint(4) == 0:
+                tri, T, sub0, sup1 = None, np.eye(n_loc), 0.0, 0.0
+            else:
+                t = rng.rand(3, n_loc)
+                T = np.diag(t[1]) + np.diag(t[0, 1:], -1) + np.diag(t[2, :-1], 1)
+                tri, sub0, sup1 = _lib_dev(t), t[0, 0], t[2, -1]
+            want = want + (mats[k] @ X) @ T.T
+            if tri is not None and lo is not None:
+                want[:, 0] += sub0 * (mats[k] @ lo)
+            if tri is not None and hi is not None:
+                want[:, -1] += sup1 * (mats[k] @ hi)
+            tris.append(tri)
+
+        def slab(a):
+            s_ = torch.zeros((M, ld), dtype=torch.float64, device='cuda')
+            s_[:, :n_loc] = torch.from_numpy(a).cuda()
+            return s_
+
+        x = slab(X)
+        glo = None if lo is None else torch.from_numpy(lo).cuda()
+        ghi = None if hi is None else torch.from_numpy(hi).cuda()
+        gh = None
+        if glo is not None or ghi is not None:
+            gh = torch.empty((M, 2), dtype=torch.float64, device='cuda')
+            stk.check(stk.lib().stk_interleave_ghosts(
+                stk.stream(), M, stk.ptr(glo), stk.ptr(ghi), stk.ptr(gh)))
+            z = torch.zeros(M, dtype=torch.float64, device='cuda')
+            assert torch.equal(gh[:, 0], z if glo is None else glo)
+            assert torch.equal(gh[:, 1], z if ghi is None else ghi)
+        y = slab(y0)
+        ell.packed.apply([(tris[k], k) for k in range(nt)], x, gh, n_loc, ld,
+                         beta, y)
+        got = y[:, :n_loc].cpu().numpy()
+        assert relerr(got, want) < 1e-13, (case, M, n_loc, nt, width)
+        if ld > n_loc:
+            assert float(y[:, n_loc:].abs().max()) == 0.0  # padding stays zero
+        y_plain = slab(y0)
+        ell.apply([(tris[k], k, x, glo, ghi) for k in range(nt)], n_loc, ld,
+                  beta, y_plain)
+        if glo is None and ghi is None:  # same arithmetic in the same order
+            assert torch.equal(y, y_plain), (case, M, n_loc, nt)
+        else:  # the plain form adds the ghost terms in a second kernel
+            assert relerr(got, y_plain[:, :n_loc].cpu().numpy()) < 1e-14
+    # too many distinct values: the planner keeps the plain form
+    m = sp.random(300, 300, density=0.02, random_state=rng, format='csr')
+    m = sp.csr_matrix(m + sp.eye(300))
+    m.data = rng.rand(m.nnz)
+    e = EllMatrices([m])
+    assert e.ovf_indptr is not None or not e.packed.ok or e.packed.n_codes <= 2048
+
+
 def test_row_engine_randomised_shapes(stk):
     """stk_ell_spmm on random rectangular matrices: y = alpha (ca A + cm[t] M) x
     + beta z for every slot count, with and without the second value array,

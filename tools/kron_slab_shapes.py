@@ -22,6 +22,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--J_space', type=int, default=9)
 ap.add_argument('--shapes', default='65:0:0,33:0:1,32:1:0,17:1:1,16:1:1,9:1:1,8:1:1')
 ap.add_argument('--tune', default='')  # key=value,...
+ap.add_argument('--flags', default='0,1,2,3')  # pack_flags values to time
 args = ap.parse_args()
 for kv in filter(None, args.tune.split(',')):
     k, v = kv.split('=')
@@ -59,6 +60,22 @@ for shape in args.shapes.split(','):
     ms_local = timed(lambda: ell.apply_local(specs, n_loc, ld, 0.0, y))
     ms_ghost = timed(lambda: ell.apply_ghost(specs, n_loc, ld, y))
     nbytes = 16 * n_loc * M + 8 * (lo + hi) * M + 12 * (M_x.nnz + A_x.nnz) + 8 * (M + 1)
-    print('n_loc=%2d ghosts=%d%d  %.3f ms (local %.3f + ghost rows %.3f)  %.0f GB/s algorithmic (%.1f%% of 8 TB/s)  -> x%d ranks: %.2f TB/s aggregate'
-          % (n_loc, lo, hi, ms, ms_local, ms_ghost, nbytes / ms / 1e6, nbytes / ms / 1e6 / 80, round(65 / n_loc),
-             round(65 / n_loc) * nbytes / ms / 1e9))
+    print('n_loc=%2d ghosts=%d%d  plain: %.3f ms (local %.3f + ghost rows %.3f)  %.0f GB/s algorithmic (%.1f%% of 8 TB/s)'
+          % (n_loc, lo, hi, ms, ms_local, ms_ghost, nbytes / ms / 1e6, nbytes / ms / 1e6 / 80))
+    # packed form: matrix stream 4 bytes per slot, ghost steps fused
+    gh = None
+    if lo or hi:
+        gh = torch.empty((M, 2), dtype=torch.float64, device='cuda')
+        _lib.check(_lib.lib().stk_interleave_ghosts(
+            _lib.stream(), M, _lib.ptr(g[0] if lo else None), _lib.ptr(g[1] if hi else None), _lib.ptr(gh)))
+    y2 = torch.empty_like(x)
+    pspecs = [(tri[0], 0), (tri[1], 1)]
+    for flags in [int(v) for v in args.flags.split(',')]:
+        _lib.check(_lib.lib().stk_set_tuning(b'pack_flags', flags))
+        msp = timed(lambda: ell.packed.apply(pspecs, x, gh, n_loc, ld, 0.0, y2))
+        ell.apply(specs, n_loc, ld, 0.0, y)
+        err = float((y2 - y).abs().max())
+        print('                     packed flags=%d: %.3f ms  %.0f GB/s algorithmic (%.1f%% of 8 TB/s)  max|diff to plain| %.1e  -> x%d ranks: %.2f TB/s aggregate'
+              % (flags, msp, nbytes / msp / 1e6, nbytes / msp / 1e6 / 80, err, round(65 / n_loc),
+                 round(65 / n_loc) * nbytes / msp / 1e9))
+    _lib.check(_lib.lib().stk_set_tuning(b'pack_flags', 0))

@@ -1,0 +1,30 @@
+#!/bin/bash
+# One rocprofv3 --pmc pass per counter group over a target command; per-kernel
+# sums and averages by tools/pmc_summary.py.  The program itself follows `--`
+# (python3 ...), never a wrapper.
+# usage: tools/pmc_passes.sh <tag> <groups: kron|gs|all> python3 <script> [args]
+set -e
+tag=$1; which=$2; shift 2
+out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+groups=(
+  "FETCH_SIZE"
+  "WRITE_SIZE"
+  "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum"
+  "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum"
+  "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_WRITE_sum TCC_EA0_RDREQ_DRAM_sum"
+  "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS"
+  "SQ_INSTS_VMEM_WR SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM_RD"
+  "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum"
+  "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TA_BUFFER_READ_WAVEFRONTS_sum"
+  "GRBM_GUI_ACTIVE"
+)
+[ "$which" = "gs" ] && groups=("${groups[@]:0:6}" "${groups[@]:9:1}")
+i=0
+for grp in "${groups[@]}"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/p$i -- "$@" > $out/p$i.log 2>&1 || { tail -5 $out/p$i.log; echo "group failed: $grp"; }
+  echo "pass $i done: $grp"
+done
+python3 tools/pmc_summary.py $out > $out/summary.txt
