@@ -188,6 +188,12 @@ int stk_kron_pack_apply(void *stream, const stk_pack_pattern *pattern_host,
                         const stk_kron_pack_term *terms_host, const double *x,
                         const double *ghosts, double beta, double *y);
 
+/* Diagnostic: while `buf` (device, at least 8 * grid * 4 words) is non-NULL,
+ * the headline instantiation (2 terms, K = 7, no ghosts) runs a stamped build
+ * that leaves, per wavefront, the shader-clock cycles spent in the four
+ * segments of a row-group iteration.  NULL switches it off. */
+int stk_kron_pack_set_diag(unsigned long long *buf);
+
 /* ghosts[2*j] = lo[j], ghosts[2*j + 1] = hi[j] (a NULL side is written as
  * zero): brings the two received time rows into the layout above. */
 int stk_interleave_ghosts(void *stream, int32_t M, const double *lo,

@@ -22,7 +22,7 @@ int stk_kron_ell_set_tuning(const char *key, int32_t value);  // kron_ell.hip
 int stk_kron_pack_set_tuning(const char *key, int32_t value);  // kron_pack.hip
 int stk_rows_ell_set_tuning(const char *key, int32_t value);  // rows_ell.hip
 int stk_wavelet_set_tuning(const char *key, int32_t value);   // wavelet.hip
-extern int g_mg_fuse_coarse, g_mg_coarse_max_rows, g_mg_fuse_restrict, g_mg_zero_start, g_mg_strip_mb;  // mg.hip
+extern int g_mg_fuse_coarse, g_mg_coarse_max_rows, g_mg_fuse_restrict, g_mg_zero_start, g_mg_strip_mb, g_mg_strips_used, g_mg_strip_width;  // mg.hip
 extern int g_mg_coarse_pairs, g_mg_coarse_lds;                // mg_coarse.hip
 
 namespace {
@@ -412,6 +412,18 @@ extern "C" int stk_set_tuning(const char *key, int32_t value)
     if (stk_wavelet_set_tuning(key, value) == 0) return 0;
     if (std::strcmp(key, "mg_strip_mb") == 0) {
         g_mg_strip_mb = value;
+        return 0;
+    }
+    if (std::strcmp(key, "mg_strip_width") == 0) {
+        g_mg_strip_width = value;
+        return 0;
+    }
+    if (std::strcmp(key, "mg_strips_used") == 0) {  // tests: reset (0) / require at least `value` strip launches
+        if (value > 0 && g_mg_strips_used < value) {
+            stk_set_error("mg_strips_used: %d strip launches so far, %d required", g_mg_strips_used, value);
+            return 2;
+        }
+        if (value == 0) g_mg_strips_used = 0;
         return 0;
     }
     if (std::strcmp(key, "mg_zero_start") == 0) {

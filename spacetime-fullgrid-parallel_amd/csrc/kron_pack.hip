@@ -36,8 +36,6 @@
 
 namespace {
 
-constexpr int BS = 512;
-
 template <int NT>
 struct PackArgs {
     const uint32_t *slots;   // [M][K]
@@ -54,13 +52,30 @@ struct PackArgs {
     int32_t ngroups, chunk;  // groups in total / per XCD
     int32_t col_bits, n_codes;
     int32_t flags;  // bit 0: non-temporal y stores, bit 1: non-temporal slot loads
+    unsigned long long *diag;  // DIAG instantiation: [waves][4] cycle sums
 };
 
 typedef double stk_v2d __attribute__((ext_vector_type(2)));
 
 __device__ inline double2 load2(const char *p) { return *reinterpret_cast<const double2 *>(p); }
 
-template <int NT, int K, int NPF, bool GHOST>
+// One stamp of the shader clock, ordered against the instruction stream (diagnostic
+// builds only; see the DIAG parameter below).
+__device__ inline unsigned long long stamp()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+
+// DIAG = true is a separate diagnostic instantiation (tools/kron_phases.py): every
+// wave sums the shader-clock cycles it spends in the four segments of an
+// iteration -- publish + barrier, gathers + space factors, exchange + barrier,
+// time stencil + store -- into a.diag[wave][4].  Its outputs are still correct;
+// its run time is not quoted anywhere.
+template <int NT, int K, int NPF, bool GHOST, int BS, bool DIAG>
 __global__ __launch_bounds__(BS, K >= 12 ? 4 : 6) void kron_pack_kernel(const PackArgs<NT> a)
 {
     constexpr int KS = (K + 3) & ~3;  // LDS stride of a row's slots (16-byte vectors)
@@ -132,7 +147,9 @@ __global__ __launch_bounds__(BS, K >= 12 ? 4 : 6) void kron_pack_kernel(const Pa
     };
     if (g < gend) fetch(g);
 
+    unsigned long long seg[4] = {0, 0, 0, 0}, ts = 0;
     for (; g < gend; g += step) {
+        if (DIAG) ts = stamp();
         const int rows = min(R, a.M - g * R);
         // ---- publish this group's entries ----------------------------------
 #pragma unroll
@@ -143,6 +160,10 @@ __global__ __launch_bounds__(BS, K >= 12 ? 4 : 6) void kron_pack_kernel(const Pa
         }
         if (tid < rows) s_row[tid] = (uint32_t)prow;
         __syncthreads();
+        if (DIAG) {
+            const unsigned long long t = stamp();
+            seg[0] += t - ts, ts = t;
+        }
         if (g + step < gend) fetch(g + step);  // in flight behind the gathers
 
         const bool active = in_row && r < rows;
@@ -198,6 +219,13 @@ __global__ __launch_bounds__(BS, K >= 12 ? 4 : 6) void kron_pack_kernel(const Pa
             }
         }
 
+        if (DIAG) {
+            // the sums must exist before the stamp: make them opaque to the scheduler
+#pragma unroll
+            for (int k = 0; k < NT; ++k) asm volatile("" : "+v"(acc0[k]), "+v"(acc1[k]));
+            const unsigned long long t = stamp();
+            seg[1] += t - ts, ts = t;
+        }
         // ---- time stencil through LDS, store ---------------------------------
         double y0 = 0.0, y1 = 0.0;
         if (a.any_tri) {
@@ -211,6 +239,10 @@ __global__ __launch_bounds__(BS, K >= 12 ? 4 : 6) void kron_pack_kernel(const Pa
                 }
             }
             __syncthreads();
+            if (DIAG) {
+                const unsigned long long t = stamp();
+                seg[2] += t - ts, ts = t;
+            }
             if (active && !ghost_lane) {
 #pragma unroll
                 for (int k = 0; k < NT; ++k) {
@@ -261,6 +293,16 @@ __global__ __launch_bounds__(BS, K >= 12 ? 4 : 6) void kron_pack_kernel(const Pa
                 *dst = make_double2(y0, y1);
             }
         }
+        if (DIAG) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // charge the store to this segment
+            const unsigned long long t = stamp();
+            seg[3] += t - ts;
+        }
+    }
+    if (DIAG && a.diag != nullptr && (tid & 63) == 0) {
+        unsigned long long *d = a.diag + ((size_t)blockIdx.x * (BS / 64) + (tid >> 6)) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[q] = seg[q];
     }
 }
 
@@ -275,22 +317,31 @@ __global__ __launch_bounds__(256) void interleave_ghosts_kernel(int32_t M, const
 
 int g_pack_wg_per_cu = 0;
 int g_pack_flags = 0;
+int g_pack_block = 512;                   // threads per workgroup: 512 or 256
+unsigned long long *g_pack_diag = nullptr;  // set: the next headline-shape launch runs the DIAG instantiation
 
-template <int NT, int K, bool GHOST>
+template <int NT, int K, bool GHOST, int BS>
 int launch_npf(hipStream_t st, const PackArgs<NT> &a, unsigned grid, size_t lds)
 {
     const int npf = (a.R * K + BS - 1) / BS;
+    if constexpr (NT == 2 && K == 7 && !GHOST && BS == 512) {
+        if (a.diag != nullptr && npf <= 1) {
+            hipLaunchKernelGGL((kron_pack_kernel<NT, K, 1, GHOST, BS, true>), dim3(grid), dim3(BS), lds, st, a);
+            STK_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (npf <= 1)
-        hipLaunchKernelGGL((kron_pack_kernel<NT, K, 1, GHOST>), dim3(grid), dim3(BS), lds, st, a);
+        hipLaunchKernelGGL((kron_pack_kernel<NT, K, 1, GHOST, BS, false>), dim3(grid), dim3(BS), lds, st, a);
     else if (npf <= 2)
-        hipLaunchKernelGGL((kron_pack_kernel<NT, K, 2, GHOST>), dim3(grid), dim3(BS), lds, st, a);
+        hipLaunchKernelGGL((kron_pack_kernel<NT, K, 2, GHOST, BS, false>), dim3(grid), dim3(BS), lds, st, a);
     else
-        hipLaunchKernelGGL((kron_pack_kernel<NT, K, 4, GHOST>), dim3(grid), dim3(BS), lds, st, a);
+        hipLaunchKernelGGL((kron_pack_kernel<NT, K, 4, GHOST, BS, false>), dim3(grid), dim3(BS), lds, st, a);
     STK_LAUNCH_CHECK();
     return 0;
 }
 
-template <int NT>
+template <int NT, int BS>
 int launch(hipStream_t st, PackArgs<NT> a, int K)
 {
     const bool ghost = a.gh != nullptr;
@@ -300,13 +351,14 @@ int launch(hipStream_t st, PackArgs<NT> a, int K)
     a.ngroups = (a.M + a.R - 1) / a.R;
     a.chunk = (a.ngroups + 7) / 8;
     a.flags = g_pack_flags;
+    a.diag = g_pack_diag;
     const int KS = (K + 3) & ~3;
     const size_t lds = sizeof(double) * ((a.any_tri ? (size_t)NT * a.R * (a.n_loc + 3) : 0) +
                                           (size_t)a.n_codes * NT + (size_t)NT * 3 * (a.n_loc + 2)) +
                        sizeof(uint32_t) * ((size_t)a.R * KS + a.R + 4) + 32;
     STK_REQUIRE(lds <= 64 * 1024, "stk_kron_pack_apply: %zu bytes of LDS per workgroup (dictionary too large?)", lds);
     const int n_cu = stk_cu_count();
-    int per_cu = g_pack_wg_per_cu > 0 ? g_pack_wg_per_cu : (K >= 12 ? 2 : 3);
+    int per_cu = g_pack_wg_per_cu > 0 ? g_pack_wg_per_cu : (K >= 12 ? 2 : 3) * (512 / BS);
     const int by_lds = (int)(160 * 1024 / (lds + 256));
     if (per_cu > by_lds) per_cu = by_lds > 0 ? by_lds : 1;
     int per_xcd = (n_cu / 8) * per_cu;
@@ -315,8 +367,8 @@ int launch(hipStream_t st, PackArgs<NT> a, int K)
     const unsigned grid = (unsigned)per_xcd * 8;
 #define STK_PACK_CASE(KK)                                                   \
     case KK:                                                                \
-        return ghost ? launch_npf<NT, KK, true>(st, a, grid, lds)           \
-                     : launch_npf<NT, KK, false>(st, a, grid, lds);
+        return ghost ? launch_npf<NT, KK, true, BS>(st, a, grid, lds)       \
+                     : launch_npf<NT, KK, false, BS>(st, a, grid, lds);
     switch (K) {
         STK_PACK_CASE(5)
         STK_PACK_CASE(7)
@@ -352,7 +404,9 @@ int dispatch(hipStream_t st, const stk_pack_pattern *pat, int32_t n_loc, int32_t
         if (t[k].tri) a.any_tri = 1;
     }
     a.P = (n_loc + 1) / 2;
-    return launch<NT>(st, a, pat->K);
+    // 256-thread workgroups: only where a row still fits comfortably
+    if (g_pack_block == 256 && a.P + 1 <= 64) return launch<NT, 256>(st, a, pat->K);
+    return launch<NT, 512>(st, a, pat->K);
 }
 
 }  // namespace
@@ -365,6 +419,10 @@ int stk_kron_pack_set_tuning(const char *key, int32_t value)
     }
     if (std::strcmp(key, "pack_flags") == 0) {
         g_pack_flags = value;
+        return 0;
+    }
+    if (std::strcmp(key, "pack_block") == 0) {
+        g_pack_block = value == 256 ? 256 : 512;
         return 0;
     }
     return 1;
@@ -383,7 +441,7 @@ extern "C" int stk_kron_pack_apply(void *stream, const stk_pack_pattern *pat, in
     STK_REQUIRE(n_loc > 0 && ld >= n_loc && (ld & 1) == 0,
                 "stk_kron_pack_apply: bad sizes n_loc=%d ld=%d (ld must be even)", n_loc, ld);
     STK_REQUIRE(n_terms >= 1 && n_terms <= 3, "stk_kron_pack_apply: n_terms=%d not in 1..3", n_terms);
-    STK_REQUIRE((n_loc + 1) / 2 + 2 <= BS, "stk_kron_pack_apply: n_loc=%d too large", n_loc);
+    STK_REQUIRE((n_loc + 1) / 2 + 2 <= 512, "stk_kron_pack_apply: n_loc=%d too large", n_loc);
     STK_REQUIRE(x != y, "stk_kron_pack_apply: input aliases output");
     STK_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)ghosts) & 15) == 0,
                 "stk_kron_pack_apply: x, y and ghosts must be 16-byte aligned");
@@ -405,5 +463,14 @@ extern "C" int stk_interleave_ghosts(void *stream, int32_t M, const double *lo, 
     hipLaunchKernelGGL(interleave_ghosts_kernel, dim3(stk_flat_grid(M, 256)), dim3(256), 0, stk_stream(stream), M, lo,
                        hi, reinterpret_cast<double2 *>(ghosts));
     STK_LAUNCH_CHECK();
+    return 0;
+}
+
+/* Diagnostic (tools/kron_phases.py): while `buf` is set, launches of the headline
+ * instantiation (2 terms, K = 7, no ghosts) run the stamped build and leave
+ * per-wave cycle sums of the four segments of an iteration in buf[wave][4]. */
+extern "C" int stk_kron_pack_set_diag(unsigned long long *buf)
+{
+    g_pack_diag = buf;
     return 0;
 }

@@ -91,7 +91,8 @@ __global__ __launch_bounds__(GBS) void coarse_kernel(int32_t n0, int32_t n_loc, 
 
 }  // namespace
 
-int g_mg_strip_mb = 400;        // strip-wise sweeps: working set (u and f) of a strip in MB; 0 = off
+int g_mg_strip_width = 2;       // least width of a strip in units of (sweeps x groups) bands
+int g_mg_strip_mb = 120;        // strip-wise smoothing: working set (u and f) of a strip in MB; 0 = off
 int g_mg_zero_start = 1;        // 0: zero u in memory and run the first sweep like the others
 int g_mg_fuse_restrict = 1;     // 0: residual and restriction as two steps
 int g_mg_fuse_coarse = 1;       // 0 disables the fused coarse sub-V-cycle
@@ -138,42 +139,62 @@ static bool can_zero_start(const stk_mg *mg, int level, int ld)
            E.fwd0.size() + 1 == E.fwd_pos.size() && ell_slab_ok(mg->lv[level].n, ld);
 }
 
-// Strip-wise sweep.  On a large level one group pass streams the whole level
-// through the caches, so the next group finds nothing of it there.  The rows are
-// listed in a geometric order, tile row by tile row, and a row only couples to
-// the tile rows next to its own; so the level is cut into S strips of tile rows
-// and ALL groups run on strip s before strip s+1, group g shifted down by g tile
-// rows against group 0: group g then still finds every row of the groups < g it
-// reads already updated, and no row of a group > g that it reads has been
-// touched -- the order of updates, and with it the result, is unchanged, but the
-// strip (u and f: `strip_mb` MB) stays in the 256 MB Infinity Cache between the
-// group passes.  Returns the [S][groups][2] position table, or NULL.
-static const std::vector<int32_t> *strip_table(const EllLevel &E, bool backward, int64_t rows, int ld)
+// Strip-wise smoothing.  On a large level one group pass streams the whole level
+// through the caches, so the next pass finds nothing of it there: `its` sweeps
+// of `ng` dependency groups cost its*ng passes over u (and its passes over f)
+// from HBM.  The plan knows a BAND of every row (stk_mg_level.*_tile_row_host:
+// ascending inside every group; coupled rows lie at most one band apart --
+// mesh rows of a structured mesh).  The level is cut into S strips of bands and
+// ALL stages q = it*ng + g (sweep it, group g) run on strip s before strip s+1,
+// stage q shifted down by q bands against stage 0.  A row of stage q in band b
+// then finds
+//   * every row of an earlier group of the same sweep that it reads (band
+//     b-1..b+1, stage q' < q, so b' + q' <= b + q: same strip earlier, or an
+//     earlier strip) already updated, and
+//   * every row of a later group (stage q'' > q of this sweep, b'' + q'' >= b + q:
+//     same strip later, or a later strip) still holding the value of the previous
+//     sweep, whose stage q'' - ng < q has run by the same argument,
+// i.e. exactly the operands of the level-wide passes: the order of updates, and
+// with it the result bit for bit, is unchanged, while u and f of a strip
+// (`strip_mb` MB) are read from HBM once per smoothing call, not once per pass.
+// Returns the [S][its*ng][2] position table (positions of group q % ng), or NULL.
+static const std::vector<int32_t> *strip_table(const EllLevel &E, bool backward, int64_t rows, int ld, int its)
 {
-    if (g_mg_strip_mb <= 0 || E.n_tile_rows < 2) return nullptr;
+    if (g_mg_strip_mb <= 0 || E.n_tile_rows < 2 || its < 1) return nullptr;
     const double level_mb = 2.0 * (double)rows * ld * 8.0 / 1.0e6;  // u and f
     int S = (int)(level_mb / g_mg_strip_mb + 0.999);
     const std::vector<int32_t> &pos = backward ? E.bwd_pos : E.fwd_pos;
     const int ng = (int)pos.size() - 1;
-    if (S > (E.n_tile_rows - ng) / 2) S = (E.n_tile_rows - ng) / 2;  // strips of at least 2 tile rows
+    const int Q = its * ng;
+    // Strips partition the axis band + stage, 0 .. T + Q - 2.  Any width is
+    // correct; a strip touches its own bands plus the skew of its Q stages, so it
+    // should be a few times wider than Q (g_mg_strip_width: in units of Q; tests
+    // set 0 to force many thin strips).
+    const int T = E.n_tile_rows, span = T + Q - 1;
+    const int min_width = g_mg_strip_width > 0 ? g_mg_strip_width * Q : 2;
+    if (S > span / min_width) S = span / min_width;
     if (S < 2) return nullptr;
     auto &cache = backward ? E.bwd_strips : E.fwd_strips;
-    auto it = cache.find(S);
+    const int key = S * 1024 + its;
+    auto it = cache.find(key);
     if (it != cache.end()) return &it->second;
     const std::vector<int32_t> &tr = backward ? E.bwd_trow : E.fwd_trow;
-    std::vector<int32_t> tab((size_t)S * ng * 2);
-    const int T = E.n_tile_rows;
+    std::vector<int32_t> tab((size_t)S * Q * 2);
     for (int s = 0; s < S; ++s)
-        for (int g = 0; g < ng; ++g) {
+        for (int q = 0; q < Q; ++q) {
+            const int g = q % ng;
             const int32_t *b = tr.data() + pos[g], *e = tr.data() + pos[g + 1];
-            const int lo_row = (int)((int64_t)s * T / S) - g, hi_row = (int)((int64_t)(s + 1) * T / S) - g;
+            // rows of stage q with lo <= band + q < hi
+            const int lo_row = (int)((int64_t)s * span / S) - q, hi_row = (int)((int64_t)(s + 1) * span / S) - q;
             const int32_t *lo = (s == 0) ? b : std::lower_bound(b, e, lo_row);
             const int32_t *hi = (s == S - 1) ? e : std::lower_bound(b, e, hi_row);
-            tab[((size_t)s * ng + g) * 2] = (int32_t)(lo - tr.data());
-            tab[((size_t)s * ng + g) * 2 + 1] = (int32_t)(hi - tr.data());
+            tab[((size_t)s * Q + q) * 2] = (int32_t)(lo - tr.data());
+            tab[((size_t)s * Q + q) * 2 + 1] = (int32_t)(hi - tr.data());
         }
-    return &cache.emplace(S, std::move(tab)).first->second;
+    return &cache.emplace(key, std::move(tab)).first->second;
 }
+
+int g_mg_strips_used = 0;  // launches that came from a strip table (tests read it through stk_set_tuning)
 
 static int smooth_level(stk_mg *mg, hipStream_t st, int level, int n_loc, int ld, double ca, const double *cm,
                         int its, bool backward, const double *f, double *u, bool zero_start = false)
@@ -184,33 +205,30 @@ static int smooth_level(stk_mg *mg, hipStream_t st, int level, int n_loc, int ld
         const stk_ell_rows &e = backward ? E.bwd : E.fwd;
         const std::vector<int32_t> &pos = backward ? E.bwd_pos : E.fwd_pos;
         const int ng = (int)pos.size() - 1;
-        const std::vector<int32_t> *strips = strip_table(E, backward, L.n, ld);
-        const int S = strips ? (int)(strips->size() / (2 * (size_t)ng)) : 1;
-        int first = 0;
-        if (zero_start && !backward && its >= 1) {
-            // u is NOT initialised: group 0 has no entries left and gathers its
-            // (zero-weighted) padding slots from f; later groups only read rows
-            // of earlier groups, which this sweep has written
-            for (int s = 0; s < S; ++s)
-                for (int g = 0; g < ng; ++g) {
-                    const stk_ell_rows &e0 = E.fwd0[g];
-                    // positions of a per-group matrix count from the start of its group
-                    const int p0 = strips ? (*strips)[((size_t)s * ng + g) * 2] - pos[g] : 0;
-                    const int p1 = strips ? (*strips)[((size_t)s * ng + g) * 2 + 1] - pos[g] : e0.n_pos;
-                    int rc = stk_rows_ell_launch(st, 1, &e0, p0, p1, n_loc, ld, L.n, L.n, ca, cm, g == 0 ? f : u, 0.0,
-                                                 0.0, f, u, /*zero_own=*/1);
-                    if (rc) return rc;
+        const bool zs = zero_start && !backward && its >= 1;
+        const std::vector<int32_t> *strips = strip_table(E, backward, L.n, ld, its);
+        const int S = strips ? (int)(strips->size() / (2 * (size_t)ng * its)) : 1;
+        const int Q = its * ng;
+        for (int s = 0; s < S; ++s)
+            for (int q = 0; q < Q; ++q) {
+                const int g = q % ng;
+                const int p0 = strips ? (*strips)[((size_t)s * Q + q) * 2] : pos[g];
+                const int p1 = strips ? (*strips)[((size_t)s * Q + q) * 2 + 1] : pos[g + 1];
+                if (strips) ++g_mg_strips_used;
+                int rc;
+                if (zs && q < ng) {
+                    // first sweep of a level visit: u is NOT initialised.  Group 0
+                    // has no entries left and gathers its (zero-weighted) padding
+                    // slots from f; later groups only read rows of earlier groups,
+                    // which this sweep has written.  Positions of a per-group
+                    // matrix count from the start of its group.
+                    rc = stk_rows_ell_launch(st, 1, &E.fwd0[g], p0 - pos[g], p1 - pos[g], n_loc, ld, L.n, L.n, ca, cm,
+                                             g == 0 ? f : u, 0.0, 0.0, f, u, /*zero_own=*/1);
+                } else {
+                    rc = stk_rows_ell_launch(st, 1, &e, p0, p1, n_loc, ld, L.n, L.n, ca, cm, u, 0.0, 0.0, f, u);
                 }
-            first = 1;
-        }
-        for (int it = first; it < its; ++it)
-            for (int s = 0; s < S; ++s)
-                for (int g = 0; g < ng; ++g) {
-                    const int p0 = strips ? (*strips)[((size_t)s * ng + g) * 2] : pos[g];
-                    const int p1 = strips ? (*strips)[((size_t)s * ng + g) * 2 + 1] : pos[g + 1];
-                    int rc = stk_rows_ell_launch(st, 1, &e, p0, p1, n_loc, ld, L.n, L.n, ca, cm, u, 0.0, 0.0, f, u);
-                    if (rc) return rc;
-                }
+                if (rc) return rc;
+            }
         return 0;
     }
     const std::vector<int32_t> &ptr = backward ? mg->bwd_ptr[level] : mg->fwd_ptr[level];

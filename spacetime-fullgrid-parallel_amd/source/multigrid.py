@@ -89,6 +89,42 @@ def gauss_seidel_schedule(indptr, indices, backward=False):
     return ptr, order.astype(np.int32)
 
 
+def coupling_bands(coords, indptr, indices):
+    """A band index per row such that two coupled rows always lie in the same
+    or in adjacent bands -- the property the strip-wise Gauss-Seidel sweep of
+    csrc/mg.hip rests on -- with bands as thin as that allows.  The property is
+    VERIFIED on the pattern, never assumed.  With coordinates the bands are
+    slices along the last axis (mesh rows of a structured mesh, halved until the
+    property holds on an unstructured one); without, the levels of a
+    breadth-first search, which have it by construction for a symmetric
+    pattern.  Returns None when there is no useful banding."""
+    n = len(indptr) - 1
+    if n < 2:
+        return None
+    rows_of = np.repeat(np.arange(n), np.diff(indptr))
+
+    def ok(b):
+        return len(indices) == 0 or np.abs(b[rows_of] - b[indices]).max() <= 1
+
+    if coords is not None:
+        _, band = np.unique(np.round(np.asarray(coords)[:n, -1], 12),
+                            return_inverse=True)
+        band = band.astype(np.int64)
+        while band.max() > 0 and not ok(band):
+            band //= 2
+    else:
+        from scipy.sparse.csgraph import dijkstra
+        pat = sp.csr_matrix((np.ones(len(indices)), indices, indptr),
+                            shape=(n, n))
+        dist = dijkstra(pat + pat.T, unweighted=True, indices=0)
+        if not np.isfinite(dist).all():
+            return None
+        band = dist.astype(np.int64)
+    if band.max() < 1 or not ok(band):
+        return None
+    return band
+
+
 class _DeviceHierarchy:
     """Everything one libstk multigrid plan needs, resident on the device."""
     def __init__(self, mat_a, mat_m, hierarchy, smoothsteps, vcycles,
@@ -145,8 +181,9 @@ class _DeviceHierarchy:
                 tile = np.arange(n, dtype=np.int32)
             rank = np.empty(n, dtype=np.int64)
             rank[tile] = np.arange(n)
-            trow = (tile_rows_from_coords(hierarchy.coords[:n])
-                    if hierarchy.coords is not None else None)
+            # bands for the strip-wise sweeps: coupled rows at most one band apart
+            band = coupling_bands(hierarchy.coords, indptr, indices)
+            key = rank if band is None else band * np.int64(n) + rank
             vm = vals[1] if self.has_m else None
             ells = {'a': EllRowsMatrix(indptr, indices, vals[0], vm, tile)}
             for name, bw in (('fwd', False), ('bwd', True)):
@@ -156,27 +193,27 @@ class _DeviceHierarchy:
                 setattr(L, 'n_' + name, len(ptr) - 1)
                 setattr(L, name + '_ptr_host',
                         ptr.ctypes.data_as(ctypes.c_void_p))
-                # the same groups, each in tile order, as one ELL matrix
-                order = np.concatenate([
-                    np.sort(rank[rows[ptr[g]:ptr[g + 1]]])
-                    for g in range(len(ptr) - 1)
-                ]) if n else np.zeros(0, dtype=np.int64)
+                # the same groups as one ELL matrix, each group band by band and
+                # in tile order inside a band
+                groups = [rows[ptr[g]:ptr[g + 1]] for g in range(len(ptr) - 1)]
+                groups = [r_[np.argsort(key[r_], kind='stable')] for r_ in groups]
+                listed = (np.concatenate(groups) if n else
+                          np.zeros(0, dtype=np.int64))
                 ells[name] = EllRowsMatrix(indptr, indices, vals[0], vm,
-                                           tile[order], diag=True)
-                if trow is not None and trow.max() > 0:
-                    # tile row of every ELL position (ascending inside a group):
-                    # lets the plan run a sweep strip by strip (mg.hip)
+                                           listed, diag=True)
+                if band is not None:
+                    # band of every ELL position (ascending inside a group):
+                    # lets the plan run the sweeps strip by strip (mg.hip)
                     host[name + '_trow'] = np.ascontiguousarray(
-                        trow[tile[order]], dtype=np.int32)
+                        band[listed], dtype=np.int32)
                     setattr(L, name + '_tile_row_host',
                             host[name + '_trow'].ctypes.data_as(ctypes.c_void_p))
-                    L.n_tile_rows = int(trow.max()) + 1
+                    L.n_tile_rows = int(band.max()) + 1
                 host[name + '_pos'] = ptr  # group g = positions ptr[g]:ptr[g+1]
                 setattr(L, name + '_pos_host',
                         ptr.ctypes.data_as(ctypes.c_void_p))
                 if not bw:
-                    fwd_groups = [tile[np.sort(rank[rows[ptr[g]:ptr[g + 1]]])]
-                                  for g in range(len(ptr) - 1)]
+                    fwd_groups = groups
             P = sp.csr_matrix(hierarchy.P_mats[j - 1])
             R = sp.csr_matrix(hierarchy.R_mats[j - 1])
             nc = P.shape[1]

@@ -1007,24 +1007,68 @@ def test_zero_start_first_sweep_is_exact(stk):
         assert np.array_equal(res[0][1], res[1][1])
 
 
-def test_strip_wise_sweeps_are_exact(stk, monkeypatch):
-    """Gauss-Seidel sweeps run strip by strip (all dependency groups on one strip
-    of tile rows before the next, each group shifted by one tile row: mg.hip)
-    update every row from exactly the same values as level-wide group passes:
-    bitwise the same V-cycle.  Small tiles so that small levels have many tile
-    rows; strip sizes from 2 strips to as many as fit."""
+def test_strip_wise_sweeps_are_exact(stk):
+    """Smoothing run strip by strip (ALL sweeps and dependency groups on one
+    strip of bands before the next, every stage shifted by one band: mg.hip)
+    updates every row from exactly the same values as level-wide group passes:
+    bitwise the same V-cycle.  Strip widths from a few wide strips down to strips
+    thinner than the skew of their stages; the plan must really have taken the
+    strip path (launch counter), on the cube too."""
     import heateq_mpi as hm
-    monkeypatch.setenv('STK_ROWS_PER_TILE', '48')
     for problem, J_space in (('square', 6), ('lshape', 5), ('cube', 3)):
         h = hm.HeatEquationMPI(J_space=J_space, J_time=3, problem=problem)
         x = _vec(h.dofs_distr, np.random.RandomState(14).rand(h.N, h.M))
         res = []
         try:
-            # level working set here is a few MB: strip_mb = 1 gives many strips
-            for strip_mb in (0, 1, 2):
+            # level working sets here are a few MB: strip_mb = 1 gives several
+            # strips; width 0 lifts the lower bound on a strip's width
+            for strip_mb, width in ((0, 2), (1, 2), (1, 0), (2, 1)):
                 stk.check(stk.lib().stk_set_tuning(b'mg_strip_mb', strip_mb))
+                stk.check(stk.lib().stk_set_tuning(b'mg_strip_width', width))
+                stk.check(stk.lib().stk_set_tuning(b'mg_strips_used', 0))
                 res.append((_np(h.P @ x), _np(h.S @ x)))
+                if strip_mb and (width == 0 or problem != 'cube'):
+                    # at least two strips of >= 3 stages ran from a strip table
+                    stk.check(stk.lib().stk_set_tuning(b'mg_strips_used', 6))
         finally:
-            stk.check(stk.lib().stk_set_tuning(b'mg_strip_mb', 400))
+            stk.check(stk.lib().stk_set_tuning(b'mg_strip_mb', 120))
+            stk.check(stk.lib().stk_set_tuning(b'mg_strip_width', 2))
         for Pv, Sv in res[1:]:
             assert np.array_equal(Pv, res[0][0]) and np.array_equal(Sv, res[0][1])
+
+
+def test_coupling_bands_are_verified(stk):
+    """The bands the strip-wise smoothing relies on (coupled rows at most one
+    band apart) are checked on the pattern: a matrix with a long-range entry
+    loses its banding (coarser bands, or none) instead of silently breaking the
+    sweep order, and the V-cycle stays the oracle's."""
+    from oracle.multigrid import MultiGrid as OracleMG
+    from source.assembly import prolongation_matrices, space_matrices
+    from source.multigrid import MeshHierarchy, MultiGrid, coupling_bands
+    from source.problem import problem_helper
+    mesh = problem_helper('square', J_space=5, J_time=2)[0]
+    M_x, A_x = space_matrices(mesh)
+    n = A_x.shape[0]
+    hier = MeshHierarchy(mesh)
+    band = coupling_bands(hier.coords, A_x.indptr, A_x.indices)
+    assert band is not None and band.max() + 1 == 63  # the mesh rows
+    # couple the first and the last dof: no thin banding along y survives
+    B = sp.lil_matrix(A_x)
+    far = int(np.argmax(hier.coords[:n, -1]))
+    near = int(np.argmin(hier.coords[:n, -1]))
+    B[near, far] = B[far, near] = -1e-3
+    B = sp.csr_matrix(B)
+    b2 = coupling_bands(hier.coords, B.indptr, B.indices)
+    rows_of = np.repeat(np.arange(n), np.diff(B.indptr))
+    assert b2 is None or np.abs(b2[rows_of] - b2[B.indices]).max() <= 1
+    try:
+        stk.check(stk.lib().stk_set_tuning(b'mg_strip_mb', 1))
+        stk.check(stk.lib().stk_set_tuning(b'mg_strip_width', 0))
+        mg = MultiGrid(B, hier, smoothsteps=3, vcycles=2)
+        F = np.random.RandomState(3).rand(n, 6)
+        got = (mg @ F)
+    finally:
+        stk.check(stk.lib().stk_set_tuning(b'mg_strip_mb', 120))
+        stk.check(stk.lib().stk_set_tuning(b'mg_strip_width', 2))
+    want = OracleMG(B, prolongation_matrices(mesh), 3, 2) @ F
+    assert relerr(got, want) < 1e-12

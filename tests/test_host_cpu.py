@@ -406,3 +406,31 @@ def test_properties_partition_schedule_staging():
 
     partition()
     schedule()
+
+
+@pytest.mark.parametrize('name,J', [('square', 4), ('lshape', 3), ('cube', 2)])
+def test_coupling_bands_property(name, J):
+    """Bands of the strip-wise smoothing: coupled rows at most one band apart,
+    on every level, with coordinates (mesh rows) and without (BFS levels)."""
+    from source.assembly import prolongation_matrices, space_matrices
+    from source.multigrid import MeshHierarchy, coupling_bands
+    from source.problem import problem_helper
+    mesh = problem_helper(name, J_space=J, J_time=2)[0]
+    M_x, A_x = space_matrices(mesh)
+    hier = MeshHierarchy(mesh)
+    mats = [sp.csr_matrix(M_x + A_x)]
+    for P in reversed(hier.P_mats):
+        mats.insert(0, sp.csr_matrix(P.T @ mats[0] @ P))
+    for m in mats[1:]:
+        n = m.shape[0]
+        rows_of = np.repeat(np.arange(n), np.diff(m.indptr))
+        for coords in (hier.coords, None):
+            band = coupling_bands(coords, m.indptr, m.indices)
+            if band is None:
+                assert n < 4 or coords is None
+                continue
+            assert band.min() == 0 and len(band) == n
+            assert np.abs(band[rows_of] - band[m.indices]).max() <= 1
+            if coords is not None and n > 8:
+                # as thin as the mesh rows on these structured meshes
+                assert band.max() + 1 == len(np.unique(np.round(coords[:n, -1], 12)))
