@@ -194,8 +194,13 @@ def main():
     mesh_mod = load_build_module('mesh')
     asm = load_build_module('assembly')
 
+    out_dir = os.environ.get('STK_GOLDEN_OUT', HERE)
+    only = [k for k in os.environ.get('STK_GOLDEN_ONLY', '').split(',') if k]
+
     def save(name, **arrays):
-        path = os.path.join(HERE, name + '.npz')
+        if only and name not in only:
+            return
+        path = os.path.join(out_dir, name + '.npz')
         np.savez_compressed(path, **arrays)
         print('wrote', os.path.relpath(path, REPO),
               '%.1f kB' % (os.path.getsize(path) / 1024))
@@ -245,6 +250,8 @@ def main():
         ('square3', mesh_mod.construct_2d_square_mesh, 3, 2),
         ('cube', mesh_mod.construct_3d_cube_mesh, 1, 2),
     ]:
+        if only and 'g3_' + pname not in only:
+            continue
         mesh, _ = meshfn(J_space)
         tmesh = mesh_mod.construct_interval(2**J_time)
         A_t, L_t, M_t, G_t, u0_t = asm.time_matrices(tmesh)

@@ -1,13 +1,14 @@
 """Pins the CPU oracle against golden vectors produced by the reference's own
 classes (tests/golden/make_golden.py) and against the known-answer values in
 the reference's tests.  CPU only."""
+import os
 from math import sqrt
 
 import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from conftest import csr_from, load_golden, problem_from, relerr
+from conftest import GOLDEN, csr_from, load_golden, problem_from, relerr
 from oracle import kron, partition, wavelets
 from oracle.heat import HeatEquationOracle
 from oracle.krylov import Lanczos, pcg
@@ -254,3 +255,29 @@ def test_serial_wiring_equals_parallel_wiring():
         assert relerr(ser.P(Xp.reshape(-1)).reshape(X.shape), par.P(X)[perm]) < 1e-15
         assert relerr(ser.WT_S_W(Xp.reshape(-1)).reshape(X.shape),
                       par.WT_S_W(X)[perm]) < 1e-13
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference'),
+                    reason='the reference only exists in the build container')
+def test_committed_goldens_are_what_the_committed_script_produces(tmp_path):
+    """Staleness guard: re-derives one fixture (g3_square, plus the wavelet and
+    partition tables) by running tests/golden/make_golden.py -- i.e. the
+    reference's own classes on the build's current assembly -- and compares
+    every key with the committed file."""
+    import subprocess
+    import sys
+    env = dict(os.environ, STK_GOLDEN_OUT=str(tmp_path),
+               STK_GOLDEN_ONLY='g1_wavelets,g2_partition,g3_square')
+    subprocess.run([sys.executable, os.path.join(GOLDEN, 'make_golden.py')],
+                   env=env, check=True, capture_output=True, timeout=900)
+    for name in ('g1_wavelets', 'g2_partition', 'g3_square'):
+        new = np.load(os.path.join(str(tmp_path), name + '.npz'))
+        old = load_golden(name)
+        assert sorted(new.files) == sorted(old.files), name
+        for k in new.files:
+            a, b = new[k], old[k]
+            assert a.shape == b.shape, (name, k)
+            if a.dtype.kind in 'iub':
+                assert np.array_equal(a, b), (name, k)
+            else:
+                assert np.allclose(a, b, rtol=1e-12, atol=1e-300), (name, k)

@@ -17,10 +17,9 @@ groups=(
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS"
   "SQ_INSTS_VMEM_WR SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM_RD"
   "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum"
-  "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TA_BUFFER_READ_WAVEFRONTS_sum"
   "GRBM_GUI_ACTIVE"
 )
-[ "$which" = "gs" ] && groups=("${groups[@]:0:6}" "${groups[@]:9:1}")
+[ "$which" = "gs" ] && groups=("${groups[@]:0:6}" "${groups[@]:8:1}")
 i=0
 for grp in "${groups[@]}"; do
   i=$((i+1))
