@@ -41,44 +41,170 @@ def seeded_slab(t_begin, t_end, M):
     return out
 
 
-def cpu_baseline(A_t, M_t, M_x, A_x, N, M, nbytes):
-    """The CPU oracle (NumPy/SciPy restatement of the reference's
-    SumMPI([TridiagKronMatMPI, TridiagKronMatMPI]) path) on one host core."""
+_CPU = {}
+
+
+def _cpu_slab(args):
+    """One worker of the all-cores baseline: `reps` applies of the time rows
+    [t0, t1) of y = (A_t kron M_x + M_t kron A_x) x through the oracle's
+    functions (T_t kron I first, then I kron X_x; reference mpi_kron.py:214-219).
+    The matrices are inherited from the parent (fork)."""
+    t0, t1, reps = args
     from oracle import kron as okron
-    rows = min(N, 17)  # bounded sample: the leading 17 time rows
-    T1, T2 = A_t[:rows, :rows].tocsr(), M_t[:rows, :rows].tocsr()
-    X = seeded_slab(0, rows, M)
-    okron.sum_apply([(T1, M_x), (T2, A_x)], X)  # warm
+    A_t, M_t, M_x, A_x, N, M = (_CPU[k] for k in ('A_t', 'M_t', 'M_x', 'A_x', 'N', 'M'))
+    lo, hi = max(t0 - 1, 0), min(t1 + 1, N)
+    X = seeded_slab(lo, hi, M)  # the rows the slab's time stencil reaches
+    T1, T2 = A_t[t0:t1, lo:hi].tocsr(), M_t[t0:t1, lo:hi].tocsr()
+    tic = time.perf_counter()
+    for _ in range(reps):
+        out = okron.identity_kron_mat(M_x, okron.tridiag_kron_identity(T1, X))
+        out += okron.identity_kron_mat(A_x, okron.tridiag_kron_identity(T2, X))
+    return time.perf_counter() - tic
+
+
+def cpu_baseline(A_t, M_t, M_x, A_x, N, M, nbytes, budget_s=10.0):
+    """The CPU oracle (NumPy/SciPy restatement of the reference's
+    SumMPI([TridiagKronMatMPI, TridiagKronMatMPI]) path, kind 'port') on the
+    host cores of this box, protocol of reference heateq_mpi_timing.py:81-102
+    (seeded vector, warm-up, repeated applies): the WHOLE N time rows on one
+    core, and on all cores as independent time slabs in a process pool
+    (SURVEY.md section 8d).  Runs before anything touches the GPU, so the pool
+    can fork."""
+    import multiprocessing as mp
+    import platform
+    from oracle import kron as okron
+    terms = [(A_t, M_x), (M_t, A_x)]
+    X = seeded_slab(0, N, M)
+    okron.sum_apply(terms, X)  # warm
     reps, t0 = 0, time.perf_counter()
-    while reps < 2 or time.perf_counter() - t0 < 8.0:
-        okron.sum_apply([(T1, M_x), (T2, A_x)], X)
+    while reps < 2 or time.perf_counter() - t0 < budget_s:
+        okron.sum_apply(terms, X)
         reps += 1
-    dt = (time.perf_counter() - t0) / reps
-    sample_bytes = 16 * rows * M + 12 * (M_x.nnz + A_x.nnz) + 8 * (M + 1)
+    dt1 = (time.perf_counter() - t0) / reps
+    del X
+    cores = len(os.sched_getaffinity(0))
+    _CPU.update(A_t=A_t.tocsr(), M_t=M_t.tocsr(), M_x=M_x, A_x=A_x, N=N, M=M)
+    workers = min(cores, N)
+    edges = np.linspace(0, N, workers + 1).astype(int)
+    # as many applies per worker as fill the budget at the one-core rate
+    preps = max(2, int(budget_s / max(dt1 / workers, 1e-3)))
+    with mp.get_context('fork').Pool(workers) as pool:
+        pool.map(_cpu_slab, [(int(a), int(b), 1) for a, b in zip(edges[:-1], edges[1:])])  # warm
+        tic = time.perf_counter()
+        pool.map(_cpu_slab, [(int(a), int(b), preps) for a, b in zip(edges[:-1], edges[1:])])
+        dtp = (time.perf_counter() - tic) / preps
+    model = platform.processor() or ''
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                model = line.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {
-        'value': sample_bytes / dt / 1e9,
+        'value': nbytes / dtp / 1e9,
         'unit': 'GB/s',
-        'cores': 1,
+        'cores': workers,
         'kind': 'port',
-        'sample': 'leading %d of %d time rows, %d applies, %.3f s each' %
-                  (rows, N, reps, dt),
+        'one_core_value': nbytes / dt1 / 1e9,
+        'cpu_model': model,
+        'sample': 'all %d time rows; 1 core: %d applies of %.3f s; %d cores '
+                  '(independent time slabs, process pool): %d applies of %.3f s'
+                  % (N, reps, dt1, workers, preps, dtp),
     }
 
 
-def pmc_traffic(args, size):
+KERNEL_SOURCES = ('csrc/kron_pack.hip', 'csrc/kron_ell.hip', 'csrc/stk_common.h',
+                  'source/linop.py')
+
+
+def kernel_source_sha():
+    """Identity of the build the PMC traffic figure belongs to: a hash of the
+    sources of the benched kernel and of its plan builder."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        h.update(open(os.path.join(PKG, rel), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(args, size, kernel):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes
-    (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-byte-per-lane
-    streams, plus WRITE_SIZE, both KiB), collected by tools/pmc_kron.sh in
-    separate runs and committed under profiles/.  Only meaningful for the
-    configuration it was measured on."""
-    path = os.path.join(REPO, 'profiles', 'r01_pmc_traffic.json')
-    if not os.path.exists(path) or size != 1:
-        return None
-    rec = json.load(open(path))
-    if (rec.get('J_time'), rec.get('J_space'), rec.get('problem')) != (
-            args.J_time, args.J_space, args.problem):
-        return None
-    return rec['hbm_bytes_per_launch']
+    (tools/pmc_passes.sh + tools/pmc_traffic.py: FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE, both KiB;
+    separate passes).  The record names the kernel and the source hash it was
+    measured on; a record of another kernel, build or configuration is refused
+    (null), not reported."""
+    import glob
+    if size != 1:
+        return None, None
+    sha = kernel_source_sha()
+    for path in sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_pmc_traffic.json')), reverse=True):
+        rec = json.load(open(path))
+        if ((rec.get('J_time'), rec.get('J_space'), rec.get('problem')) == (
+                args.J_time, args.J_space, args.problem)
+                and rec.get('source_sha') == sha and rec.get('kernel', '') in kernel):
+            return rec['hbm_bytes_per_launch'], {
+                'file': os.path.relpath(path, REPO), 'kernel': rec['kernel'],
+                'source_sha': sha, 'fetch_size_kib': rec.get('fetch_size_kib'),
+                'write_size_kib': rec.get('write_size_kib')}
+    return None, {'source_sha': sha, 'note': 'no PMC record for this build'}
+
+
+def pcg_byte_model(h, n_loc):
+    """Algorithmic bytes of ONE iteration of PCG(W^T S W, P, rhs) on a slab of
+    n_loc time rows, from the operator list of SURVEY.md section 3.1: every
+    operator of the reference's decomposition moves its vector operands once
+    (8 bytes per entry) and its matrix once in the reference's CSR format
+    (12 bytes per entry + 4 per row); level sizes and entry counts are those of
+    the Galerkin hierarchies actually built.  Returns (bytes, breakdown)."""
+    from source.wavelets import WaveletTransformOp
+    N = n_loc
+
+    def V(n):
+        return 8.0 * N * n
+
+    def csr(m):
+        return 12.0 * m.nnz + 4.0 * (m.shape[0] + 1)
+
+    def mg_apply(mats, P_mats, smoothsteps, vcycles):
+        cyc = 2.0 * V(mats[0].shape[0])  # exact solve on level 0
+        for l in range(1, len(mats)):
+            n, nc = mats[l].shape[0], mats[l - 1].shape[0]
+            sweep = 3.0 * V(n) + csr(mats[l])
+            cyc += 2 * smoothsteps * sweep          # pre- and post-smoothing
+            cyc += 3.0 * V(n) + csr(mats[l])        # residual
+            cyc += V(n) + V(nc) + csr(P_mats[l - 1])  # restriction
+            cyc += V(nc)                            # zero coarse iterate
+            cyc += V(nc) + 2.0 * V(n) + csr(P_mats[l - 1])  # prolongate + correct
+        return vcycles * cyc + V(mats[-1].shape[0])
+
+    M = h.M
+    P_mats = h.hierarchy.P_mats
+    kd, fd = h.Kinv_x._dev, h.C_family._dev
+    mg_K = mg_apply(kd.mats_a, P_mats, kd.smoothsteps, kd.vcycles)
+    # the preconditioner's matrices 2^j M + alpha A live on the union pattern
+    union = [sp_union(a, m) for a, m in zip(fd.mats_a, fd.mats_m)]
+    mg_C = mg_apply(union, P_mats, fd.smoothsteps, fd.vcycles)
+    spmv_M, spmv_A = 2.0 * V(M) + csr(h.M_x), 2.0 * V(M) + csr(h.A_x)
+    tri = 2.0 * V(M)
+    S = (4 * (tri + mg_K) + (spmv_M + spmv_M) + (spmv_M + spmv_A) + (spmv_A + spmv_M)
+         + (spmv_A + spmv_A) + (tri + spmv_M) + 4 * 3.0 * V(M))
+    wt = WaveletTransformOp(h.J_time, interleaved=True)
+    W = 0.0
+    for j in range(1, h.J_time + 1):
+        W += 2.0 * V(M) + 24.0 * M * wt.split(j).nnz * N / float(h.N)
+    P = 2.0 * mg_C + spmv_A
+    blas1 = 15.0 * V(M)
+    total = 2.0 * W + S + P + blas1
+    return total, {'S': S, 'W_and_WT': 2.0 * W, 'P': P, 'blas1': blas1,
+                   'mg_apply_K': mg_K, 'mg_apply_C': mg_C}
+
+
+def sp_union(a, m):
+    import scipy.sparse as sp
+    u = sp.csr_matrix(abs(a) + abs(m))
+    return u
 
 
 def main():
@@ -92,20 +218,13 @@ def main():
     ap.add_argument('--solve-iters', type=int, default=10,
                     help='PCG iterations to time for iters/s (0 = skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=10.0,
+                    help='time budget of each leg (1 core, all cores) of the CPU baseline')
     ap.add_argument('--preheat', type=float, default=0.5,
                     help='seconds of untimed applies before the warm-up steps')
     args = ap.parse_args()
 
-    import torch
-    from source.comm import MPI
-    comm = MPI.COMM_WORLD
-    rank, size = comm.Get_rank(), comm.Get_size()
-    assert size == args.gpus, 'launch one process per GPU (torchrun)'
-    assert torch.cuda.is_available(), 'bench.py needs a GPU; no CPU fallback'
-
     from source.assembly import space_matrices, time_matrices
-    from source.mpi_kron import SumMPI, TridiagKronMatMPI
-    from source.mpi_vector import DofDistributionMPI, KronVectorMPI
     from source.problem import problem_helper
 
     mesh_space, _, mesh_time, data, _ = problem_helper(args.problem,
@@ -114,6 +233,25 @@ def main():
     A_t, L_t, M_t, G_t, u0_t = time_matrices(mesh_time)
     M_x, A_x = space_matrices(mesh_space)
     N, M = A_t.shape[0], M_x.shape[0]
+
+    # CPU baseline first: nothing has touched the GPU yet, so its process pool
+    # can fork (rank 0 of a one-GPU run only)
+    cpu = None
+    if (int(os.environ.get('RANK', '0')) == 0 and args.gpus == 1
+            and int(os.environ.get('WORLD_SIZE', '1')) == 1 and not args.no_cpu_baseline):
+        nb = 16 * N * M + 12 * (M_x.nnz + A_x.nnz) + 8 * (M + 1)
+        cpu = cpu_baseline(A_t, M_t, M_x, A_x, N, M, nb, args.cpu_seconds)
+
+    import torch
+    from source.comm import MPI
+    comm = MPI.COMM_WORLD
+    rank, size = comm.Get_rank(), comm.Get_size()
+    assert size == args.gpus, 'launch one process per GPU (torchrun)'
+    assert torch.cuda.is_available(), 'bench.py needs a GPU; no CPU fallback'
+
+    from source.mpi_kron import SumMPI, TridiagKronMatMPI
+    from source.mpi_vector import DofDistributionMPI, KronVectorMPI
+
     dd = DofDistributionMPI(comm, N, M)
     op = SumMPI(dd, [TridiagKronMatMPI(dd, A_t, M_x),
                      TridiagKronMatMPI(dd, M_t, A_x)])
@@ -206,13 +344,28 @@ def main():
         if size > 1:
             dist.all_reduce(ds, op=dist.ReduceOp.MAX)
         ds = float(ds[0])
+        model_bytes, parts = pcg_byte_model(h, n_loc)
+        mb = torch.tensor([model_bytes], dtype=torch.float64, device=red_dev)
+        if size > 1:
+            dist.all_reduce(mb, op=dist.ReduceOp.SUM)
+        model_total = float(mb[0])
         solve = {'iters_timed': n_it, 'iters_per_s': n_it / ds,
                  'ms_per_iter': ds / n_it * 1e3,
-                 'r_dot_Pr': [float(v) for v in hist]}
+                 'r_dot_Pr': [float(v) for v in hist],
+                 # secondary roofline: algorithmic bytes of one iteration by the
+                 # operator list of SURVEY.md section 3.1
+                 'roofline': {
+                     'bound': 'hbm', 'unit': 'GB/s', 'peak': HBM_PEAK_GBS * size,
+                     'bytes_per_iteration': model_total,
+                     'achieved': model_total / (ds / n_it) / 1e9,
+                     'frac': model_total / (ds / n_it) / 1e9 / (HBM_PEAK_GBS * size),
+                     'breakdown_rank0_bytes': parts}}
 
     if rank != 0:
         return
     achieved = my_bytes / (kernel_ms * 1e-3) / 1e9
+    kernel = fused.kernel_name(n_loc)
+    traffic, traffic_src = pmc_traffic(args, size, kernel)
     out = {
         'metric': 'Kronecker-matvec GB/s (algorithmic bytes; share of 8 TB/s HBM '
                   'peak in roofline.frac) + PCG iters/s, J_time=%d J_space=%d %s'
@@ -243,17 +396,17 @@ def main():
             'peak': HBM_PEAK_GBS,
             'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS,
-            'traffic': pmc_traffic(args, size),
-            'kernel': 'kron_ell_kernel<NT=2, shared input, K=7>' + (
-                '' if size == 1 else ' + kron_ell_ghost_kernel (rank 0 slab)'),
+            'traffic': traffic,
+            'traffic_source': traffic_src,
+            'kernel': kernel,
             'bytes_per_launch': my_bytes,
             'avg_launch_ms': kernel_ms,
             'step_ms_with_halo_exchange': dev_ms,
         },
         'pcg': solve,
     }
-    if size == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(A_t, M_t, M_x, A_x, N, M, my_bytes)
+    if cpu is not None:
+        out['cpu_baseline'] = cpu
     print(json.dumps(out))
 
 

@@ -185,8 +185,24 @@ __global__ __launch_bounds__(BS, K >= 12 ? 4 : 6) void kron_pack_kernel(const Pa
                     const uint4 v = so[u];
                     sl[4 * u] = v.x, sl[4 * u + 1] = v.y, sl[4 * u + 2] = v.z, sl[4 * u + 3] = v.w;
                 }
+                if constexpr (DIAG) {
+                    // ablations of the diagnostic build (wrong results, timing only):
+                    // 16: every slot gathers the row's own column (one line set per row,
+                    //     same instruction count); 32: one gather per lane instead of K
+                    if (a.flags & 16) {
 #pragma unroll
-                for (int u = 0; u < K; ++u) xv[u] = load2(base_lane + (size_t)(sl[u] & col_mask) * stride_lane);
+                        for (int u = 0; u < K; ++u) sl[u] = yrow;
+                    }
+                }
+                if (DIAG && (a.flags & 32)) {
+                    xv[0] = load2(base_lane + (size_t)(sl[0] & col_mask) * stride_lane);
+#pragma unroll
+                    for (int u = 1; u < K; ++u) xv[u] = xv[0];
+                } else {
+#pragma unroll
+                    for (int u = 0; u < K; ++u)
+                        xv[u] = load2(base_lane + (size_t)(sl[u] & col_mask) * stride_lane);
+                }
             }
             // The slot words are read a second time for their codes rather than
             // kept in registers across the gathers (the offset is made opaque so

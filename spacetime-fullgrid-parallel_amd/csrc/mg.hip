@@ -24,6 +24,8 @@
 // (reference heateq_mpi.py:97-98) share one stored hierarchy: Galerkin
 // coarsening is linear, so R(2^j M + alpha A)P = 2^j RMP + alpha RAP.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <vector>
 
@@ -160,6 +162,11 @@ static bool can_zero_start(const stk_mg *mg, int level, int ld)
 // Returns the [S][its*ng][2] position table (positions of group q % ng), or NULL.
 static const std::vector<int32_t> *strip_table(const EllLevel &E, bool backward, int64_t rows, int ld, int its)
 {
+    static const bool debug = getenv("STK_DEBUG_STRIPS") != nullptr;
+    if (debug)
+        fprintf(stderr, "strip_table: rows=%lld ld=%d its=%d bands=%d strip_mb=%d width=%d groups=%d\n",
+                (long long)rows, ld, its, E.n_tile_rows, g_mg_strip_mb, g_mg_strip_width,
+                (int)(backward ? E.bwd_pos : E.fwd_pos).size() - 1);
     if (g_mg_strip_mb <= 0 || E.n_tile_rows < 2 || its < 1) return nullptr;
     const double level_mb = 2.0 * (double)rows * ld * 8.0 / 1.0e6;  // u and f
     int S = (int)(level_mb / g_mg_strip_mb + 0.999);

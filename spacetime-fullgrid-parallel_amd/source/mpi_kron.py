@@ -452,6 +452,17 @@ class _FusedKronSum:
             _lib.ptr(vec_out.buf)))
         return time_comm
 
+    def kernel_name(self, n_loc):
+        """Name of the kernel instantiation `apply` launches (for the bench
+        line and for matching a PMC record to the build)."""
+        if not self.use_ell:
+            return 'kron_sum_kernel<%d>' % self.n_terms
+        if type(self).use_pack and self.ell.packed.ok:
+            ghost = self.dofs_distr.size > 1 and (self.needs_lo or self.needs_hi)
+            return 'kron_pack_kernel<%d, %d, %s>' % (
+                self.n_terms, self.ell.K, 'ghost lanes' if ghost else 'no ghosts')
+        return 'kron_ell_kernel<%d, shared input, %d>' % (self.n_terms, self.ell.K)
+
     def algorithmic_bytes(self, n_loc, M):
         """Bytes one apply must move: x once, y once,
         ghost rows, every CSR array once."""

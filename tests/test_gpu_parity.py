@@ -475,19 +475,19 @@ def test_midsize_solve_matches_oracle_fixture(stk):
     oracle's trajectory (tests/golden/make_oracle_vectors.py)."""
     import heateq_mpi as hm
     from source.linalg import PCG
-    g = load_golden('o1_pcg_J5_J6')
+    g = load_golden('o1_pcg_square_J5_J6')
     h = hm.HeatEquationMPI(J_space=int(g['J_space']), J_time=int(g['J_time']))
-    X = np.random.RandomState(128).rand(h.N, h.M)
-    x = _vec(h.dofs_distr, X)
-    assert relerr(_np(h.S @ x)[::4, ::97], g['SX_sample']) < 1e-11
-    assert relerr(_np(h.P @ x)[::4, ::97], g['PX_sample']) < 1e-11
+    st, sx = (int(v) for v in g['sample_strides'])
+    x = _vec(h.dofs_distr, _bench_vector(h.N, h.M))
+    assert relerr(_np(h.S @ x)[::st, ::sx], g['SX_sample']) < 1e-11
+    assert relerr(_np(h.P @ x)[::st, ::sx], g['PX_sample']) < 1e-11
     hist = []
     w, it = PCG(h.WT_S_W, h.P, h.rhs, history=hist)
     assert it == int(g['iters'])
-    assert np.allclose(hist, g['hist'], rtol=1e-8, atol=1e-28)
+    assert _record_history_dev('square_J5_J6', hist, g['hist']) < HIST_RTOL
     wn = _np(w)
-    assert abs(np.linalg.norm(wn) - g['w_norm']) < 1e-9 * g['w_norm']
-    assert relerr(wn[::4, ::97], g['w_sample']) < 1e-8
+    assert abs(np.linalg.norm(wn) - g['w_norm']) < 1e-10 * g['w_norm']
+    assert relerr(wn[::st, ::sx], g['w_sample']) < 1e-9
 
 
 def test_wide_slab_addressing_matches(stk):
@@ -544,15 +544,79 @@ def test_coarse_subcycle_variants_agree(stk):
             assert np.array_equal(Pv, res[0][0]) and np.array_equal(Sv, res[0][1])
 
 
-@pytest.mark.parametrize('problem,J_space,J_time', [('square', 9, 6),
+# r.Pr histories against the oracle: the bound asserted below, and the measured
+# deviations (written to gpurun_out/parity_history_dev.json when that directory
+# exists, so that the figure quoted in DESIGN.md section 5 has a source).
+HIST_RTOL = 1e-10
+
+
+def _record_history_dev(tag, hist, ref):
+    import json
+    import os
+    dev = float(np.max(np.abs(np.asarray(hist) / np.asarray(ref) - 1.0)))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                       'gpurun_out')
+    if os.path.isdir(out):
+        path = os.path.join(out, 'parity_history_dev.json')
+        rec = json.load(open(path)) if os.path.exists(path) else {}
+        rec[tag] = {'max_rel_dev_r_dot_Pr': dev, 'iterations': len(hist) - 1}
+        json.dump(rec, open(path, 'w'), indent=1, sort_keys=True)
+    print('history deviation %s: %.2e' % (tag, dev))
+    return dev
+
+
+def _bench_vector(N, M):
+    """The bench's input: one seeded row per global time step."""
+    X = np.empty((N, M))
+    for t in range(N):
+        X[t] = np.random.RandomState(128 + t).rand(M)
+    return X
+
+
+@pytest.mark.parametrize('problem,J_space,J_time', [('square', 6, 3),
+                                                    ('square', 8, 5),
+                                                    ('square', 9, 6),
                                                     ('lshape', 8, 5)])
+def test_baseline_configs_solve_matches_oracle_trajectory(stk, problem, J_space, J_time):
+    """BASELINE.json configs 1-4 at full size, the whole solve as the
+    reference's integration test compares it (heateq_mpi_test.py:138-189):
+    iteration count EQUAL to the CPU oracle's, every r.Pr of the history within
+    HIST_RTOL, the solution on the fixture's sample, plus S, P and W applied
+    to the bench's vector on the same sample.  The oracle trajectories are
+    fixtures (tests/golden/make_oracle_vectors.py; config 3 takes 11 minutes on
+    6 host threads)."""
+    import heateq_mpi as hm
+    from source.linalg import PCG
+    g = load_golden('o1_pcg_%s_J%d_J%d' % (problem, J_time, J_space))
+    h = hm.HeatEquationMPI(J_space=J_space, J_time=J_time, problem=problem)
+    st, sx = (int(v) for v in g['sample_strides'])
+    x = _vec(h.dofs_distr, _bench_vector(h.N, h.M))
+    assert relerr(_np(h.W @ x)[::st, ::sx], g['WX_sample']) < 1e-13
+    assert relerr(_np(h.S @ x)[::st, ::sx], g['SX_sample']) < 1e-11
+    assert relerr(_np(h.P @ x)[::st, ::sx], g['PX_sample']) < 1e-11
+    del x
+    hist = []
+    w, it = PCG(h.WT_S_W, h.P, h.rhs, history=hist)
+    assert it == int(g['iters']), (it, int(g['iters']))
+    dev = _record_history_dev('%s_J%d_J%d' % (problem, J_time, J_space), hist, g['hist'])
+    assert dev < HIST_RTOL, dev
+    wn = _np(w)
+    assert abs(np.linalg.norm(wn) - g['w_norm']) < 1e-10 * g['w_norm']
+    assert relerr(wn[::st, ::sx], g['w_sample']) < 1e-9
+
+
+@pytest.mark.parametrize('problem,J_space,J_time', [('square', 9, 6),
+                                                    ('lshape', 8, 5),
+                                                    ('square', 10, 7)])
 def test_baseline_configs_full_size_against_oracle(stk, problem, J_space, J_time):
-    """BASELINE.json configs 3 and 4 at their full size (square: N = 65,
-    M = 1 046 529).  The Kronecker metric operator and W / W^T are compared
+    """BASELINE.json configs 3, 4 and 5 at their full size (config 5: N = 129,
+    M = 4 190 209, a 4.3 GB vector -- slabs of 4 GiB and more, 64-bit addressing
+    in every ELL kernel).  The Kronecker metric operator and W / W^T are compared
     with the oracle on the WHOLE vector; S and P, whose oracle needs seconds
     per time slice, on sampled time slices (space operators act slice by slice,
-    so (S x)[t] only needs the rows t-1, t, t+1 of the time factors); the solve
-    through the iteration count and the residual the reference prints."""
+    so (S x)[t] only needs the rows t-1, t, t+1 of the time factors).  Config 5
+    has no oracle trajectory (hours of CPU): its solve is held to the iteration
+    count of the smaller configs' pattern and a monotone history."""
     import heateq_mpi as hm
     from oracle import kron as okron
     from oracle import wavelets as ow
@@ -573,7 +637,8 @@ def test_baseline_configs_full_size_against_oracle(stk, problem, J_space, J_time
     P_mats = h.hierarchy.P_mats
     levels = ow.levels(J_time, interleaved=True)
     sample = [0, N // 2 + 1]
-    Sx, Px = _np(h.S @ x), _np(h.P @ x)
+    Sx = _np(h.S @ x)[sample]
+    Px = _np(h.P @ x)[sample]
     K = OracleMG(h.A_x, P_mats, 3, 2)
     Mx, Ax = h.M_x, h.A_x
     want = np.zeros((len(sample), M))
@@ -582,11 +647,11 @@ def test_baseline_configs_full_size_against_oracle(stk, problem, J_space, J_time
                    (h.G_t, [Mx])]:  # heateq_mpi.py:166-181
         Z = sp.csr_matrix(T)[sample] @ X
         want += okron.composite_space(ops, Z.T).T
-    assert relerr(Sx[sample], want) < 1e-10
-    for t in sample:
+    assert relerr(Sx, want) < 1e-10
+    for k, t in enumerate(sample):
         C = OracleMG(sp.csr_matrix(2.0**levels[t] * Mx + 0.3 * Ax), P_mats, 3, 2)
-        assert relerr(Px[t], C @ (Ax @ (C @ X[t]))) < 1e-10
-    del Sx, Px
+        assert relerr(Px[k], C @ (Ax @ (C @ X[t]))) < 1e-10
+    del Sx, Px, X, x
     hist = []
     w, iters = PCG(h.WT_S_W, h.P, h.rhs, history=hist)
     assert 10 <= iters <= 16 and hist[-1] < 1e-12
@@ -1015,7 +1080,8 @@ def test_strip_wise_sweeps_are_exact(stk):
     thinner than the skew of their stages; the plan must really have taken the
     strip path (launch counter), on the cube too."""
     import heateq_mpi as hm
-    for problem, J_space in (('square', 6), ('lshape', 5), ('cube', 3)):
+    # (the cube needs J_space = 4: its 15^3 level runs inside the fused coarse kernel)
+    for problem, J_space in (('square', 6), ('lshape', 5), ('cube', 4)):
         h = hm.HeatEquationMPI(J_space=J_space, J_time=3, problem=problem)
         x = _vec(h.dofs_distr, np.random.RandomState(14).rand(h.N, h.M))
         res = []

@@ -97,8 +97,25 @@ if args.phases and g is None:
         buf.zero_()
         fn()
     torch.cuda.synchronize()
+    first = buf.cpu().numpy().astype(np.float64)
+    # ablations of the stamped build (timing only)
+    for flags, what in ((0, 'stamped build as is'), (16, 'all slots gather the own column'),
+                        (32, 'one gather per lane'), (48, 'one gather, own column')):
+        _lib.check(_lib.lib().stk_set_tuning(b'pack_flags', flags))
+        _lib.check(_lib.lib().stk_kron_pack_set_diag(buf.data_ptr()))
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        print('   ablation %-36s %.4f ms' % (what, e0.elapsed_time(e1) / args.reps))
+    _lib.check(_lib.lib().stk_set_tuning(b'pack_flags', 0))
     _lib.check(_lib.lib().stk_kron_pack_set_diag(None))
-    d = buf.cpu().numpy().astype(np.float64)
+    d = first
     d = d[d.sum(axis=1) > 0]
     tot = d.sum(axis=1)
     names = ['publish + barrier 1', 'gathers + space factors', 'exchange + barrier 2', 'time stencil + store']
