@@ -51,7 +51,9 @@ if g is not None:
     _lib.check(_lib.lib().stk_interleave_ghosts(_lib.stream(), M, _lib.ptr(g[0]), _lib.ptr(g[1]), _lib.ptr(gh)))
 lo, hi = (g[0], g[1]) if g is not None else (None, None)
 nbytes = 16 * n_loc * M + 8 * (2 if g is not None else 0) * M + 12 * (M_x.nnz + A_x.nnz) + 8 * (M + 1)
-KEYS = {'pack_flags': 0, 'pack_block': 512, 'pack_wg_per_cu': 0, 'ell_wg_per_cu': 0}
+KEYS = {'pack_flags': 0, 'pack_block': 512, 'pack_wg_per_cu': 0, 'ell_wg_per_cu': 0,
+        'tile_flags': 0, 'tile_wg_per_cu': 0}
+TILED = {}
 
 
 def run(variant):
@@ -63,10 +65,27 @@ def run(variant):
         _lib.check(_lib.lib().stk_set_tuning(k.encode(), int(v)))
     if parts[0] == 'plain':
         return lambda: ell.apply([(tri[0], 0, x, lo, hi), (tri[1], 1, x, lo, hi)], n_loc, ld, 0.0, y)
+    if parts[0].startswith('tile'):  # tile1 / tile2: one- or two-pass tiles
+        from source.linop import TiledEllMatrices
+        passes = int(parts[0][4:] or 1)
+        if passes not in TILED:
+            TILED[passes] = TiledEllMatrices(ell.packed, ell._strip_of_pos, n_loc, gh is not None, passes)
+            t = TILED[passes]
+            print('tile plan, %d pass(es): ok=%s' % (passes, t.ok), '' if not t.ok else
+                  'tiles=%d nc_max=%d tr_max=%d lds=%d columns/row=%.2f' % (t.n_tiles, t.nc_max, t.tr_max, t.lds, t.cols_per_row))
+        t = TILED[passes]
+        return lambda: t.apply([(tri[0], 0), (tri[1], 1)], x, gh, n_loc, ld, 0.0, y)
     return lambda: ell.packed.apply([(tri[0], 0), (tri[1], 1)], x, gh, n_loc, ld, 0.0, y)
 
 
 variants = args.variants.split(';')
+run('pack')()
+y_ref = y.clone()
+for v in variants:
+    if v.startswith('tile'):
+        y.zero_()
+        run(v)()
+        print('%-40s max |diff to packed form| = %.3e' % (v, float((y - y_ref).abs().max())))
 times = {v: [] for v in variants}
 for rnd in range(args.rounds):
     for v in variants:
