@@ -217,6 +217,26 @@ int stk_kron_tile_apply(void *stream, const stk_tile_pattern *pattern_host,
                         const stk_kron_pack_term *terms_host, const double *x,
                         const double *ghosts, double beta, double *y);
 
+/* The same operator, WAVE-AUTONOMOUS (csrc/kron_wave.hip): no workgroup barrier
+ * in the loop; a wavefront owns 62 consecutive (row, time-pair) tasks and gets
+ * the neighbouring time steps' sums by DPP wave shifts.  recs holds one record
+ * of KS = round_up(K + 1, 4) 32-bit words per row of the processing order: the K
+ * slot words `code << col_bits | column` of stk_kron_pack_apply, padding, and
+ * the output row id in the last word.  Dictionary, terms and ghosts as there.
+ * Tuning keys: "wave_wg_per_cu", "wave_block" (256 / 512), "wave_flags" (bit 0:
+ * non-temporal y stores). */
+typedef struct {
+    int32_t M, K;
+    int32_t col_bits, n_codes, n_mats;
+    const uint32_t *recs; /* M * round_up(K + 1, 4), 16-byte aligned */
+    const double *dict;   /* n_mats*n_codes */
+} stk_wave_pattern;
+
+int stk_kron_wave_apply(void *stream, const stk_wave_pattern *pattern_host,
+                        int32_t n_loc, int32_t ld, int32_t n_terms,
+                        const stk_kron_pack_term *terms_host, const double *x,
+                        const double *ghosts, double beta, double *y);
+
 /* Diagnostic: while `buf` (device, at least 8 * grid * 4 words) is non-NULL,
  * the headline instantiation (2 terms, K = 7, no ghosts) runs a stamped build
  * that leaves, per wavefront, the shader-clock cycles spent in the four

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(BS, NPF <= 3 ? 6 : 4) void kron_tile_kernel(const T
     {                                                                                                \
         const int c = tid + Q * BS;                                                                  \
         if (c < total) {                                                                             \
-            const int j = (int)__umulhi((uint32_t)c, a.magic_P); /* c / P */                         \
+            const int j = P == 1 ? c : (int)__umulhi((uint32_t)c, a.magic_P); /* c / P */            \
             DST = *reinterpret_cast<const double2 *>(a.x + (size_t)cols[j] * a.ld + 2 * (c - j * P)); \
         }                                                                                            \
     }
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(BS, NPF <= 3 ? 6 : 4) void kron_tile_kernel(const T
         for (int base = 0; base < tasks; base += TASKS_PER_PASS) {
             const int tau = base + wave * 62 + lane - 1;  // lanes 0 and 63: halo tasks
             const bool valid = tau >= 0 && tau < tasks;
-            const int r = valid ? (int)__umulhi((uint32_t)tau, a.magic_W) : 0;  // tau / W
+            const int r = !valid ? 0 : (W == 1 ? tau : (int)__umulhi((uint32_t)tau, a.magic_W));  // tau / W
             const int p = tau - r * W;
             const bool g_lo = GHOST && p == 0, g_hi = GHOST && p == W - 1;
             const bool ghost = g_lo || g_hi;
@@ -342,8 +342,8 @@ int dispatch(hipStream_t st, const stk_tile_pattern *pat, int32_t n_loc, int32_t
     }
     a.P = (n_loc + 1) / 2;
     a.W = a.P + (gh ? 2 : 0);
-    a.magic_W = (uint32_t)((((uint64_t)1 << 32) + a.W - 1) / a.W);
-    a.magic_P = (uint32_t)((((uint64_t)1 << 32) + a.P - 1) / a.P);
+    a.magic_W = a.W > 1 ? (uint32_t)((((uint64_t)1 << 32) + a.W - 1) / a.W) : 0u;
+    a.magic_P = a.P > 1 ? (uint32_t)((((uint64_t)1 << 32) + a.P - 1) / a.P) : 0u;
     a.n_tiles = pat->n_tiles;
     a.chunk = (pat->n_tiles + 7) / 8;
     a.nc_max = pat->nc_max;

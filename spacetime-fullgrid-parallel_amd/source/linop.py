@@ -433,6 +433,33 @@ class PackedEllMatrices:
             _lib.stream(), ctypes.byref(self.pattern), n_loc, ld, len(specs),
             terms, _lib.ptr(x), _lib.ptr(ghosts), beta, _lib.ptr(out)))
 
+    def wave_pattern(self):
+        """Row records of the wave-autonomous kernel (stk_kron_wave_apply): the K
+        slot words of a row, padding, and its output row id in one 16-byte
+        aligned record; built on first use."""
+        if getattr(self, '_wave', None) is None:
+            M, K = self.M, self.K
+            KS = ((K + 1) + 3) & ~3
+            rec = np.zeros((M, KS), dtype=np.uint32)
+            rec[:, :K] = self.slots.cpu().numpy().view(np.uint32)
+            rec[:, KS - 1] = (self.row_ids.cpu().numpy().astype(np.uint32)
+                              if self.row_ids is not None else
+                              np.arange(M, dtype=np.uint32))
+            self._recs = _lib.to_dev(rec.view(np.int32))
+            self._wave = _lib.WavePattern(M, K, self.col_bits, self.n_codes,
+                                          self.n_mats, _lib.ptr(self._recs),
+                                          _lib.ptr(self.dict))
+        return self._wave
+
+    def apply_wave(self, specs, x, ghosts, n_loc, ld, beta, out):
+        terms = (_lib.KronPackTerm * len(specs))()
+        for t, (tri, k) in zip(terms, specs):
+            t.tri, t.mat = _lib.ptr(tri), k
+        _lib.check(_lib.lib().stk_kron_wave_apply(
+            _lib.stream(), ctypes.byref(self.wave_pattern()), n_loc, ld,
+            len(specs), terms, _lib.ptr(x), _lib.ptr(ghosts), beta,
+            _lib.ptr(out)))
+
 
 class TiledEllMatrices:
     """The packed plan cut into tiles for ``stk_kron_tile_apply``

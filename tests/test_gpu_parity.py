@@ -966,6 +966,15 @@ def test_kron_pack_randomised_shapes(stk):
             assert torch.equal(y, y_plain), (case, M, n_loc, nt)
         else:  # the plain form adds the ghost terms in a second kernel
             assert relerr(got, y_plain[:, :n_loc].cpu().numpy()) < 1e-14
+        # the wave-autonomous form (no barriers, DPP time stencil), both block sizes
+        for block in (256, 512):
+            stk.check(stk.lib().stk_set_tuning(b'wave_block', block))
+            y_w = slab(y0)
+            ell.packed.apply_wave([(tris[k], k) for k in range(nt)], x, gh, n_loc,
+                                  ld, beta, y_w)
+            assert torch.equal(y_w, y), (case, M, n_loc, nt, block,
+                                         float((y_w - y).abs().max()))
+        stk.check(stk.lib().stk_set_tuning(b'wave_block', 256))
         # the tile-staged form (LDS-resident columns, DPP time stencil), one- and
         # two-pass tiles: bit for bit the packed form's result
         for passes in (1, 2):

@@ -52,7 +52,7 @@ if g is not None:
 lo, hi = (g[0], g[1]) if g is not None else (None, None)
 nbytes = 16 * n_loc * M + 8 * (2 if g is not None else 0) * M + 12 * (M_x.nnz + A_x.nnz) + 8 * (M + 1)
 KEYS = {'pack_flags': 0, 'pack_block': 512, 'pack_wg_per_cu': 0, 'ell_wg_per_cu': 0,
-        'tile_flags': 0, 'tile_wg_per_cu': 0}
+        'tile_flags': 0, 'tile_wg_per_cu': 0, 'wave_flags': 0, 'wave_wg_per_cu': 0, 'wave_block': 256}
 TILED = {}
 
 
@@ -65,6 +65,8 @@ def run(variant):
         _lib.check(_lib.lib().stk_set_tuning(k.encode(), int(v)))
     if parts[0] == 'plain':
         return lambda: ell.apply([(tri[0], 0, x, lo, hi), (tri[1], 1, x, lo, hi)], n_loc, ld, 0.0, y)
+    if parts[0] == 'wave':
+        return lambda: ell.packed.apply_wave([(tri[0], 0), (tri[1], 1)], x, gh, n_loc, ld, 0.0, y)
     if parts[0].startswith('tile'):  # tile1 / tile2: one- or two-pass tiles
         from source.linop import TiledEllMatrices
         passes = int(parts[0][4:] or 1)
@@ -82,7 +84,7 @@ variants = args.variants.split(';')
 run('pack')()
 y_ref = y.clone()
 for v in variants:
-    if v.startswith('tile'):
+    if v.startswith('tile') or v.startswith('wave'):
         y.zero_()
         run(v)()
         print('%-40s max |diff to packed form| = %.3e' % (v, float((y - y_ref).abs().max())))
