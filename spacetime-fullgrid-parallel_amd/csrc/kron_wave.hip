@@ -119,14 +119,39 @@ __global__ __launch_bounds__(BS, K >= 12 ? 4 : 6) void kron_wave_kernel(const Wa
     };
     if (u < uend) fetch(u);
 
+    // results of the previous round, stored one round late: vmcnt counts in order, so
+    // a wait for the prefetched records issued after a store would also wait for
+    // that store to complete.  The store goes out right after the records have been
+    // taken over, and overlaps with the gathers that follow.
+    double dy0 = 0.0, dy1 = 0.0;
+    double2 *ddst = nullptr;
+    bool dpend = false;
+    auto flush = [&]() __attribute__((always_inline)) {
+        if (dpend) {
+            if (a.flags & 1) {
+                stk_v2d out;
+                out.x = dy0, out.y = dy1;
+                __builtin_nontemporal_store(out, reinterpret_cast<stk_v2d *>(ddst));
+            } else {
+                *ddst = make_double2(dy0, dy1);
+            }
+        }
+        dpend = false;
+    };
     for (; u < uend; u += step) {
         int pos, p;
         const bool valid = locate(u, pos, p);
         uint32_t sl[KS];
 #pragma unroll
         for (int q = 0; q < KS / 4; ++q) {
+            // (the empty statement makes every lane take the wait for the records here)
+            asm volatile("" ::"v"(rec[q].x), "v"(rec[q].y), "v"(rec[q].z), "v"(rec[q].w));
             sl[4 * q] = rec[q].x, sl[4 * q + 1] = rec[q].y, sl[4 * q + 2] = rec[q].z, sl[4 * q + 3] = rec[q].w;
         }
+        flush();
+        // next round's records first: they are older than this round's gathers in
+        // the (in-order) vmcnt queue, so waiting for the gathers never waits for them
+        if (u + step < uend) fetch(u + step);
         const bool g_lo = GHOST && p == 0, g_hi = GHOST && p == W - 1;
         const bool ghost = g_lo || g_hi;
         const int t0 = 2 * (p - (GHOST ? 1 : 0));
@@ -145,7 +170,6 @@ __global__ __launch_bounds__(BS, K >= 12 ? 4 : 6) void kron_wave_kernel(const Wa
 #pragma unroll
             for (int e = 0; e < K; ++e) xv[e] = make_double2(0.0, 0.0);
         }
-        if (u + step < uend) fetch(u + step);  // next round's records, behind the gathers
 
         double acc0[NT], acc1[NT];
 #pragma unroll
@@ -206,23 +230,19 @@ __global__ __launch_bounds__(BS, K >= 12 ? 4 : 6) void kron_wave_kernel(const Wa
                 y1 += acc1[k];
             }
         }
-        if (valid && !ghost && lane >= 1 && lane <= 62) {
+        dpend = valid && !ghost && lane >= 1 && lane <= 62;
+        if (dpend) {
             if (!has1) y1 = 0.0;  // padding slot stays zero
-            double2 *dst = reinterpret_cast<double2 *>(a.y + (size_t)sl[KS - 1] * a.ld + t0);
+            ddst = reinterpret_cast<double2 *>(a.y + (size_t)sl[KS - 1] * a.ld + t0);
             if (a.beta != 0.0) {
-                const double2 old = *dst;
+                const double2 old = *ddst;
                 y0 = fma(a.beta, old.x, y0);
                 if (has1) y1 = fma(a.beta, old.y, y1);
             }
-            if (a.flags & 1) {
-                stk_v2d out;
-                out.x = y0, out.y = y1;
-                __builtin_nontemporal_store(out, reinterpret_cast<stk_v2d *>(dst));
-            } else {
-                *dst = make_double2(y0, y1);
-            }
+            dy0 = y0, dy1 = y1;
         }
     }
+    flush();
 }
 
 int g_wave_wg_per_cu = 0;

@@ -1,0 +1,233 @@
+// Plan construction behind the C ABI: from the CSR matrices a caller of the
+// reference holds (mpi_shared_mem.py:46-48: int32 pattern, float64 values) to
+// the device-resident forms the Kronecker kernels stream -- union pattern,
+// sliced-ELL copy in a processing order, dictionary of value tuples, packed
+// slot words, per-row records -- so that a host program in any language reaches
+// the fast path of  y = beta*y + sum_k (T_k kron X_k) x  (reference
+// TridiagKronMatMPI / SumMPI, mpi_kron.py:77-90, 204-222) with three calls:
+// stk_kron_plan_create, stk_kron_plan_apply, stk_kron_plan_destroy.
+// The Python classes build the same arrays with NumPy (source/linop.py); tests
+// compare the two bit for bit.
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <vector>
+
+#include "stk_common.h"
+
+struct stk_kron_plan {
+    int32_t M = 0, K = 0, n_mats = 0;
+    bool packed = false;
+    // plain ELL form
+    stk_ell_pattern ell{};
+    std::vector<double *> ell_vals, ovf_vals;
+    // packed + wave forms
+    stk_pack_pattern pack{};
+    stk_wave_pattern wave{};
+    std::vector<void *> owned;  // every device allocation
+    int64_t nnz_union = 0;
+};
+
+namespace {
+
+template <typename T>
+int upload(stk_kron_plan *p, const std::vector<T> &host, T **dev)
+{
+    *dev = nullptr;
+    if (host.empty()) return 0;
+    STK_HIP(hipMalloc((void **)dev, host.size() * sizeof(T)));
+    p->owned.push_back(*dev);
+    STK_HIP(hipMemcpy(*dev, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int build(stk_kron_plan *p, int32_t M, int32_t n_mats, const int32_t *const *indptr, const int32_t *const *indices,
+          const double *const *data, const int32_t *order)
+{
+    p->M = M;
+    p->n_mats = n_mats;
+    // ---- union pattern, row by row, in processing order ------------------------
+    std::vector<int32_t> u_ptr(M + 1, 0), u_idx;
+    std::vector<std::vector<double>> u_val(n_mats);
+    std::vector<int32_t> cols;
+    int kmax = 0;
+    for (int pos = 0; pos < M; ++pos) {
+        const int i = order ? order[pos] : pos;
+        cols.clear();
+        for (int m = 0; m < n_mats; ++m)
+            cols.insert(cols.end(), indices[m] + indptr[m][i], indices[m] + indptr[m][i + 1]);
+        std::sort(cols.begin(), cols.end());
+        cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+        const size_t base = u_idx.size();
+        u_idx.insert(u_idx.end(), cols.begin(), cols.end());
+        for (int m = 0; m < n_mats; ++m) {
+            u_val[m].resize(u_idx.size(), 0.0);
+            for (int e = indptr[m][i]; e < indptr[m][i + 1]; ++e) {
+                const size_t at = std::lower_bound(cols.begin(), cols.end(), indices[m][e]) - cols.begin();
+                u_val[m][base + at] += data[m][e];  // duplicate entries of a row add up, as in CSR arithmetic
+            }
+        }
+        u_ptr[pos + 1] = (int32_t)u_idx.size();
+        kmax = std::max(kmax, (int)cols.size());
+    }
+    p->nnz_union = (int64_t)u_idx.size();
+    static const int slots[] = {5, 7, 9, 12, 16};
+    int K = 16;
+    for (int s : slots)
+        if (s >= kmax) {
+            K = s;
+            break;
+        }
+    p->K = K;
+    // ---- sliced ELL: K slots per row, the rest into an overflow CSR -------------
+    std::vector<int32_t> ell_idx((size_t)M * K), row_ids(M), ovf_ptr(M + 1, 0), ovf_idx;
+    std::vector<std::vector<double>> ell_val(n_mats, std::vector<double>((size_t)M * K, 0.0)), ovf_val(n_mats);
+    for (int pos = 0; pos < M; ++pos) {
+        const int i = order ? order[pos] : pos;
+        row_ids[pos] = i;
+        const int n = u_ptr[pos + 1] - u_ptr[pos];
+        for (int e = 0; e < K; ++e) {
+            ell_idx[(size_t)pos * K + e] = e < n ? u_idx[u_ptr[pos] + e] : i;  // unused: own column, value 0
+            if (e < n)
+                for (int m = 0; m < n_mats; ++m) ell_val[m][(size_t)pos * K + e] = u_val[m][u_ptr[pos] + e];
+        }
+        for (int e = K; e < n; ++e) {
+            ovf_idx.push_back(u_idx[u_ptr[pos] + e]);
+            for (int m = 0; m < n_mats; ++m) ovf_val[m].push_back(u_val[m][u_ptr[pos] + e]);
+        }
+        ovf_ptr[pos + 1] = (int32_t)ovf_idx.size();
+    }
+    const bool overflow = !ovf_idx.empty();
+    int32_t *d_idx, *d_rows, *d_optr = nullptr, *d_oidx = nullptr;
+    if (upload(p, ell_idx, &d_idx) || upload(p, row_ids, &d_rows)) return 1;
+    if (overflow && (upload(p, ovf_ptr, &d_optr) || upload(p, ovf_idx, &d_oidx))) return 1;
+    p->ell = stk_ell_pattern{M, K, d_idx, order ? d_rows : nullptr, d_optr, d_oidx};
+    p->ell_vals.resize(n_mats);
+    p->ovf_vals.assign(n_mats, nullptr);
+    for (int m = 0; m < n_mats; ++m) {
+        if (upload(p, ell_val[m], &p->ell_vals[m])) return 1;
+        if (overflow && upload(p, ovf_val[m], &p->ovf_vals[m])) return 1;
+    }
+    // ---- dictionary of value tuples, packed slots, row records ------------------
+    if (overflow) return 0;
+    int col_bits = 1;
+    while (((int64_t)1 << col_bits) < M) ++col_bits;
+    const int64_t max_codes = std::min<int64_t>((int64_t)1 << (32 - col_bits), 2048);
+    std::map<std::vector<uint64_t>, uint32_t> dict;  // bit patterns: +0.0 and -0.0 stay apart
+    std::vector<uint32_t> code((size_t)M * K);
+    std::vector<uint64_t> key(n_mats);
+    for (size_t s = 0; s < (size_t)M * K; ++s) {
+        for (int m = 0; m < n_mats; ++m) std::memcpy(&key[m], &ell_val[m][s], 8);
+        auto it = dict.find(key);
+        if (it == dict.end()) {
+            if ((int64_t)dict.size() >= max_codes) return 0;  // too many distinct tuples: plain form only
+            it = dict.emplace(key, (uint32_t)dict.size()).first;
+        }
+        code[s] = it->second;
+    }
+    // codes in the order of the tuples' bit patterns (what np.unique gives the Python planner)
+    std::vector<uint32_t> rank(dict.size());
+    {
+        uint32_t r = 0;
+        for (auto &kv : dict) rank[kv.second] = r++;
+    }
+    const int n_codes = (int)dict.size();
+    std::vector<double> table((size_t)n_mats * n_codes);
+    for (auto &kv : dict)
+        for (int m = 0; m < n_mats; ++m) std::memcpy(&table[(size_t)m * n_codes + rank[kv.second]], &kv.first[m], 8);
+    const int KS = ((K + 1) + 3) & ~3;
+    std::vector<uint32_t> slots_w((size_t)M * K), recs((size_t)M * KS, 0u);
+    for (int pos = 0; pos < M; ++pos) {
+        for (int e = 0; e < K; ++e) {
+            const size_t s = (size_t)pos * K + e;
+            const uint32_t w = (rank[code[s]] << col_bits) | (uint32_t)ell_idx[s];
+            slots_w[s] = w;
+            recs[(size_t)pos * KS + e] = w;
+        }
+        recs[(size_t)pos * KS + KS - 1] = (uint32_t)row_ids[pos];
+    }
+    uint32_t *d_slots, *d_recs;
+    double *d_dict;
+    if (upload(p, slots_w, &d_slots) || upload(p, recs, &d_recs) || upload(p, table, &d_dict)) return 1;
+    p->pack = stk_pack_pattern{M, K, col_bits, n_codes, n_mats, d_slots, order ? d_rows : nullptr, d_dict};
+    p->wave = stk_wave_pattern{M, K, col_bits, n_codes, n_mats, d_recs, d_dict};
+    p->packed = true;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int stk_kron_plan_create(int32_t M, int32_t n_mats, const int32_t *const *indptr_host,
+                                    const int32_t *const *indices_host, const double *const *data_host,
+                                    const int32_t *row_order_host, stk_kron_plan **out)
+{
+    STK_REQUIRE(M > 0 && n_mats >= 1 && n_mats <= 8 && indptr_host && indices_host && data_host && out,
+                "stk_kron_plan_create: bad arguments");
+    for (int m = 0; m < n_mats; ++m)
+        STK_REQUIRE(indptr_host[m] && indices_host[m] && data_host[m] && indptr_host[m][0] == 0,
+                    "stk_kron_plan_create: matrix %d incomplete", m);
+    if (row_order_host) {
+        std::vector<char> seen(M, 0);
+        for (int pos = 0; pos < M; ++pos) {
+            const int i = row_order_host[pos];
+            STK_REQUIRE(i >= 0 && i < M && !seen[i], "stk_kron_plan_create: row_order is not a permutation");
+            seen[i] = 1;
+        }
+    }
+    for (int m = 0; m < n_mats; ++m)
+        for (int32_t e = 0; e < indptr_host[m][M]; ++e)
+            STK_REQUIRE(indices_host[m][e] >= 0 && indices_host[m][e] < M,
+                        "stk_kron_plan_create: matrix %d has column %d outside 0..%d", m, indices_host[m][e], M - 1);
+    stk_kron_plan *p = new stk_kron_plan();
+    const int rc = build(p, M, n_mats, indptr_host, indices_host, data_host, row_order_host);
+    if (rc) {
+        stk_kron_plan_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return 0;
+}
+
+extern "C" int stk_kron_plan_destroy(stk_kron_plan *p)
+{
+    if (!p) return 0;
+    for (void *d : p->owned) (void)hipFree(d);
+    delete p;
+    return 0;
+}
+
+extern "C" int stk_kron_plan_info(const stk_kron_plan *p, int32_t *K, int32_t *n_codes, int32_t *packed,
+                                  int64_t *nnz_union)
+{
+    STK_REQUIRE(p, "stk_kron_plan_info: null plan");
+    if (K) *K = p->K;
+    if (n_codes) *n_codes = p->packed ? p->pack.n_codes : 0;
+    if (packed) *packed = p->packed ? 1 : 0;
+    if (nnz_union) *nnz_union = p->nnz_union;
+    return 0;
+}
+
+extern "C" int stk_kron_plan_apply(stk_kron_plan *p, void *stream, int32_t n_loc, int32_t ld, int32_t n_terms,
+                                   const stk_kron_pack_term *t, const double *x, const double *x_lo,
+                                   const double *x_hi, double *ghost_work, double beta, double *y)
+{
+    STK_REQUIRE(p && t && x && y, "stk_kron_plan_apply: null pointer");
+    STK_REQUIRE(n_terms >= 1 && n_terms <= 3, "stk_kron_plan_apply: n_terms=%d not in 1..3", n_terms);
+    for (int k = 0; k < n_terms; ++k)
+        STK_REQUIRE(t[k].mat >= 0 && t[k].mat < p->n_mats, "stk_kron_plan_apply: term %d names matrix %d of %d", k,
+                    t[k].mat, p->n_mats);
+    const bool ghosts = x_lo || x_hi;
+    if (p->packed) {
+        if (ghosts) {
+            STK_REQUIRE(ghost_work, "stk_kron_plan_apply: ghost rows need ghost_work (2*M doubles)");
+            int rc = stk_interleave_ghosts(stream, p->M, x_lo, x_hi, ghost_work);
+            if (rc) return rc;
+        }
+        return stk_kron_pack_apply(stream, &p->pack, n_loc, ld, n_terms, t, x, ghosts ? ghost_work : nullptr, beta,
+                                   y);
+    }
+    stk_kron_ell_term terms[3];
+    for (int k = 0; k < n_terms; ++k)
+        terms[k] = stk_kron_ell_term{t[k].tri, p->ell_vals[t[k].mat], p->ovf_vals[t[k].mat], x, x_lo, x_hi};
+    return stk_kron_ell_apply(stream, &p->ell, n_loc, ld, n_terms, terms, beta, y);
+}

@@ -34,8 +34,9 @@ class LinearOperatorMPI:
     (reference mpi_kron.py:13-59)."""
 
     # The reference times every apply with MPI.Wtime.  Kernels are
-    # asynchronous; set this to True (the timing driver does) to bracket each
-    # apply with a device synchronisation so that time_applies is wall time.
+    # asynchronous; set this to True (the drivers do) and every apply is timed
+    # on the device with a pair of HIP events, so that time_applies is the time
+    # the GPU spent on it.
     sync_timing = False
 
     def __init__(self, dofs_distr):
@@ -48,16 +49,23 @@ class LinearOperatorMPI:
 
     def __matmul__(self, x):
         assert isinstance(x, KronVectorMPI)
-        if LinearOperatorMPI.sync_timing:
-            torch.cuda.synchronize()
-        start_time = MPI.Wtime()
-
+        if not LinearOperatorMPI.sync_timing:
+            start_time = MPI.Wtime()
+            y = self._matvec(x, x._like())
+            self.num_applies += 1
+            self.time_applies += MPI.Wtime() - start_time  # enqueue time only
+            return y
+        # device time of the apply: HIP events on the stream the kernels are
+        # launched on, bracketing everything _matvec enqueues (and the gaps in
+        # which the host waits for a halo)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
         y = self._matvec(x, x._like())
-
-        if LinearOperatorMPI.sync_timing:
-            torch.cuda.synchronize()
+        e1.record()
+        e1.synchronize()
         self.num_applies += 1
-        self.time_applies += MPI.Wtime() - start_time
+        self.time_applies += e0.elapsed_time(e1) * 1e-3
         return y
 
     def time_per_apply(self):

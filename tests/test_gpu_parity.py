@@ -1180,3 +1180,67 @@ def test_coupling_bands_are_verified(stk):
         stk.check(stk.lib().stk_set_tuning(b'mg_strip_width', 2))
     want = OracleMG(B, prolongation_matrices(mesh), 3, 2) @ F
     assert relerr(got, want) < 1e-12
+
+
+def _decode_blob(text):
+    """The reference's result record: base64(zlib(pickle(per-rank list)))
+    printed as 'data: ...' (heateq_mpi.py:308-312, heateq_mpi_timing.py:124-128)."""
+    import base64
+    import pickle
+    import zlib
+    line = [ln for ln in text.splitlines() if ln.startswith('data: ')][-1]
+    return pickle.loads(zlib.decompress(base64.b64decode(line[len('data: '):])))
+
+
+def test_driver_telemetry_records(stk, capsys):
+    """Row f3: the timing driver and the solve driver print the reference's
+    fields and gather the per-rank record into the base64 blob (reference
+    heateq_mpi_timing.py:62-128, heateq_mpi.py:259-312).  The blob is decoded and
+    its per-operator keys, apply counts and timings (HIP events on the launch
+    stream) are checked."""
+    import heateq_mpi
+    import heateq_mpi_timing
+    from source.mpi_kron import LinearOperatorMPI
+    iters = 3
+    try:
+        heateq_mpi_timing.main(['--J_time=3', '--J_space=3', '--iters=%d' % iters])
+        out = capsys.readouterr().out
+        for field in ('Creating mesh with 3 time refines and 3 space refines.',
+                      'N = 9. M = 225.', 'Constructed bilinear forms in',
+                      'Completed %d iters steps.' % iters, 'Total time:'):
+            assert field in out, field
+        for name in ('W:  ', 'S:  ', 'WT: ', 'P:  '):  # print_time_per_apply
+            assert name in out
+        ranks = _decode_blob(out)
+        assert len(ranks) == 1 and ranks[0]['rank'] == 0
+        rec = ranks[0]
+        assert rec['time_total'] > 0 and rec['mem_after_timing'] > 0
+        for name in ('W', 'S', 'WT', 'P'):
+            r = rec[name]
+            assert sorted(r) == ['num_applies', 'time_applies', 'time_applies_iter',
+                                 'time_communication', 'time_communication_iter',
+                                 'time_total']
+            assert r['num_applies'] == iters
+            assert len(r['time_applies_iter']) == iters == len(r['time_communication_iter'])
+            assert all(t > 0 for t in r['time_applies_iter'])
+            assert abs(sum(r['time_applies_iter']) - r['time_applies']) < 1e-9
+            assert r['time_communication'] == 0  # one rank: no halo
+            assert r['time_total'] >= r['time_applies']
+        # device times: S (two multigrid applies inside) costs more than W
+        assert rec['S']['time_applies'] > rec['W']['time_applies']
+
+        h, w, its, hist = heateq_mpi.main(['--J_time=3', '--J_space=3'])
+        out = capsys.readouterr().out
+        assert 'Completed in %d PCG steps.' % its in out and 'Total solve time:' in out
+        rec = _decode_blob(out)[0]
+        assert rec['iters'] == its and len(rec['r_dot_Pr']) == its + 1
+        assert rec['N'] == 9 and rec['M'] == 225 and rec['args']['J_time'] == 3
+        assert rec['solve_time'] > 0 and rec['mem_after_solve'] > 0
+        # PCG applies T once for the initial residual and once per iteration; P alike
+        # (reference linalg.py:20-34)
+        for name in ('W', 'S', 'WT', 'WT_S_W', 'P'):
+            assert rec[name]['num_applies'] == its + 1, (name, rec[name])
+            assert rec[name]['time_applies'] > 0
+        assert rec['WT_S_W']['time_applies'] >= rec['S']['time_applies']
+    finally:
+        LinearOperatorMPI.sync_timing = False
