@@ -237,6 +237,36 @@ int stk_kron_wave_apply(void *stream, const stk_wave_pattern *pattern_host,
                         const stk_kron_pack_term *terms_host, const double *x,
                         const double *ghosts, double beta, double *y);
 
+/* ---- plan construction from CSR (no Python needed) ---------------------------
+ * Everything the three forms above stream is derived here, on the host side of
+ * the library, from the CSR matrices a caller of the reference holds
+ * (mpi_shared_mem.py:46-48; TridiagKronMatMPI keeps references to them,
+ * mpi_kron.py:209-210): union pattern of the n_mats matrices, K = the smallest
+ * instantiated slot count that holds the longest row (overflow CSR beyond 16),
+ * rows listed in `row_order_host` (a permutation of 0..M-1, e.g. a mesh-tile or
+ * RCM order; NULL = index order), the dictionary of distinct value tuples and
+ * the packed slot words when the tuples fit.  All arrays are HOST pointers;
+ * the plan owns its device copies.  stk_kron_plan_apply runs
+ *   y = beta*y + sum_k (T_k kron X_{t[k].mat}) x
+ * on the fastest form the plan has; x_lo / x_hi are the ghost time rows
+ * (device, length M, or NULL) and ghost_work 2*M device doubles of scratch,
+ * needed when either is given. */
+typedef struct stk_kron_plan stk_kron_plan;
+int stk_kron_plan_create(int32_t M, int32_t n_mats,
+                         const int32_t *const *indptr_host,
+                         const int32_t *const *indices_host,
+                         const double *const *data_host,
+                         const int32_t *row_order_host, stk_kron_plan **out);
+int stk_kron_plan_destroy(stk_kron_plan *plan);
+/* Any output may be NULL.  packed = 1 if the dictionary form was built. */
+int stk_kron_plan_info(const stk_kron_plan *plan, int32_t *K, int32_t *n_codes,
+                       int32_t *packed, int64_t *nnz_union);
+int stk_kron_plan_apply(stk_kron_plan *plan, void *stream, int32_t n_loc,
+                        int32_t ld, int32_t n_terms,
+                        const stk_kron_pack_term *terms_host, const double *x,
+                        const double *x_lo, const double *x_hi,
+                        double *ghost_work, double beta, double *y);
+
 /* Diagnostic: while `buf` (device, at least 8 * grid * 4 words) is non-NULL,
  * the headline instantiation (2 terms, K = 7, no ghosts) runs a stamped build
  * that leaves, per wavefront, the shader-clock cycles spent in the four

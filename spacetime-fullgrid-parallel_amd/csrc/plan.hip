@@ -6,8 +6,9 @@
 // the fast path of  y = beta*y + sum_k (T_k kron X_k) x  (reference
 // TridiagKronMatMPI / SumMPI, mpi_kron.py:77-90, 204-222) with three calls:
 // stk_kron_plan_create, stk_kron_plan_apply, stk_kron_plan_destroy.
-// The Python classes build the same arrays with NumPy (source/linop.py); tests
-// compare the two bit for bit.
+// The Python classes build the same forms with NumPy (source/linop.py); tests
+// compare the results of the two bit for bit (the numbering of the dictionary
+// codes may differ, the products and their order do not).
 #include <algorithm>
 #include <cstring>
 #include <map>
@@ -125,7 +126,7 @@ int build(stk_kron_plan *p, int32_t M, int32_t n_mats, const int32_t *const *ind
         }
         code[s] = it->second;
     }
-    // codes in the order of the tuples' bit patterns (what np.unique gives the Python planner)
+    // codes numbered in the order of the tuples' bit patterns (deterministic)
     std::vector<uint32_t> rank(dict.size());
     {
         uint32_t r = 0;

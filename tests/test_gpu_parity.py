@@ -1244,3 +1244,115 @@ def test_driver_telemetry_records(stk, capsys):
         assert rec['WT_S_W']['time_applies'] >= rec['S']['time_applies']
     finally:
         LinearOperatorMPI.sync_timing = False
+
+
+def test_kron_plan_from_csr_through_ctypes_only(stk):
+    """Row b: the fast path without any Python planner.  stk_kron_plan_create
+    gets the host CSR arrays of the factors (and a row order), builds union
+    pattern, sliced ELL, dictionary and packed words inside libstk, and
+    stk_kron_plan_apply runs the operator -- only ctypes calls and device
+    buffers here.  Against dense NumPy, and bit for bit against the Python-planned
+    forms; matrices with too many distinct values / over-long rows take the plain
+    ELL form inside the same call."""
+    import ctypes
+    from source.linop import EllMatrices
+    lib = stk.lib()
+    rng = np.random.RandomState(99)
+    for case in range(12):
+        M = int(rng.randint(5, 500))
+        n_loc = int(rng.choice([1, 4, 9, 16, 33]))
+        ld = n_loc + (n_loc & 1)
+        n_mats = int(rng.randint(1, 4))
+        width = int(rng.choice([3, 6, 9, 14, 20]))  # 20: overflow rows
+        base = sp.csr_matrix(sp.random(M, M, density=min(1.0, width / M),
+                                       random_state=rng, format='csr') + sp.eye(M))
+        few = case % 2 == 0  # dictionary-sized value sets on even cases
+        palette = rng.randn(5)
+        mats = []
+        for k in range(n_mats):
+            m = base.copy()
+            m.data = (palette[rng.randint(5, size=m.nnz)] if few else rng.rand(m.nnz))
+            if k == 1:  # patterns differ: drop some entries of the second matrix
+                m.data[rng.rand(m.nnz) < 0.3] = 0.0
+                m.eliminate_zeros()
+            m.sort_indices()
+            mats.append(m)
+        order = rng.permutation(M).astype(np.int32) if case % 3 else None
+        keep = [(m.indptr.astype(np.int32), m.indices.astype(np.int32),
+                 m.data.astype(np.float64)) for m in mats]
+        arr = lambda j: (ctypes.c_void_p * n_mats)(*[k[j].ctypes.data for k in keep])
+        plan = ctypes.c_void_p()
+        stk.check(lib.stk_kron_plan_create(
+            M, n_mats, arr(0), arr(1), arr(2),
+            None if order is None else order.ctypes.data, ctypes.byref(plan)))
+        K, nc, packed = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        nnz = ctypes.c_int64()
+        stk.check(lib.stk_kron_plan_info(plan, ctypes.byref(K), ctypes.byref(nc),
+                                         ctypes.byref(packed), ctypes.byref(nnz)))
+        pattern = sum(sp.csr_matrix((np.ones(m.nnz), m.indices, m.indptr), shape=m.shape)
+                      for m in mats)
+        assert nnz.value == sp.csr_matrix(pattern).nnz
+        nt = int(rng.randint(1, 4))
+        X, y0 = rng.rand(M, n_loc), rng.rand(M, n_loc)
+        lo = rng.rand(M) if rng.randint(2) else None
+        hi = rng.rand(M) if rng.randint(2) else None
+        beta = float(rng.choice([0.0, 0.5]))
+        terms = (stk.KronPackTerm * nt)()
+        want, keep_tri = beta * y0, []
+        for k in range(nt):
+            mat = int(rng.randint(n_mats))
+            t = rng.rand(3, n_loc)
+            T = np.diag(t[1]) + np.diag(t[0, 1:], -1) + np.diag(t[2, :-1], 1)
+            dev = _lib_dev(t)
+            keep_tri.append(dev)
+            terms[k].tri, terms[k].mat = dev.data_ptr(), mat
+            want = want + (mats[mat] @ X) @ T.T
+            if lo is not None:
+                want[:, 0] += t[0, 0] * (mats[mat] @ lo)
+            if hi is not None:
+                want[:, -1] += t[2, -1] * (mats[mat] @ hi)
+
+        def slab(a):
+            s_ = torch.zeros((M, ld), dtype=torch.float64, device='cuda')
+            s_[:, :n_loc] = torch.from_numpy(a).cuda()
+            return s_
+
+        x, y = slab(X), slab(y0)
+        glo = None if lo is None else torch.from_numpy(lo).cuda()
+        ghi = None if hi is None else torch.from_numpy(hi).cuda()
+        work = torch.empty((M, 2), dtype=torch.float64, device='cuda')
+        stk.check(lib.stk_kron_plan_apply(plan, stk.stream(), n_loc, ld, nt, terms,
+                                          stk.ptr(x), stk.ptr(glo), stk.ptr(ghi),
+                                          stk.ptr(work), beta, stk.ptr(y)))
+        got = y[:, :n_loc].cpu().numpy()
+        assert relerr(got, want) < 1e-13, (case, M, n_loc, n_mats, width, few)
+        if ld > n_loc:
+            assert float(y[:, n_loc:].abs().max()) == 0.0
+        # the Python-planned form of the same matrices, same row order
+        if order is not None:
+            for m in mats:
+                m.stk_row_order = order
+        ell = EllMatrices(mats)
+        assert ell.K == K.value and ell.packed.ok == bool(packed.value)
+        y_py = slab(y0)
+        specs = [(keep_tri[k], terms[k].mat) for k in range(nt)]
+        if ell.packed.ok:
+            gh = None
+            if glo is not None or ghi is not None:
+                gh = torch.empty((M, 2), dtype=torch.float64, device='cuda')
+                stk.check(lib.stk_interleave_ghosts(stk.stream(), M, stk.ptr(glo),
+                                                    stk.ptr(ghi), stk.ptr(gh)))
+            ell.packed.apply(specs, x, gh, n_loc, ld, beta, y_py)
+        else:
+            ell.apply([(tri, k, x, glo, ghi) for tri, k in specs], n_loc, ld, beta, y_py)
+        assert torch.equal(y, y_py), (case, float((y - y_py).abs().max()))
+        stk.check(lib.stk_kron_plan_destroy(plan))
+    # argument errors come back as status + message, not as a crash
+    plan = ctypes.c_void_p()
+    bad = np.array([0, 0, 1], dtype=np.int32)  # not a permutation
+    m = sp.identity(3, format='csr')
+    ip, ix, dv = m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data
+    one = lambda a: (ctypes.c_void_p * 1)(a.ctypes.data)
+    assert lib.stk_kron_plan_create(3, 1, one(ip), one(ix), one(dv), bad.ctypes.data,
+                                    ctypes.byref(plan)) != 0
+    assert b'permutation' in lib.stk_last_error()
