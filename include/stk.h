@@ -188,55 +188,6 @@ int stk_kron_pack_apply(void *stream, const stk_pack_pattern *pattern_host,
                         const stk_kron_pack_term *terms_host, const double *x,
                         const double *ghosts, double beta, double *y);
 
-/* The same operator, TILE-STAGED (csrc/kron_tile.hip): rows are grouped into
- * tiles of consecutive rows of the processing order; rows [tile_row_ptr[t],
- * tile_row_ptr[t+1]) of tile t only reference the columns
- * tile_cols[tile_col_ptr[t] .. tile_col_ptr[t+1]), which a workgroup copies to
- * LDS once (prefetched a tile ahead).  slots[pos*K + e] = code << 7 | index of
- * the column in its tile's list; dictionary, terms and ghosts as for
- * stk_kron_pack_apply.  The plan depends on the slab length through the LDS
- * footprint: nc_max * ceil(n_loc / 2) must not exceed 3072 (16-byte pieces
- * staged per tile) and the launch refuses more than 64 KiB of LDS.
- * Tuning keys: "tile_wg_per_cu", "tile_flags" (bit 0: non-temporal y stores). */
-typedef struct {
-    int32_t M, K;
-    int32_t n_tiles;
-    int32_t nc_max; /* most columns of a tile, <= 128 */
-    int32_t tr_max; /* most rows of a tile, tr_max * K <= 512 */
-    int32_t n_codes, n_mats; /* n_codes <= 512 */
-    const int32_t *tile_row_ptr; /* n_tiles + 1 */
-    const int32_t *tile_col_ptr; /* n_tiles + 1 */
-    const int32_t *tile_cols;
-    const uint16_t *slots;  /* M*K */
-    const int32_t *row_ids; /* M or NULL */
-    const double *dict;     /* n_mats*n_codes */
-} stk_tile_pattern;
-
-int stk_kron_tile_apply(void *stream, const stk_tile_pattern *pattern_host,
-                        int32_t n_loc, int32_t ld, int32_t n_terms,
-                        const stk_kron_pack_term *terms_host, const double *x,
-                        const double *ghosts, double beta, double *y);
-
-/* The same operator, WAVE-AUTONOMOUS (csrc/kron_wave.hip): no workgroup barrier
- * in the loop; a wavefront owns 62 consecutive (row, time-pair) tasks and gets
- * the neighbouring time steps' sums by DPP wave shifts.  recs holds one record
- * of KS = round_up(K + 1, 4) 32-bit words per row of the processing order: the K
- * slot words `code << col_bits | column` of stk_kron_pack_apply, padding, and
- * the output row id in the last word.  Dictionary, terms and ghosts as there.
- * Tuning keys: "wave_wg_per_cu", "wave_block" (256 / 512), "wave_flags" (bit 0:
- * non-temporal y stores). */
-typedef struct {
-    int32_t M, K;
-    int32_t col_bits, n_codes, n_mats;
-    const uint32_t *recs; /* M * round_up(K + 1, 4), 16-byte aligned */
-    const double *dict;   /* n_mats*n_codes */
-} stk_wave_pattern;
-
-int stk_kron_wave_apply(void *stream, const stk_wave_pattern *pattern_host,
-                        int32_t n_loc, int32_t ld, int32_t n_terms,
-                        const stk_kron_pack_term *terms_host, const double *x,
-                        const double *ghosts, double beta, double *y);
-
 /* ---- plan construction from CSR (no Python needed) ---------------------------
  * Everything the three forms above stream is derived here, on the host side of
  * the library, from the CSR matrices a caller of the reference holds

@@ -16,20 +16,22 @@ void stk_set_error(const char *fmt, ...)
 
 extern "C" const char *stk_last_error(void) { return g_err; }
 
-extern "C" int stk_version(void) { return 100; }
+extern "C" int stk_version(void) { return 200; }
 
 int stk_cu_count()
 {
-    static int cached = 0;
-    if (cached == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-            cached = n;
+    // per device (one process may drive several), queried once per device and thread
+    static thread_local int cached[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            cached[dev] = n;
         else
-            cached = 256;
+            cached[dev] = 256;
     }
-    return cached;
+    return cached[dev];
 }
 
 extern "C" int stk_device_info(int32_t *n_cu, int32_t *wave_size, int64_t *hbm_bytes)

@@ -20,8 +20,6 @@
 
 int stk_kron_ell_set_tuning(const char *key, int32_t value);  // kron_ell.hip
 int stk_kron_pack_set_tuning(const char *key, int32_t value);  // kron_pack.hip
-int stk_kron_tile_set_tuning(const char *key, int32_t value);  // kron_tile.hip
-int stk_kron_wave_set_tuning(const char *key, int32_t value);  // kron_wave.hip
 int stk_rows_ell_set_tuning(const char *key, int32_t value);  // rows_ell.hip
 int stk_wavelet_set_tuning(const char *key, int32_t value);   // wavelet.hip
 extern int g_mg_fuse_coarse, g_mg_coarse_max_rows, g_mg_fuse_restrict, g_mg_zero_start, g_mg_strip_mb, g_mg_strips_used, g_mg_strip_width;  // mg.hip
@@ -410,8 +408,6 @@ extern "C" int stk_set_tuning(const char *key, int32_t value)
     }
     if (stk_kron_ell_set_tuning(key, value) == 0) return 0;
     if (stk_kron_pack_set_tuning(key, value) == 0) return 0;
-    if (stk_kron_tile_set_tuning(key, value) == 0) return 0;
-    if (stk_kron_wave_set_tuning(key, value) == 0) return 0;
     if (stk_rows_ell_set_tuning(key, value) == 0) return 0;
     if (stk_wavelet_set_tuning(key, value) == 0) return 0;
     if (std::strcmp(key, "mg_strip_mb") == 0) {

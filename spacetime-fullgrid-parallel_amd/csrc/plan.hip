@@ -2,7 +2,7 @@
 // reference holds (mpi_shared_mem.py:46-48: int32 pattern, float64 values) to
 // the device-resident forms the Kronecker kernels stream -- union pattern,
 // sliced-ELL copy in a processing order, dictionary of value tuples, packed
-// slot words, per-row records -- so that a host program in any language reaches
+// slot words -- so that a host program in any language reaches
 // the fast path of  y = beta*y + sum_k (T_k kron X_k) x  (reference
 // TridiagKronMatMPI / SumMPI, mpi_kron.py:77-90, 204-222) with three calls:
 // stk_kron_plan_create, stk_kron_plan_apply, stk_kron_plan_destroy.
@@ -22,9 +22,8 @@ struct stk_kron_plan {
     // plain ELL form
     stk_ell_pattern ell{};
     std::vector<double *> ell_vals, ovf_vals;
-    // packed + wave forms
+    // packed form
     stk_pack_pattern pack{};
-    stk_wave_pattern wave{};
     std::vector<void *> owned;  // every device allocation
     int64_t nnz_union = 0;
 };
@@ -136,22 +135,12 @@ int build(stk_kron_plan *p, int32_t M, int32_t n_mats, const int32_t *const *ind
     std::vector<double> table((size_t)n_mats * n_codes);
     for (auto &kv : dict)
         for (int m = 0; m < n_mats; ++m) std::memcpy(&table[(size_t)m * n_codes + rank[kv.second]], &kv.first[m], 8);
-    const int KS = ((K + 1) + 3) & ~3;
-    std::vector<uint32_t> slots_w((size_t)M * K), recs((size_t)M * KS, 0u);
-    for (int pos = 0; pos < M; ++pos) {
-        for (int e = 0; e < K; ++e) {
-            const size_t s = (size_t)pos * K + e;
-            const uint32_t w = (rank[code[s]] << col_bits) | (uint32_t)ell_idx[s];
-            slots_w[s] = w;
-            recs[(size_t)pos * KS + e] = w;
-        }
-        recs[(size_t)pos * KS + KS - 1] = (uint32_t)row_ids[pos];
-    }
-    uint32_t *d_slots, *d_recs;
+    std::vector<uint32_t> slots_w((size_t)M * K);
+    for (size_t s = 0; s < (size_t)M * K; ++s) slots_w[s] = (rank[code[s]] << col_bits) | (uint32_t)ell_idx[s];
+    uint32_t *d_slots;
     double *d_dict;
-    if (upload(p, slots_w, &d_slots) || upload(p, recs, &d_recs) || upload(p, table, &d_dict)) return 1;
+    if (upload(p, slots_w, &d_slots) || upload(p, table, &d_dict)) return 1;
     p->pack = stk_pack_pattern{M, K, col_bits, n_codes, n_mats, d_slots, order ? d_rows : nullptr, d_dict};
-    p->wave = stk_wave_pattern{M, K, col_bits, n_codes, n_mats, d_recs, d_dict};
     p->packed = true;
     return 0;
 }

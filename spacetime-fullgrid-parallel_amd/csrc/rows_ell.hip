@@ -116,33 +116,8 @@ __global__ __launch_bounds__(BS, K >= 12 ? 4 : 6) void rows_ell_kernel(const Row
     };
     if (g < gend) load_group(g);
 
-    // Results of the previous group, stored one iteration late.  vmcnt counts in
-    // order: a wait for the prefetched entries issued AFTER a store also waits for
-    // that store to complete, a full store round trip at the top of every
-    // iteration.  So the entries are taken over first (every lane takes that wait,
-    // see the empty statements below), then the deferred store goes out and
-    // overlaps with this group's gathers.  Rows of one launch never read each
-    // other's results (one Gauss-Seidel dependency group / y distinct from x), so
-    // the delay is invisible.
-    double d0 = 0.0, d1 = 0.0;
-    uint32_t dyo = 0;
-    bool dpend = false;
-    auto flush = [&]() __attribute__((always_inline)) {
-        if (dpend) sy.store(dyo, t0_bytes, make_double2(d0, d1));
-        dpend = false;
-    };
     int flip = 0;
     for (; g < gend; g += step, flip ^= 1) {
-#pragma unroll
-        for (int q = 0; q < NPF; ++q) {
-            asm volatile("" ::"v"(pidx[q]), "v"(pva[q]));
-            if (HAS_M) asm volatile("" ::"v"(pvm[q]));
-        }
-        asm volatile("" ::"v"(prow));
-        if (MODE == MODE_GS) {
-            asm volatile("" ::"v"(pda));
-            if (HAS_M) asm volatile("" ::"v"(pdm));
-        }
         double *b_va = sm + flip * buf_doubles;
         double *b_vm = b_va + R * KS;
         double *b_da = b_va + (HAS_M ? 2 : 1) * R * KS;
@@ -169,7 +144,6 @@ __global__ __launch_bounds__(BS, K >= 12 ? 4 : 6) void rows_ell_kernel(const Row
             }
         }
         __syncthreads();
-        flush();
         if (g + step < gend) load_group(g + step);  // in flight behind the gathers
 
         if (lane_ok && r < rows) {
@@ -224,10 +198,9 @@ __global__ __launch_bounds__(BS, K >= 12 ? 4 : 6) void rows_ell_kernel(const Row
                 }
             }
             if (!has1) o1 = 0.0;  // padding slot stays zero
-            d0 = o0, d1 = o1, dyo = yo, dpend = true;
+            sy.store(yo, t0_bytes, make_double2(o0, o1));
         }
     }
-    flush();
 }
 
 int g_rows_wg_per_cu = 0;

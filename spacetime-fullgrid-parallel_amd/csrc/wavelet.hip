@@ -208,6 +208,15 @@ int launch_reg(hipStream_t st, int32_t M, int transposed, const double *x, doubl
 {
     const unsigned grid = (unsigned)((M + 63) / 64);
     const size_t lds = sizeof(double) * 64 * WConst<J>::LD;
+    if (lds > 64 * 1024) {
+        // J = 7: 66 560 bytes of dynamic LDS, above the 64 KiB a kernel gets without
+        // asking (the device has 160 KiB per CU); the attribute belongs to the
+        // function on the current device, so it is set on every launch (cheap)
+        STK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wavelet_reg_kernel<J, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        STK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wavelet_reg_kernel<J, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     if (transposed)
         hipLaunchKernelGGL((wavelet_reg_kernel<J, true>), dim3(grid), dim3(64), lds, st, M, x, y);
     else

@@ -106,19 +106,33 @@ class SchurMPI(LinearOperatorMPI):
         x = vec_in.buf
         n_loc, ld = vec_in.n_loc, vec_in.ld
         u = torch.empty_like(x)
-        first = [(self.tA, 0, x, None, None), (self.tL, 1, x, None, None)]
-        if self.dofs_distr.size > 1:
-            # slab-local part of the first launch while the halo is in flight
-            self.time_communication = vec_in.communicate_bdr(
-                callback=lambda: self.ell.apply_local(first, n_loc, ld, 0.0, u))
+        if self.ell.packed.ok:
+            # packed matrix stream, ghost time steps fused into the one pass
+            # (csrc/kron_pack.hip); the halo has to be there first
+            ghosts = None
+            if self.dofs_distr.size > 1:
+                self.time_communication = vec_in.communicate_bdr()
+                ghosts = vec_in.ghost_interleaved()
+            self.ell.packed.apply([(self.tA, 0), (self.tL, 1)], x, ghosts,
+                                  n_loc, ld, 0.0, u)
+            v1 = self.Kinv_x.apply(u, n_loc=n_loc)
+            self.ell.packed.apply([(self.tLT, 0), (self.tM, 1)], x, ghosts,
+                                  n_loc, ld, 0.0, u)
+            v2 = self.Kinv_x.apply(u, n_loc=n_loc)
         else:
-            self.ell.apply_local(first, n_loc, ld, 0.0, u)
-        self.ell.apply_ghost([self._spec(self.tA, 0, vec_in),
-                              self._spec(self.tL, 1, vec_in)], n_loc, ld, u)
-        v1 = self.Kinv_x.apply(u, n_loc=n_loc)
-        self.ell.apply([self._spec(self.tLT, 0, vec_in),
-                        self._spec(self.tM, 1, vec_in)], n_loc, ld, 0.0, u)
-        v2 = self.Kinv_x.apply(u, n_loc=n_loc)
+            first = [(self.tA, 0, x, None, None), (self.tL, 1, x, None, None)]
+            if self.dofs_distr.size > 1:
+                # slab-local part of the first launch while the halo is in flight
+                self.time_communication = vec_in.communicate_bdr(
+                    callback=lambda: self.ell.apply_local(first, n_loc, ld, 0.0, u))
+            else:
+                self.ell.apply_local(first, n_loc, ld, 0.0, u)
+            self.ell.apply_ghost([self._spec(self.tA, 0, vec_in),
+                                  self._spec(self.tL, 1, vec_in)], n_loc, ld, u)
+            v1 = self.Kinv_x.apply(u, n_loc=n_loc)
+            self.ell.apply([self._spec(self.tLT, 0, vec_in),
+                            self._spec(self.tM, 1, vec_in)], n_loc, ld, 0.0, u)
+            v2 = self.Kinv_x.apply(u, n_loc=n_loc)
         self.ell.apply([(None, 0, v1, None, None), (None, 1, v2, None, None),
                         self._spec(self.tG, 0, vec_in)], n_loc, ld, 0.0,
                        vec_out.buf)

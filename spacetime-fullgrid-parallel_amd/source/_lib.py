@@ -46,20 +46,6 @@ class PackPattern(ctypes.Structure):
                 ('row_ids', c_p), ('dict', c_p)]
 
 
-class TilePattern(ctypes.Structure):
-    _fields_ = [('M', c_i32), ('K', c_i32), ('n_tiles', c_i32),
-                ('nc_max', c_i32), ('tr_max', c_i32), ('n_codes', c_i32),
-                ('n_mats', c_i32), ('tile_row_ptr', c_p), ('tile_col_ptr', c_p),
-                ('tile_cols', c_p), ('slots', c_p), ('row_ids', c_p),
-                ('dict', c_p)]
-
-
-class WavePattern(ctypes.Structure):
-    _fields_ = [('M', c_i32), ('K', c_i32), ('col_bits', c_i32),
-                ('n_codes', c_i32), ('n_mats', c_i32), ('recs', c_p),
-                ('dict', c_p)]
-
-
 class KronPackTerm(ctypes.Structure):
     _fields_ = [('tri', c_p), ('mat', c_i32)]
 
@@ -118,14 +104,6 @@ _PROTOTYPES = {
     ]),
     'stk_kron_pack_apply': (ctypes.c_int, [
         c_p, ctypes.POINTER(PackPattern), c_i32, c_i32, c_i32,
-        ctypes.POINTER(KronPackTerm), c_p, c_p, c_f64, c_p
-    ]),
-    'stk_kron_tile_apply': (ctypes.c_int, [
-        c_p, ctypes.POINTER(TilePattern), c_i32, c_i32, c_i32,
-        ctypes.POINTER(KronPackTerm), c_p, c_p, c_f64, c_p
-    ]),
-    'stk_kron_wave_apply': (ctypes.c_int, [
-        c_p, ctypes.POINTER(WavePattern), c_i32, c_i32, c_i32,
         ctypes.POINTER(KronPackTerm), c_p, c_p, c_f64, c_p
     ]),
     'stk_interleave_ghosts': (ctypes.c_int, [c_p, c_i32, c_p, c_p, c_p]),

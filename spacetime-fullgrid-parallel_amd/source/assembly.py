@@ -153,48 +153,6 @@ def tile_order_from_coords(coords, rows_per_tile=None, small_lexsort=True):
     return np.lexsort(lex + tiles).astype(np.int32)
 
 
-def patch_order_from_coords(coords, rows_per_tile=None, strip_rows=5):
-    """Processing order for the tile-staged Kronecker kernel (csrc/kron_tile.hip),
-    and the strip every point lies in.  Macro tiles as in tile_order_from_coords
-    (so that an XCD's working set stays in its L2); inside a macro tile the
-    points are grouped into strips about `strip_rows` vertex spacings high along
-    the last axis and listed column by column inside a strip: any run of
-    consecutive points of a strip is then a compact patch, whose rows reference
-    about 2 distinct columns each instead of 7.  Returns (order, strip) with
-    strip[i] = id of the strip point i belongs to (ids ascend along the order).
-    Purely a performance hint; results never depend on it."""
-    rows_per_tile = _rows_per_tile(rows_per_tile)
-    p = np.asarray(coords)
-    n, d = p.shape
-    lo, hi = p.min(axis=0), p.max(axis=0)
-    ext = np.maximum(hi - lo, 1e-30)
-    spacing = (np.prod(ext) / max(n, 1))**(1.0 / d)
-    ntiles = max(1.0, n / float(rows_per_tile))
-    side = (np.prod(ext) / ntiles)**(1.0 / d)
-    # whole macro tiles along every axis, whole strips inside a macro tile: no
-    # thin leftovers (a strip one vertex high would make very wide tiles)
-    eps = 1e-9
-    nt = np.maximum(1, np.round(ext / side)).astype(np.int64)
-    sides = ext * (1.0 + eps) / nt
-    tiles = [np.minimum(np.floor((p[:, k] - lo[k]) / sides[k]).astype(np.int64), nt[k] - 1)
-             for k in range(d)]
-    ns = max(1, int(round(sides[d - 1] / (strip_rows * spacing))))
-    local = (p[:, d - 1] - lo[d - 1]) - tiles[d - 1] * sides[d - 1]
-    strip = np.minimum(np.floor(local / (sides[d - 1] / ns)).astype(np.int64), ns - 1)
-    # primary key last: tile (slowest axis first), strip, then the fast axes, the
-    # strip's own axis (the last one) varying fastest
-    keys = (p[:, d - 1],) + tuple(p[:, k] for k in range(d - 2, -1, -1)) + (strip,) + tuple(tiles)
-    order = np.lexsort(keys)
-    # consecutive ids along the order
-    s_sorted = np.stack([t[order] for t in tiles] + [strip[order]], axis=1)
-    change = np.ones(n, dtype=np.int64)
-    change[1:] = (np.diff(s_sorted, axis=0) != 0).any(axis=1)
-    ids = np.cumsum(change) - 1
-    strip_id = np.empty(n, dtype=np.int64)
-    strip_id[order] = ids
-    return order.astype(np.int32), strip_id.astype(np.int32)
-
-
 def tile_rows_from_coords(coords, rows_per_tile=None):
     """Index of the tile ROW (the slowest key of tile_order_from_coords) every
     point falls into; all zero when the points fit one tile."""
@@ -242,11 +200,7 @@ def space_matrices(mesh):
     A.data[np.abs(A.data) < 1e-14 * np.abs(A.data).max()] = 0.0
     fd = free_dofs(mesh)
     M, A = _restrict(M, fd), _restrict(A, fd)
-    order, strip = patch_order_from_coords(mesh.points[fd])
-    # processing order of the rows (a locality hint for the gather kernels) and
-    # the strip of every row (tile boundaries of the tile-staged kernel)
-    M.stk_row_order = A.stk_row_order = order
-    M.stk_row_strip = A.stk_row_strip = strip
+    M.stk_row_order = A.stk_row_order = tile_row_order(mesh)
     return M, A
 
 

@@ -45,7 +45,13 @@ class Lanczos:
                 self.converged = False
                 break
             v -= self.alpha[k] * w
-            self.beta[k] = sqrt((A @ v).dot(v))
+            self.beta[k] = sqrt(max((A @ v).dot(v), 0.0))
+            if self.beta[k] == 0.0:
+                # breakdown: the Krylov space is invariant (P A = alpha I on it,
+                # e.g. an exact preconditioner): the extreme Ritz values are final
+                k += 1
+                self.alpha[k] = self.alpha[k - 1]
+                break
             w_prev, w = w, v / self.beta[k]
             v = -self.beta[k] * w_prev
             v += P @ (A @ w)

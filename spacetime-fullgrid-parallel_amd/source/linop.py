@@ -327,23 +327,6 @@ class EllMatrices:
                                        _lib.ptr(self.ovf_indices))
         self.packed = PackedEllMatrices(M, K, ell_idx, ell_vals, self.row_ids,
                                         not main.all())
-        # strip of every position (patch order of the assembly), if known
-        self._strip_of_pos = None
-        for m in list(order_hints) + list(mats):
-            strip = getattr(m, 'stk_row_strip', None)
-            if strip is not None and row_ids is not None and len(strip) == M:
-                self._strip_of_pos = np.asarray(strip)[row_ids]
-                break
-        self._tiled = {}
-
-    def tiled(self, n_loc, ghost):
-        """The tile-staged plan for slabs of n_loc time steps (built on first
-        use); ``.ok`` tells whether it fits."""
-        key = (n_loc, bool(ghost))
-        if key not in self._tiled:
-            self._tiled[key] = TiledEllMatrices(self.packed, self._strip_of_pos,
-                                                n_loc, ghost)
-        return self._tiled[key]
 
     def _terms(self, specs, ghosts):
         terms = (_lib.KronEllTerm * len(specs))()
@@ -408,10 +391,6 @@ class PackedEllMatrices:
         self.ok = True
         self.M, self.K, self.col_bits, self.n_codes = M, K, col_bits, len(uniq)
         self.n_mats = len(ell_vals)
-        # host copies for the tile planner (TiledEllMatrices), which is built per
-        # slab length on first use
-        self._host_cols = ell_idx.reshape(M, K)
-        self._host_codes = codes.reshape(M, K).astype(np.uint16)
         slots = (codes.reshape(-1).astype(np.uint32) << np.uint32(col_bits)
                  ) | ell_idx.reshape(-1).astype(np.uint32)
         self.slots = _lib.to_dev(slots.view(np.int32).reshape(M, K))
@@ -433,124 +412,6 @@ class PackedEllMatrices:
             _lib.stream(), ctypes.byref(self.pattern), n_loc, ld, len(specs),
             terms, _lib.ptr(x), _lib.ptr(ghosts), beta, _lib.ptr(out)))
 
-    def wave_pattern(self):
-        """Row records of the wave-autonomous kernel (stk_kron_wave_apply): the K
-        slot words of a row, padding, and its output row id in one 16-byte
-        aligned record; built on first use."""
-        if getattr(self, '_wave', None) is None:
-            M, K = self.M, self.K
-            KS = ((K + 1) + 3) & ~3
-            rec = np.zeros((M, KS), dtype=np.uint32)
-            rec[:, :K] = self.slots.cpu().numpy().view(np.uint32)
-            rec[:, KS - 1] = (self.row_ids.cpu().numpy().astype(np.uint32)
-                              if self.row_ids is not None else
-                              np.arange(M, dtype=np.uint32))
-            self._recs = _lib.to_dev(rec.view(np.int32))
-            self._wave = _lib.WavePattern(M, K, self.col_bits, self.n_codes,
-                                          self.n_mats, _lib.ptr(self._recs),
-                                          _lib.ptr(self.dict))
-        return self._wave
-
-    def apply_wave(self, specs, x, ghosts, n_loc, ld, beta, out):
-        terms = (_lib.KronPackTerm * len(specs))()
-        for t, (tri, k) in zip(terms, specs):
-            t.tri, t.mat = _lib.ptr(tri), k
-        _lib.check(_lib.lib().stk_kron_wave_apply(
-            _lib.stream(), ctypes.byref(self.wave_pattern()), n_loc, ld,
-            len(specs), terms, _lib.ptr(x), _lib.ptr(ghosts), beta,
-            _lib.ptr(out)))
-
-
-class TiledEllMatrices:
-    """The packed plan cut into tiles for ``stk_kron_tile_apply``
-    (csrc/kron_tile.hip, include/stk.h): consecutive rows of the processing
-    order -- never across a strip boundary of the patch order -- with the list
-    of distinct columns each tile references, and 16-bit slots
-    ``code << 7 | local column``.  The tile size follows the slab: a tile is
-    what a 512-thread workgroup turns over in `passes` passes of 496 tasks
-    (task = row x pair of time steps, plus two ghost tasks per row on a slab
-    with neighbours).  ``ok`` is False when a tile would not fit (more than
-    128 columns, more than 512 codes, too much LDS): the caller keeps the
-    packed gather kernel."""
-    LDS_BUDGET = 52 * 1024  # three workgroups per CU
-
-    def __init__(self, packed, strip_of_pos, n_loc, ghost, passes=None):
-        import os
-        self.ok = False
-        if not packed.ok or packed.n_codes > 512:
-            return
-        M, K = packed.M, packed.K
-        P = (n_loc + 1) // 2
-        W = P + (2 if ghost else 0)
-        cols, codes = packed._host_cols, packed._host_codes
-        env = os.environ.get('STK_TILE_PASSES')
-        tries = [int(env)] if env else [passes or 1]
-        plan = None
-        for npass in tries:
-            TR = max(1, min((496 * npass) // W, 512 // K))
-            # what a tile may hold: 128 columns (7-bit local index), 3072 pieces,
-            # and for one-pass tiles the 1536 pieces of the three-register
-            # prefetch (three workgroups per CU)
-            cap = min(128, (1536 if npass == 1 else 3072) // P)
-            pos = np.arange(M, dtype=np.int64)
-            if strip_of_pos is not None:
-                start = np.flatnonzero(np.r_[True, np.diff(strip_of_pos) != 0])
-                first = np.repeat(start, np.diff(np.r_[start, M]))
-                rank = pos - first
-                new = (rank % TR) == 0  # a tile ends with its strip, or after TR rows
-            else:
-                new = (pos % TR) == 0
-            for _ in range(4):
-                tile_of = np.cumsum(new) - 1
-                n_tiles = int(tile_of[-1]) + 1
-                row_ptr = np.r_[np.flatnonzero(new), M].astype(np.int64)
-                keys = (np.repeat(tile_of, K) << np.int64(32)) | cols.reshape(-1).astype(np.int64)
-                uniq, inv = np.unique(keys, return_inverse=True)
-                counts = np.bincount(uniq >> np.int64(32), minlength=n_tiles)
-                wide = np.flatnonzero((counts > cap) & (np.diff(row_ptr) > 1))
-                if len(wide) == 0:
-                    break
-                # halve the few tiles that reference too many columns
-                new = new.copy()
-                new[(row_ptr[wide] + row_ptr[wide + 1]) // 2] = True
-            row_ptr = row_ptr.astype(np.int32)
-            col_ptr = np.r_[0, np.cumsum(counts)].astype(np.int64)
-            nc_max = int(counts.max())
-            tr_max = int(np.diff(row_ptr).max())
-            KS = (K + 7) & ~7
-            lds = (16 * nc_max * (P + (1 if ghost else 0)) + 2 * tr_max * KS +
-                   4 * tr_max + 8 * (packed.n_mats * (3 * (n_loc + 2) + packed.n_codes)) + 64)
-            if nc_max <= 128 and nc_max * P <= 3072 and lds <= 64 * 1024:
-                local = (inv - np.repeat(col_ptr[tile_of], K)).astype(np.uint16)
-                plan = (npass, n_tiles, nc_max, tr_max, row_ptr,
-                        col_ptr.astype(np.int32), (uniq & np.int64(0xffffffff)).astype(np.int32),
-                        local, lds)
-        if plan is None:
-            return
-        npass, n_tiles, nc_max, tr_max, row_ptr, col_ptr, tcols, local, lds = plan
-        self.ok = True
-        self.passes, self.n_tiles, self.nc_max, self.tr_max, self.lds = (
-            npass, n_tiles, nc_max, tr_max, lds)
-        self.cols_per_row = len(tcols) / float(M)
-        slots = (codes.reshape(-1).astype(np.uint16) << np.uint16(7)) | local
-        self.slots = _lib.to_dev(slots.view(np.int16).reshape(M, K))
-        self.row_ptr = _lib.to_dev(row_ptr)
-        self.col_ptr = _lib.to_dev(col_ptr)
-        self.tile_cols = _lib.to_dev(tcols)
-        self.row_ids, self.dict = packed.row_ids, packed.dict
-        self.pattern = _lib.TilePattern(
-            M, K, n_tiles, nc_max, tr_max, packed.n_codes, packed.n_mats,
-            _lib.ptr(self.row_ptr), _lib.ptr(self.col_ptr),
-            _lib.ptr(self.tile_cols), _lib.ptr(self.slots),
-            _lib.ptr(self.row_ids), _lib.ptr(self.dict))
-
-    def apply(self, specs, x, ghosts, n_loc, ld, beta, out):
-        terms = (_lib.KronPackTerm * len(specs))()
-        for t, (tri, k) in zip(terms, specs):
-            t.tri, t.mat = _lib.ptr(tri), k
-        _lib.check(_lib.lib().stk_kron_tile_apply(
-            _lib.stream(), ctypes.byref(self.pattern), n_loc, ld, len(specs),
-            terms, _lib.ptr(x), _lib.ptr(ghosts), beta, _lib.ptr(out)))
 
 
 # ----------------------------------------------------------------------------

@@ -379,7 +379,6 @@ class _FusedKronSum:
     the persistent sliced-ELL kernel (default) or the plain CSR one."""
     use_ell = True
     use_pack = True  # packed matrix stream + fused ghost steps when the plan fits
-    use_tile = True  # ... and its tile-staged form (LDS-resident columns) on top
 
     @classmethod
     def max_terms(cls):
@@ -421,14 +420,9 @@ class _FusedKronSum:
             if self.dofs_distr.size > 1 and (self.needs_lo or self.needs_hi):
                 time_comm = vec_in.communicate_bdr()
                 ghosts = vec_in.ghost_interleaved()
-            form = self.ell.packed
-            if type(self).use_tile:
-                tiled = self.ell.tiled(vec_in.n_loc, ghosts is not None)
-                if tiled.ok:
-                    form = tiled
-            form.apply([(self.tri[k], k) for k in range(self.n_terms)],
-                       vec_in.buf, ghosts, vec_in.n_loc, vec_in.ld, beta,
-                       vec_out.buf)
+            self.ell.packed.apply([(self.tri[k], k) for k in range(self.n_terms)],
+                                  vec_in.buf, ghosts, vec_in.n_loc, vec_in.ld,
+                                  beta, vec_out.buf)
             return time_comm
         if self.use_ell:
             # the slab-local part runs while the halo exchange is in flight
@@ -473,9 +467,6 @@ class _FusedKronSum:
             return 'kron_sum_kernel<%d>' % self.n_terms
         if type(self).use_pack and self.ell.packed.ok:
             ghost = self.dofs_distr.size > 1 and (self.needs_lo or self.needs_hi)
-            if type(self).use_tile and self.ell.tiled(n_loc, ghost).ok:
-                return 'kron_tile_kernel<%d, %d, %s>' % (
-                    self.n_terms, self.ell.K, 'ghost tasks' if ghost else 'no ghosts')
             return 'kron_pack_kernel<%d, %d, %s>' % (
                 self.n_terms, self.ell.K, 'ghost lanes' if ghost else 'no ghosts')
         return 'kron_ell_kernel<%d, shared input, %d>' % (self.n_terms, self.ell.K)

@@ -30,12 +30,15 @@ ap.add_argument('--reps', type=int, default=20)
 ap.add_argument('--variants', default='plain;pack;pack,pack_flags=1;pack,pack_flags=2;pack,pack_flags=3')
 ap.add_argument('--phases', action='store_true')
 ap.add_argument('--rows-per-tile', default='')
+ap.add_argument('--order', default='patch', help='patch (assembly hint) or index (memory order)')
 args = ap.parse_args()
 if args.rows_per_tile:
     os.environ['STK_ROWS_PER_TILE'] = args.rows_per_tile
 mesh = problem_helper(args.problem, J_space=args.J_space, J_time=2)[0]
 M_x, A_x = space_matrices(mesh)
 M = M_x.shape[0]
+if args.order == 'index':
+    M_x.stk_row_order = A_x.stk_row_order = np.arange(M, dtype=np.int32)
 ell = EllMatrices([M_x, A_x], [M_x])
 n_loc = args.n_loc
 ld = n_loc + (n_loc & 1)
@@ -51,9 +54,7 @@ if g is not None:
     _lib.check(_lib.lib().stk_interleave_ghosts(_lib.stream(), M, _lib.ptr(g[0]), _lib.ptr(g[1]), _lib.ptr(gh)))
 lo, hi = (g[0], g[1]) if g is not None else (None, None)
 nbytes = 16 * n_loc * M + 8 * (2 if g is not None else 0) * M + 12 * (M_x.nnz + A_x.nnz) + 8 * (M + 1)
-KEYS = {'pack_flags': 0, 'pack_block': 512, 'pack_wg_per_cu': 0, 'ell_wg_per_cu': 0,
-        'tile_flags': 0, 'tile_wg_per_cu': 0, 'wave_flags': 0, 'wave_wg_per_cu': 0, 'wave_block': 256}
-TILED = {}
+KEYS = {'pack_flags': 3, 'pack_block': 512, 'pack_wg_per_cu': 0, 'ell_wg_per_cu': 0}
 
 
 def run(variant):
@@ -65,29 +66,10 @@ def run(variant):
         _lib.check(_lib.lib().stk_set_tuning(k.encode(), int(v)))
     if parts[0] == 'plain':
         return lambda: ell.apply([(tri[0], 0, x, lo, hi), (tri[1], 1, x, lo, hi)], n_loc, ld, 0.0, y)
-    if parts[0] == 'wave':
-        return lambda: ell.packed.apply_wave([(tri[0], 0), (tri[1], 1)], x, gh, n_loc, ld, 0.0, y)
-    if parts[0].startswith('tile'):  # tile1 / tile2: one- or two-pass tiles
-        from source.linop import TiledEllMatrices
-        passes = int(parts[0][4:] or 1)
-        if passes not in TILED:
-            TILED[passes] = TiledEllMatrices(ell.packed, ell._strip_of_pos, n_loc, gh is not None, passes)
-            t = TILED[passes]
-            print('tile plan, %d pass(es): ok=%s' % (passes, t.ok), '' if not t.ok else
-                  'tiles=%d nc_max=%d tr_max=%d lds=%d columns/row=%.2f' % (t.n_tiles, t.nc_max, t.tr_max, t.lds, t.cols_per_row))
-        t = TILED[passes]
-        return lambda: t.apply([(tri[0], 0), (tri[1], 1)], x, gh, n_loc, ld, 0.0, y)
     return lambda: ell.packed.apply([(tri[0], 0), (tri[1], 1)], x, gh, n_loc, ld, 0.0, y)
 
 
 variants = args.variants.split(';')
-run('pack')()
-y_ref = y.clone()
-for v in variants:
-    if v.startswith('tile') or v.startswith('wave'):
-        y.zero_()
-        run(v)()
-        print('%-40s max |diff to packed form| = %.3e' % (v, float((y - y_ref).abs().max())))
 times = {v: [] for v in variants}
 for rnd in range(args.rounds):
     for v in variants:
