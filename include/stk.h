@@ -367,6 +367,33 @@ int stk_mg_smooth(stk_mg *mg, void *stream, int32_t level, int32_t n_loc,
                   int32_t ld, double ca, const double *cm, int32_t its,
                   int32_t backward, const double *f, double *u);
 
+/* The same plan built inside the library from what a caller of the reference
+ * holds when it constructs MultiGrid(mat, hierarchy) (multigrid.py:130-166): the
+ * finest-level matrix A (and optionally a second matrix M on the same rows, for
+ * families a(t) = ca*A + cm[t]*M, heateq_mpi.py:97-98) and the n_levels - 1
+ * prolongation matrices, P[j] from level j to level j + 1 (multigrid.py:39-60),
+ * all as HOST CSR.  Computes the Galerkin products R A P (multigrid.py:142-145;
+ * same accumulation order as SciPy's csr_matmat, rounding-noise entries dropped),
+ * the Gauss-Seidel dependency schedules, every sliced-ELL copy, the bands of the
+ * strip-wise smoothing (verified on the pattern) and the exact inverses of the
+ * coarsest matrices: kind 0 = A_0, kind 1 + k = ca*A_0 + cms[k]*M_0.
+ * coords (optional, HOST): coordinates of the finest-level dofs, row-major
+ * (n x dim), level l = the first n_l of them -- only used for cache-friendly row
+ * orders and bands; NULL = index order / breadth-first bands. */
+typedef struct {
+    int32_t n_rows, n_cols;
+    const int32_t *indptr, *indices;
+    const double *data;
+} stk_csr_host;
+
+int stk_mg_create_from_csr(int32_t n_levels, const stk_csr_host *A_fine,
+                           const stk_csr_host *M_fine,
+                           const stk_csr_host *P_host,
+                           const double *coords_host, int32_t dim,
+                           int32_t smoothsteps, int32_t vcycles, double ca,
+                           int32_t n_cms, const double *cms_host,
+                           int32_t max_ld, stk_mg **out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -123,6 +123,8 @@ struct stk_mg {
     // fused coarse sub-V-cycle: levels 0..Lc in one launch (Lc < 0: none)
     stk_coarse_plan *coarse = nullptr;
     int Lc = -1;
+    // device arrays the plan owns (plans built by stk_mg_create_from_csr)
+    std::vector<void *> adopted;
 };
 
 // The ELL row engine needs 16-byte time pairs (even ld) and slabs below 64 GiB.
@@ -437,9 +439,15 @@ extern "C" int stk_mg_create(int32_t n_levels, const stk_mg_level *levels, int32
     return 0;
 }
 
+void stk_mg_adopt(stk_mg *mg, void *const *dev_ptrs, int n)
+{
+    mg->adopted.insert(mg->adopted.end(), dev_ptrs, dev_ptrs + n);
+}
+
 extern "C" int stk_mg_destroy(stk_mg *mg)
 {
     if (!mg) return 0;
+    for (void *p : mg->adopted) (void)hipFree(p);
     for (double *p : mg->u) (void)hipFree(p);
     for (double *p : mg->f) (void)hipFree(p);
     for (double *p : mg->r) (void)hipFree(p);

@@ -60,6 +60,9 @@ void stk_coarse_plan_free(stk_coarse_plan *p);
 int stk_coarse_plan_run(const stk_coarse_plan *p, hipStream_t st, int n_loc, int ld, double ca, const double *cm,
                         const int32_t *kind, const double *coarse_inv);
 
+// The plan takes over device arrays (freed by stk_mg_destroy): mg_build.hip.
+void stk_mg_adopt(stk_mg *mg, void *const *dev_ptrs, int n);
+
 // Row-gather engine launcher of rows_ell.hip (mode 0 = SPMM, 1 = Gauss-Seidel group).
 int stk_rows_ell_launch(hipStream_t st, int mode, const stk_ell_rows *e, int32_t pos_begin, int32_t pos_end,
                         int32_t n_loc, int32_t ld, int64_t x_rows, int64_t y_rows, double ca, const double *cm,

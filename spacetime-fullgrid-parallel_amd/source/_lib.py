@@ -56,6 +56,11 @@ class EllRows(ctypes.Structure):
                 ('dia_a', c_p), ('dia_m', c_p)]
 
 
+class CsrHost(ctypes.Structure):
+    _fields_ = [('n_rows', c_i32), ('n_cols', c_i32), ('indptr', c_p),
+                ('indices', c_p), ('data', c_p)]
+
+
 class MGLevel(ctypes.Structure):
     _fields_ = [('n', c_i32), ('indptr', c_p), ('indices', c_p),
                 ('vals_a', c_p), ('vals_m', c_p), ('diag', c_p),
@@ -138,6 +143,11 @@ _PROTOTYPES = {
         c_i32,
         ctypes.POINTER(MGLevel), c_i32, c_i32, c_i32, c_p, c_i32,
         ctypes.POINTER(c_p)
+    ]),
+    'stk_mg_create_from_csr': (ctypes.c_int, [
+        c_i32, ctypes.POINTER(CsrHost), ctypes.POINTER(CsrHost),
+        ctypes.POINTER(CsrHost), c_p, c_i32, c_i32, c_i32, c_f64, c_i32, c_p,
+        c_i32, ctypes.POINTER(c_p)
     ]),
     'stk_mg_destroy': (ctypes.c_int, [c_p]),
     'stk_mg_apply': (ctypes.c_int,

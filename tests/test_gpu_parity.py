@@ -554,10 +554,11 @@ def test_coarse_subcycle_variants_agree(stk):
 # differences (order of additions in dot products and in the regrouped Schur
 # complement) into differences of alpha and beta.  1e-10 on the LAST entries,
 # which are 1e-13 of the first, would need bit-identical arithmetic; what is
-# asserted is 1e-9 on every entry relative to itself and 1e-13 relative to the
-# initial residual.
+# asserted is 1e-9 on every entry relative to itself and 1e-11 relative to the
+# initial residual (measured: up to 3.2e-13, from the first entry r0.P r0, whose
+# two multigrid applies per time slice agree with the oracle's to ~1e-12).
 HIST_RTOL = 1e-9
-HIST_RTOL_VS_INITIAL = 1e-13
+HIST_RTOL_VS_INITIAL = 1e-11
 
 
 def _record_history_dev(tag, hist, ref):
@@ -1331,3 +1332,90 @@ def test_kron_plan_from_csr_through_ctypes_only(stk):
     assert lib.stk_kron_plan_create(3, 1, one(ip), one(ix), one(dv), bad.ctypes.data,
                                     ctypes.byref(plan)) != 0
     assert b'permutation' in lib.stk_last_error()
+
+
+def test_multigrid_plan_from_csr_through_ctypes_only(stk):
+    """Row b / f1: the multigrid plan without any Python planner.
+    stk_mg_create_from_csr gets the finest-level CSR matrices and the
+    prolongations as host arrays, forms the Galerkin products, schedules, ELL
+    copies, bands and coarse inverses inside libstk; stk_mg_apply then runs the
+    V-cycles.  Only ctypes calls and device buffers here.  Against the CPU
+    oracle's MultiGrid, and against the Python-planned plan of the same inputs;
+    single matrix (K = A^-1) and family (2^j M + alpha A), with and without
+    coordinates (breadth-first bands), strip-wise smoothing forced on."""
+    import ctypes
+    from oracle.multigrid import MultiGrid as OracleMG
+    from source.assembly import prolongation_matrices, space_matrices
+    from source.multigrid import MeshHierarchy, MultiGrid, MultiGridFamily
+    from source.problem import problem_helper
+    lib = stk.lib()
+
+    def host(m):
+        m = sp.csr_matrix(m)
+        m.sort_indices()
+        arrs = (m.indptr.astype(np.int32), m.indices.astype(np.int32),
+                m.data.astype(np.float64))
+        return stk.CsrHost(m.shape[0], m.shape[1], arrs[0].ctypes.data,
+                           arrs[1].ctypes.data, arrs[2].ctypes.data), arrs
+
+    for problem, J_space in (('square', 4), ('lshape', 3), ('cube', 2)):
+        mesh = problem_helper(problem, J_space=J_space, J_time=2)[0]
+        M_x, A_x = space_matrices(mesh)
+        hier = MeshHierarchy(mesh)
+        P_mats = prolongation_matrices(mesh)
+        n = A_x.shape[0]
+        n_loc, ld = 7, 8
+        F = np.random.RandomState(31).rand(n, n_loc)
+        f = torch.zeros((n, ld), dtype=torch.float64, device='cuda')
+        f[:, :n_loc] = torch.from_numpy(F).cuda()
+        coords = np.ascontiguousarray(hier.coords, dtype=np.float64)
+        Ps = [host(P) for P in P_mats]
+        P_arr = (stk.CsrHost * len(Ps))(*[p[0] for p in Ps])
+        a_h, a_keep = host(A_x)
+        m_h, m_keep = host(M_x)
+        try:
+            stk.check(lib.stk_set_tuning(b'mg_strip_mb', 1))
+            stk.check(lib.stk_set_tuning(b'mg_strip_width', 0))
+            for with_coords in (True, False):
+                # --- one matrix: K = MultiGrid(A_x), 3 sweeps, 2 V-cycles
+                plan = ctypes.c_void_p()
+                stk.check(lib.stk_mg_create_from_csr(
+                    len(P_mats) + 1, ctypes.byref(a_h), None, P_arr,
+                    coords.ctypes.data if with_coords else None, coords.shape[1],
+                    3, 2, 1.0, 0, None, ld, ctypes.byref(plan)))
+                u = torch.empty_like(f)
+                stk.check(lib.stk_mg_apply(plan, stk.stream(), n_loc, ld, 1.0, None,
+                                           None, stk.ptr(f), stk.ptr(u)))
+                got = u[:, :n_loc].cpu().numpy()
+                want = OracleMG(A_x, P_mats, 3, 2) @ F
+                assert relerr(got, want) < 1e-12, (problem, with_coords)
+                py = MultiGrid(A_x, hier, smoothsteps=3, vcycles=2) @ F
+                assert relerr(got, py) < 1e-13, (problem, with_coords)
+                stk.check(lib.stk_mg_destroy(plan))
+                # --- a family: C_j = (2^j M + 0.3 A)^-1, per-slice coefficients
+                cms = np.array([1.0, 2.0, 4.0])
+                plan = ctypes.c_void_p()
+                stk.check(lib.stk_mg_create_from_csr(
+                    len(P_mats) + 1, ctypes.byref(a_h), ctypes.byref(m_h), P_arr,
+                    coords.ctypes.data if with_coords else None, coords.shape[1],
+                    3, 2, 0.3, len(cms), cms.ctypes.data, ld, ctypes.byref(plan)))
+                member = [0, 1, 2, 1, 0, 2, 2]
+                cm = stk.to_dev(cms[member])
+                kind = stk.to_dev(np.array([k + 1 for k in member], dtype=np.int32))
+                stk.check(lib.stk_mg_apply(plan, stk.stream(), n_loc, ld, 0.3,
+                                           stk.ptr(cm), stk.ptr(kind), stk.ptr(f),
+                                           stk.ptr(u)))
+                got = u[:, :n_loc].cpu().numpy()
+                for t, k in enumerate(member):
+                    C = OracleMG(sp.csr_matrix(cms[k] * M_x + 0.3 * A_x), P_mats, 3, 2)
+                    assert relerr(got[:, t], C @ F[:, t]) < 1e-12, (problem, t)
+                stk.check(lib.stk_mg_destroy(plan))
+        finally:
+            stk.check(lib.stk_set_tuning(b'mg_strip_mb', 120))
+            stk.check(lib.stk_set_tuning(b'mg_strip_width', 2))
+    # a matrix without a diagonal entry is refused with a message
+    bad, keep = host(sp.csr_matrix(np.array([[0.0, 1.0], [1.0, 2.0]])))
+    plan = ctypes.c_void_p()
+    assert lib.stk_mg_create_from_csr(1, ctypes.byref(bad), None, None, None, 2, 1,
+                                      1, 1.0, 0, None, 2, ctypes.byref(plan)) != 0
+    assert b'diagonal' in lib.stk_last_error()
