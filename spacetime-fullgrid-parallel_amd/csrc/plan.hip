@@ -112,7 +112,7 @@ int build(stk_kron_plan *p, int32_t M, int32_t n_mats, const int32_t *const *ind
     if (overflow) return 0;
     int col_bits = 1;
     while (((int64_t)1 << col_bits) < M) ++col_bits;
-    const int64_t max_codes = std::min<int64_t>((int64_t)1 << (32 - col_bits), 2048);
+    const int64_t max_codes = std::min<int64_t>((int64_t)1 << (32 - col_bits), 512);  // the dictionary lives in LDS
     std::map<std::vector<uint64_t>, uint32_t> dict;  // bit patterns: +0.0 and -0.0 stay apart
     std::vector<uint32_t> code((size_t)M * K);
     std::vector<uint64_t> key(n_mats);

@@ -367,6 +367,8 @@ class PackedEllMatrices:
     tuples of the union pattern.  ``ok`` is False when the plan does not fit
     (overflow rows, or more distinct tuples than the free bits can name); the
     caller then keeps the plain form."""
+    MAX_CODES = 512  # the dictionary lives in LDS next to the exchange buffers
+
     def __init__(self, M, K, ell_idx, ell_vals, row_ids, has_overflow):
         self.ok = False
         if has_overflow or M < 1:
@@ -377,10 +379,10 @@ class PackedEllMatrices:
         codes, table = np.zeros(M * K, dtype=np.int64), None
         for e in ell_vals:
             u, inv = np.unique(e.reshape(-1).view(np.int64), return_inverse=True)
-            if len(u) > 2048:
+            if len(u) > self.MAX_CODES:
                 return
             uc, codes = np.unique(codes * len(u) + inv, return_inverse=True)
-            if len(uc) > 2048:
+            if len(uc) > self.MAX_CODES:
                 return
             col = u[uc % len(u)][:, None]
             table = col if table is None else np.hstack(
