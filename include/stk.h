@@ -253,13 +253,6 @@ typedef struct {
     const double *va, *vm;  /* n_pos*K values; vm may be NULL */
     const int32_t *row_ids; /* n_pos or NULL */
     const double *dia_a, *dia_m; /* n_pos each or NULL */
-    /* Optional (NULL / 0 if absent): the same diagonals as a dictionary --
-     * dia_code[pos] indexes the n_dia_codes (<= 16) distinct pairs
-     * (dia_dict_a[c], dia_dict_m[c]).  With it the Gauss-Seidel kernel
-     * tabulates 1 / a_ii(t) once per launch instead of dividing per row. */
-    const int32_t *dia_code;
-    const double *dia_dict_a, *dia_dict_m;
-    int32_t n_dia_codes;
 } stk_ell_rows;
 
 /* y = alpha * A(t) x + beta * z; x has x_rows rows, y and z have ell->n_rows.

@@ -332,40 +332,6 @@ bool ell_rows(Builder &B, const Union &u, const std::vector<int32_t> &order, boo
     out->row_ids = B.up(rows);
     out->dia_a = (diag || dia_a) ? B.up(da) : nullptr;
     out->dia_m = ((diag || dia_a) && has_m) ? B.up(dm) : nullptr;
-    // the diagonals once more as a dictionary of at most 16 distinct pairs
-    out->dia_code = nullptr;
-    out->dia_dict_a = out->dia_dict_m = nullptr;
-    out->n_dia_codes = 0;
-    if ((diag || dia_a) && np > 0) {
-        std::map<std::pair<uint64_t, uint64_t>, int32_t> dict;
-        std::vector<int32_t> code(np);
-        bool small = true;
-        for (size_t p = 0; p < np && small; ++p) {
-            uint64_t ka, km = 0;
-            std::memcpy(&ka, &da[p], 8);
-            if (has_m) std::memcpy(&km, &dm[p], 8);
-            auto it = dict.find({ka, km});
-            if (it == dict.end()) {
-                if (dict.size() >= 16) {
-                    small = false;
-                    break;
-                }
-                it = dict.emplace(std::make_pair(ka, km), (int32_t)dict.size()).first;
-            }
-            code[p] = it->second;
-        }
-        if (small) {
-            std::vector<double> ta(dict.size()), tm(dict.size());
-            for (auto &kv : dict) {
-                std::memcpy(&ta[kv.second], &kv.first.first, 8);
-                std::memcpy(&tm[kv.second], &kv.first.second, 8);
-            }
-            out->dia_code = B.up(code);
-            out->dia_dict_a = B.up(ta);
-            out->dia_dict_m = has_m ? B.up(tm) : nullptr;
-            out->n_dia_codes = (int32_t)dict.size();
-        }
-    }
     return true;
 }
 

@@ -30,9 +30,6 @@ struct RowsArgs {
     const double *va, *vm;   // [n_pos][K]
     const int32_t *row_ids;  // [n_pos] or NULL
     const double *dia_a, *dia_m;  // [n_pos] (GS)
-    const int32_t *dia_code;      // [n_pos] index into the diagonal dictionary, or NULL
-    const double *ddict_a, *ddict_m;  // [n_dcodes] distinct diagonal entries
-    int32_t n_dcodes;
     const double *cm;        // [n_loc] or NULL
     const double *x;         // gather source slab (GS: u)
     const double *z;         // SPMM: beta operand; GS: right-hand side f
@@ -47,13 +44,7 @@ struct RowsArgs {
     int32_t wide;  // a slab of 4 GiB or more: 64-bit addressing
 };
 
-// RTAB (Gauss-Seidel only): the rows' diagonal entries come from a small
-// dictionary (on a uniformly refined mesh a level has a handful of distinct
-// diagonals), and 1 / a_ii(t) is tabulated in LDS once per launch for every
-// (dictionary entry, pair of time steps) instead of two float64 divisions per
-// lane and row -- a third of the kernel's vector instructions.  The table holds
-// exactly the quotients the division in the loop would produce.
-template <int MODE, int K, int NPF, bool HAS_M, bool WIDE, bool RTAB = false>
+template <int MODE, int K, int NPF, bool HAS_M, bool WIDE>
 __global__ __launch_bounds__(BS, K >= 12 ? 4 : 6) void rows_ell_kernel(const RowsArgs a)
 {
     constexpr int KS = (K + 3) & ~3;
@@ -76,20 +67,6 @@ __global__ __launch_bounds__(BS, K >= 12 ? 4 : 6) void rows_ell_kernel(const Row
         cm0 = a.cm[t0];
         if (has1) cm1 = a.cm[t0 + 1];
     }
-    double2 *s_rtab = reinterpret_cast<double2 *>(sm + 2 * buf_doubles);  // [n_dcodes][W]
-    if (RTAB) {
-        for (int i = tid; i < a.n_dcodes * W; i += BS) {
-            const int c = i / W, q = i - c * W;
-            double d0 = a.ca * a.ddict_a[c], d1 = d0;
-            if (HAS_M) {
-                const double m = a.ddict_m[c];
-                d0 = fma(a.cm[2 * q], m, d0);
-                d1 = fma(2 * q + 1 < a.n_loc ? a.cm[2 * q + 1] : 0.0, m, d1);
-            }
-            s_rtab[i] = make_double2(1.0 / d0, 1.0 / d1);
-        }
-        // (visible after the first barrier of the loop)
-    }
 
     int st_lds[NPF];
 #pragma unroll
@@ -107,7 +84,6 @@ __global__ __launch_bounds__(BS, K >= 12 ? 4 : 6) void rows_ell_kernel(const Row
     double pva[NPF], pvm[NPF];
     int32_t prow = 0;
     double pda = 1.0, pdm = 0.0;
-    int32_t pdc = 0;
 #pragma unroll
     for (int q = 0; q < NPF; ++q) {
         pidx[q] = 0;
@@ -133,12 +109,8 @@ __global__ __launch_bounds__(BS, K >= 12 ? 4 : 6) void rows_ell_kernel(const Row
         if (tid < rows) {
             prow = a.row_ids ? a.row_ids[first + tid] : first + tid;
             if (MODE == MODE_GS) {
-                if (RTAB) {
-                    pdc = a.dia_code[first + tid];
-                } else {
-                    pda = a.dia_a[first + tid];
-                    if (HAS_M) pdm = a.dia_m[first + tid];
-                }
+                pda = a.dia_a[first + tid];
+                if (HAS_M) pdm = a.dia_m[first + tid];
             }
         }
     };
@@ -167,12 +139,8 @@ __global__ __launch_bounds__(BS, K >= 12 ? 4 : 6) void rows_ell_kernel(const Row
         if (tid < rows) {
             b_row[tid] = (uint32_t)prow * ld_bytes;
             if (MODE == MODE_GS) {
-                if (RTAB) {
-                    reinterpret_cast<int32_t *>(b_da)[tid] = pdc;
-                } else {
-                    b_da[tid] = a.ca * pda;
-                    if (HAS_M) b_dm[tid] = pdm;
-                }
+                b_da[tid] = a.ca * pda;
+                if (HAS_M) b_dm[tid] = pdm;
             }
         }
         __syncthreads();
@@ -212,11 +180,7 @@ __global__ __launch_bounds__(BS, K >= 12 ? 4 : 6) void rows_ell_kernel(const Row
                 s1 = fma(v1, xv[u].y, s1);
             }
             double o0, o1;
-            if (MODE == MODE_GS && RTAB) {
-                const double2 rd = s_rtab[reinterpret_cast<const int32_t *>(b_da)[r] * W + p];
-                o0 = own.x + rd.x * (zv.x - s0);
-                o1 = own.y + rd.y * (zv.y - s1);
-            } else if (MODE == MODE_GS) {
+            if (MODE == MODE_GS) {
                 double d0 = b_da[r], d1 = d0;
                 if (HAS_M) {
                     const double m = b_dm[r];
@@ -242,25 +206,12 @@ __global__ __launch_bounds__(BS, K >= 12 ? 4 : 6) void rows_ell_kernel(const Row
 int g_rows_wg_per_cu = 0;
 int g_rows_force_wide = 0;  // testing: 64-bit addressing on small slabs
 int g_rows_alternate = 1;   // alternate the walking direction between launches
-int g_rows_rtab = 1;        // Gauss-Seidel: tabulated reciprocal diagonals where the plan has a dictionary
 unsigned g_rows_launch_count = 0;
 
 template <int MODE, int K, bool HAS_M, bool WIDE>
 int launch_npf_w(hipStream_t st, const RowsArgs &a, unsigned grid, size_t lds)
 {
     const int npf = (a.R * K + BS - 1) / BS;
-    if constexpr (MODE == MODE_GS && !WIDE) {
-        if (a.dia_code != nullptr) {  // reciprocal-diagonal table
-            if (npf <= 1)
-                hipLaunchKernelGGL((rows_ell_kernel<MODE, K, 1, HAS_M, WIDE, true>), dim3(grid), dim3(BS), lds, st, a);
-            else if (npf <= 2)
-                hipLaunchKernelGGL((rows_ell_kernel<MODE, K, 2, HAS_M, WIDE, true>), dim3(grid), dim3(BS), lds, st, a);
-            else
-                hipLaunchKernelGGL((rows_ell_kernel<MODE, K, 4, HAS_M, WIDE, true>), dim3(grid), dim3(BS), lds, st, a);
-            STK_LAUNCH_CHECK();
-            return 0;
-        }
-    }
     if (npf <= 1)
         hipLaunchKernelGGL((rows_ell_kernel<MODE, K, 1, HAS_M, WIDE>), dim3(grid), dim3(BS), lds, st, a);
     else if (npf <= 2)
@@ -304,10 +255,6 @@ int stk_rows_ell_set_tuning(const char *key, int32_t value)
 {
     if (std::strcmp(key, "rows_force_wide") == 0) {
         g_rows_force_wide = value;
-        return 0;
-    }
-    if (std::strcmp(key, "rows_rtab") == 0) {
-        g_rows_rtab = value;
         return 0;
     }
     if (std::strcmp(key, "rows_alternate") == 0) {
@@ -369,19 +316,7 @@ int stk_rows_ell_launch(hipStream_t st, int mode, const stk_ell_rows *e, int32_t
     const bool has_m = cm != nullptr;
     const size_t buf_doubles =
         ((size_t)(has_m ? 2 : 1) * a.R * KS + 2 * a.R + ((size_t)a.R * KS + a.R + 1) / 2 + 2) & ~(size_t)1;
-    // reciprocal-diagonal table (Gauss-Seidel, small diagonal dictionary, slabs below 4 GiB)
-    a.dia_code = nullptr;
-    a.ddict_a = a.ddict_m = nullptr;
-    a.n_dcodes = 0;
-    if (mode == MODE_GS && g_rows_rtab && !a.wide && e->dia_code && e->n_dia_codes > 0 && e->n_dia_codes <= 16 &&
-        e->dia_dict_a && (!cm || e->dia_dict_m) && a.R * K <= 4 * BS) {
-        a.dia_code = e->dia_code;
-        a.ddict_a = e->dia_dict_a;
-        a.ddict_m = e->dia_dict_m;
-        a.n_dcodes = e->n_dia_codes;
-    }
-    const size_t lds = 2 * buf_doubles * sizeof(double) + 16 +
-                       (a.dia_code ? (size_t)a.n_dcodes * a.P * sizeof(double2) : 0);
+    const size_t lds = 2 * buf_doubles * sizeof(double) + 16;
     const int n_cu = stk_cu_count();
     // wide rows (K >= 12) get 128 VGPRs: 2 workgroups per CU
     int per_cu = g_rows_wg_per_cu > 0 ? g_rows_wg_per_cu : (K >= 12 ? 2 : 3);

@@ -53,8 +53,7 @@ class KronPackTerm(ctypes.Structure):
 class EllRows(ctypes.Structure):
     _fields_ = [('n_pos', c_i32), ('n_rows', c_i32), ('K', c_i32),
                 ('idx', c_p), ('va', c_p), ('vm', c_p), ('row_ids', c_p),
-                ('dia_a', c_p), ('dia_m', c_p), ('dia_code', c_p),
-                ('dia_dict_a', c_p), ('dia_dict_m', c_p), ('n_dia_codes', c_i32)]
+                ('dia_a', c_p), ('dia_m', c_p)]
 
 
 class CsrHost(ctypes.Structure):

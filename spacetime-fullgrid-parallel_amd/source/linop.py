@@ -273,30 +273,10 @@ class EllRowsMatrix:
             self.dia_a = _lib.to_dev(va[dpos[order]])
             if vm is not None:
                 self.dia_m = _lib.to_dev(vm[dpos[order]])
-        # the diagonals once more as a small dictionary (few distinct values on a
-        # uniformly refined mesh): the Gauss-Seidel kernel then tabulates the
-        # reciprocals instead of dividing per row (include/stk.h)
-        self.dia_code = self.dia_dict_a = self.dia_dict_m = None
-        n_codes = 0
-        if self.dia_a is not None and npos:
-            da = self.dia_a.cpu().numpy()
-            dm = (self.dia_m.cpu().numpy() if self.dia_m is not None
-                  else np.zeros_like(da))
-            pairs = np.stack([da.view(np.int64), dm.view(np.int64)], axis=1)
-            uniq, codes = np.unique(pairs, axis=0, return_inverse=True)
-            if len(uniq) <= 16:
-                n_codes = len(uniq)
-                self.dia_code = _lib.to_dev(codes.reshape(-1).astype(np.int32))
-                self.dia_dict_a = _lib.to_dev(uniq[:, 0].copy().view(np.float64))
-                if self.dia_m is not None:
-                    self.dia_dict_m = _lib.to_dev(uniq[:, 1].copy().view(np.float64))
         self.struct = _lib.EllRows(npos, n, K, _lib.ptr(self.idx),
                                    _lib.ptr(self.va), _lib.ptr(self.vm),
                                    _lib.ptr(self.row_ids),
-                                   _lib.ptr(self.dia_a), _lib.ptr(self.dia_m),
-                                   _lib.ptr(self.dia_code),
-                                   _lib.ptr(self.dia_dict_a),
-                                   _lib.ptr(self.dia_dict_m), n_codes)
+                                   _lib.ptr(self.dia_a), _lib.ptr(self.dia_m))
 
 
 class EllMatrices:

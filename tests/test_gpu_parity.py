@@ -1423,25 +1423,3 @@ def test_multigrid_plan_from_csr_through_ctypes_only(stk):
     assert lib.stk_mg_create_from_csr(1, ctypes.byref(bad), None, None, None, 2, 1,
                                       1, 1.0, 0, None, 2, ctypes.byref(plan)) != 0
     assert b'diagonal' in lib.stk_last_error()
-
-
-def test_reciprocal_diagonal_table_is_exact(stk):
-    """Gauss-Seidel with the tabulated reciprocals of the diagonal dictionary
-    (1 / a_ii(t) per dictionary entry and time pair, once per launch) gives
-    bitwise the V-cycles of the kernel that divides per row; the plans of the
-    uniformly refined meshes must really carry a dictionary."""
-    import heateq_mpi as hm
-    for problem, J_space in (('square', 5), ('lshape', 4), ('cube', 3)):
-        h = hm.HeatEquationMPI(J_space=J_space, J_time=3, problem=problem)
-        fine = h.C_family._dev._keep[-1][1]['ells']['fwd']
-        assert fine.dia_code is not None and fine.struct.n_dia_codes <= 16
-        x = _vec(h.dofs_distr, np.random.RandomState(15).rand(h.N, h.M))
-        res = []
-        try:
-            for on in (0, 1):
-                stk.check(stk.lib().stk_set_tuning(b'rows_rtab', on))
-                res.append((_np(h.P @ x), _np(h.S @ x)))
-        finally:
-            stk.check(stk.lib().stk_set_tuning(b'rows_rtab', 1))
-        assert np.array_equal(res[0][0], res[1][0])
-        assert np.array_equal(res[0][1], res[1][1])
