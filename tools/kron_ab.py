@@ -25,6 +25,7 @@ ap.add_argument('--J_space', type=int, default=9)
 ap.add_argument('--problem', default='square')
 ap.add_argument('--n_loc', type=int, default=65)
 ap.add_argument('--ghosts', type=int, default=0)
+ap.add_argument('--ld', type=int, default=0, help='row stride in doubles (0: n_loc rounded up to even)')
 ap.add_argument('--rounds', type=int, default=9)
 ap.add_argument('--reps', type=int, default=20)
 ap.add_argument('--variants', default='plain;pack;pack,pack_flags=1;pack,pack_flags=2;pack,pack_flags=3')
@@ -41,7 +42,7 @@ if args.order == 'index':
     M_x.stk_row_order = A_x.stk_row_order = np.arange(M, dtype=np.int32)
 ell = EllMatrices([M_x, A_x], [M_x])
 n_loc = args.n_loc
-ld = n_loc + (n_loc & 1)
+ld = args.ld or (n_loc + (n_loc & 1))
 rng = np.random.RandomState(0)
 x = torch.rand((M, ld), dtype=torch.float64, device='cuda')
 x[:, n_loc:] = 0
