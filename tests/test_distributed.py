@@ -72,16 +72,19 @@ def test_rccl_backend_executes_on_one_rank():
 
 
 @pytest.mark.gpu
-def test_bench_runs_on_rccl_group_of_one():
-    """bench.py itself (kron steps + a short solve) through the RCCL-backed
-    communicator, launched as the driver launches it."""
+@pytest.mark.parametrize('nproc,backend', [(1, 'nccl'), (2, 'gloo'), (4, 'gloo')])
+def test_bench_runs_as_the_driver_launches_it(nproc, backend):
+    """bench.py itself (kron steps + a short solve), launched as the driver
+    launches it: one rank on the RCCL-backed communicator, and 2 / 4 ranks sharing
+    the test box's GPU over gloo (time slabs with ghost rows, halo exchange every
+    step, max-over-ranks timing, one JSON line from rank 0)."""
     import json
-    env = dict(os.environ, STK_BACKEND='nccl', STK_FORCE_COLLECTIVES='1',
+    env = dict(os.environ, STK_BACKEND=backend, STK_FORCE_COLLECTIVES='1',
                OMP_NUM_THREADS='1')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
-           '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--nproc-per-node', str(nproc), '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()),
-           os.path.join(os.path.dirname(HERE), 'bench.py'), '--gpus', '1',
+           os.path.join(os.path.dirname(HERE), 'bench.py'), '--gpus', str(nproc),
            '--steps', '2', '--warmup', '1', '--J_time', '4', '--J_space', '5',
            '--solve-iters', '2', '--no-cpu-baseline', '--preheat', '0']
     res = subprocess.run(cmd, env=env, capture_output=True, text=True,
@@ -89,4 +92,8 @@ def test_bench_runs_on_rccl_group_of_one():
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     line = [ln for ln in res.stdout.splitlines() if ln.startswith('{')][-1]
     rec = json.loads(line)
-    assert rec['n_gpus'] == 1 and rec['value'] > 0 and rec['pcg']['iters_timed'] >= 1
+    assert rec['n_gpus'] == nproc and rec['value'] > 0 and rec['pcg']['iters_timed'] >= 1
+    assert rec['scaling'] == 'strong' and rec['roofline']['frac'] > 0
+    assert rec['pcg']['roofline']['bytes_per_iteration'] > 0
+    if nproc > 1:
+        assert 'ghost' in rec['roofline']['kernel']

@@ -16,11 +16,15 @@ python3 bench.py > $out/bench.json 2> $out/bench.err || { tail -5 $out/bench.err
 echo "bench done"; cat $out/bench.json | head -c 600; echo
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/prof.log || { tail -5 $out/prof.log; exit 1; }
 cp $(ls $out/prof/*/*kernel_stats.csv | head -1) $out/kernel_stats.csv
-echo "kernel stats done"; head -4 $out/kernel_stats.csv
+python3 tools/trace_gaps.py $(ls $out/prof/*/*kernel_trace.csv | head -1) kron_pack_kernel > $out/kron_launch_gaps.txt 2>&1 || true
+rm -rf $out/prof   # the raw trace is large; gpurun_out is capped at 64 MiB
+echo "kernel stats done"; head -4 $out/kernel_stats.csv; cat $out/kron_launch_gaps.txt
 tools/pmc_passes.sh ${tag}_kron kron python3 tools/kron_one.py --kernels packed > $out/pmc_kron.log 2>&1
 cp gpurun_out/pmc_${tag}_kron/summary.txt $out/pmc_kron.txt
 python3 tools/pmc_traffic.py gpurun_out/pmc_${tag}_kron kron_pack_kernel $out/pmc_traffic.json > $out/pmc_traffic.log 2>&1
+rm -rf gpurun_out/pmc_${tag}_kron
 echo "kron pmc done"; cat $out/pmc_traffic.json | head -c 400; echo
 tools/pmc_passes.sh ${tag}_solve gs python3 bench.py --steps 2 --warmup 1 --solve-iters 2 --no-cpu-baseline --preheat 0 > $out/pmc_solve.log 2>&1
 cp gpurun_out/pmc_${tag}_solve/summary.txt $out/pmc_solve.txt
+rm -rf gpurun_out/pmc_${tag}_solve
 echo "solve pmc done"
