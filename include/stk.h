@@ -85,6 +85,24 @@ int stk_pcg_solve(void *stream, int64_t n, stk_operator_fn T, void *T_ctx,
                   void *allreduce_ctx, const double *b, double *w, double eps,
                   int32_t kmax, double *work, double *history, int32_t *iters);
 
+/* ---- Lanczos estimate of the extreme eigenvalues of P A (Lanczos,
+ *      lanczos.py:87-159; Sturm-sequence bisection bisec / pol, :20-85) ---------
+ * The reference's recurrence on device vectors of n doubles: `w` holds the start
+ * vector on entry (it is overwritten); A and P are callbacks as in
+ * stk_pcg_solve.  Stops when lambda_max and lambda_min both moved by less than
+ * `tol` relative (reference default 1e-4; bisection tolerance 1e-6), after at
+ * most max_iterations steps (*converged = 0 then), or at a breakdown (invariant
+ * Krylov space).  alpha_host / beta_host (max_iterations / max_iterations - 1
+ * host doubles, or NULL) receive the recurrence coefficients.  work:
+ * stk_lanczos_work_size(n) device doubles. */
+int64_t stk_lanczos_work_size(int64_t n);
+int stk_lanczos(void *stream, int64_t n, stk_operator_fn A, void *A_ctx,
+                stk_operator_fn P, void *P_ctx, stk_allreduce_fn allreduce,
+                void *allreduce_ctx, double *w, int32_t max_iterations,
+                double tol, double tol_bisec, double *work, double *alpha_host,
+                double *beta_host, double *lmax, double *lmin,
+                int32_t *iterations, int32_t *converged);
+
 /* ---- sum of Kronecker terms  y = beta*y + sum_k (T_k kron X_k) x_k --------
  * Replaces TridiagKronMatMPI._matvec (mpi_kron.py:214-219), i.e.
  * TridiagKronIdentityMPI (:186-201) followed by IdentityKronMatMPI (:143-150),

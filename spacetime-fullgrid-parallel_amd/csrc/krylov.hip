@@ -2,6 +2,8 @@
 // the time-slab partition (reference source/mpi_vector.py:5-38) and the
 // preconditioned CG recurrence (reference source/linalg.py:6-42) on device
 // vectors, with the operators and the rank reduction supplied as callbacks.
+#include <algorithm>
+#include <cmath>
 #include <vector>
 
 #include "stk_common.h"
@@ -95,5 +97,148 @@ extern "C" int stk_pcg_solve(void *stream, int64_t n, stk_operator_fn T, void *T
         STK_TRY(stk_axpby(stream, n, 1.0, z, rho / rho_prev, p));  // p = z + beta p
     }
 #undef STK_TRY
+    return 0;
+}
+
+// ---- Lanczos estimate of lambda_max / lambda_min of P A (reference
+// source/lanczos.py:87-159, Sturm bisection :20-85) ------------------------------
+namespace {
+
+double lz_pol(const std::vector<double> &al, const std::vector<double> &be, int k, double x)
+{
+    double prev = 1.0, cur = al[0] - x;  // lanczos.py:77-85
+    for (int l = 1; l <= k; ++l) {
+        const double nxt = (al[l] - x) * cur - be[l - 1] * be[l - 1] * prev;
+        prev = cur;
+        cur = nxt;
+    }
+    return cur;
+}
+
+void lz_bisec(const std::vector<double> &al, const std::vector<double> &be, int k, double tol, double *ymax,
+              double *zmin)
+{
+    // Gershgorin bounds of the leading (k+1) x (k+1) matrix (lanczos.py:22-32)
+    double zmax = al[0] + std::fabs(be[0]), ymin = al[0] - std::fabs(be[0]);
+    for (int l = 1; l < k; ++l) {
+        zmax = std::max(zmax, al[l] + std::fabs(be[l - 1]) + std::fabs(be[l]));
+        ymin = std::min(ymin, al[l] - std::fabs(be[l - 1]) - std::fabs(be[l]));
+    }
+    zmax = std::max(zmax, al[k] + std::fabs(be[k - 1]));
+    ymin = std::max(std::min(ymin, al[k] - std::fabs(be[k - 1])), 0.0);
+    double pz = lz_pol(al, be, k, zmax);
+    while (std::fabs(zmax - *ymax) > tol * std::min(std::fabs(zmax), std::fabs(*ymax))) {
+        const double mid = (*ymax + zmax) / 2.0, pm = lz_pol(al, be, k, mid);
+        if (std::signbit(pm) != std::signbit(pz))
+            *ymax = mid;
+        else
+            zmax = mid, pz = pm;
+    }
+    double py = lz_pol(al, be, k, *ymax);
+    if (std::signbit(pz) != std::signbit(py) && py != 0.0) *ymax = zmax;
+    py = lz_pol(al, be, k, ymin);
+    while (std::fabs(*zmin - ymin) > tol * std::min(std::fabs(*zmin), std::fabs(ymin))) {
+        const double mid = (ymin + *zmin) / 2.0, pm = lz_pol(al, be, k, mid);
+        if (std::signbit(pm) != std::signbit(py))
+            *zmin = mid;
+        else
+            ymin = mid, py = pm;
+    }
+    pz = lz_pol(al, be, k, *zmin);
+    if (std::signbit(pz) != std::signbit(py) && pz != 0.0) *zmin = ymin;
+}
+
+}  // namespace
+
+extern "C" int64_t stk_lanczos_work_size(int64_t n) { return 4 * n + stk_dot_work_size() + 2; }
+
+extern "C" int stk_lanczos(void *stream, int64_t n, stk_operator_fn A, void *A_ctx, stk_operator_fn P, void *P_ctx,
+                           stk_allreduce_fn allreduce, void *allreduce_ctx, double *w, int32_t max_iterations,
+                           double tol, double tol_bisec, double *work, double *alpha_host, double *beta_host,
+                           double *lmax, double *lmin, int32_t *iterations, int32_t *converged)
+{
+    STK_REQUIRE(n > 0 && (n & 1) == 0, "stk_lanczos: n=%lld must be positive and even", (long long)n);
+    STK_REQUIRE(A && P && w && work && lmax && lmin && iterations, "stk_lanczos: null argument");
+    STK_REQUIRE(max_iterations >= 2, "stk_lanczos: max_iterations=%d too small", max_iterations);
+    hipStream_t st = stk_stream(stream);
+    double *v = work, *u = work + n, *t = work + 2 * n, *wprev = work + 3 * n;
+    double *dot_work = work + 4 * n, *dot_out = dot_work + stk_dot_work_size();
+    auto dot = [&](const double *x, const double *y, double *value) -> int {
+        int rc = stk_dot(stream, n, x, y, dot_work, dot_out);
+        if (rc) return rc;
+        STK_HIP(hipMemcpyAsync(value, dot_out, sizeof(double), hipMemcpyDeviceToHost, st));
+        STK_HIP(hipStreamSynchronize(st));
+        if (allreduce) {
+            rc = allreduce(allreduce_ctx, value, 1);
+            if (rc) {
+                stk_set_error("stk_lanczos: allreduce callback failed (%d)", rc);
+                return rc;
+            }
+        }
+        return 0;
+    };
+    auto apply = [&](stk_operator_fn op, void *ctx, const double *x, double *y, const char *name) -> int {
+        const int rc = op(ctx, stream, x, y);
+        if (rc) stk_set_error("stk_lanczos: operator %s failed (%d)", name, rc);
+        return rc;
+    };
+#define STK_TRY(expr)        \
+    do {                     \
+        int rc_ = (expr);    \
+        if (rc_) return rc_; \
+    } while (0)
+    std::vector<double> al(max_iterations, 0.0), be(max_iterations, 0.0);
+    if (converged) *converged = 1;
+    // normalise the start vector in the A inner product (lanczos.py:109-115)
+    STK_TRY(apply(A, A_ctx, w, v, "A"));
+    double nrm2 = 0.0;
+    STK_TRY(dot(v, w, &nrm2));
+    STK_REQUIRE(nrm2 > 0.0, "stk_lanczos: start vector has w.Aw = %g", nrm2);
+    const double nrm = std::sqrt(nrm2);
+    STK_TRY(stk_axpby(stream, n, 0.0, v, 1.0 / nrm, v));  // v /= nrm
+    STK_TRY(stk_axpby(stream, n, 0.0, w, 1.0 / nrm, w));  // w /= nrm
+    STK_TRY(apply(P, P_ctx, v, u, "P"));                  // v = P v (into u, then swap roles)
+    std::swap(v, u);
+    STK_TRY(apply(A, A_ctx, v, u, "A"));
+    STK_TRY(dot(u, w, &al[0]));
+    double hi = al[0], lo = al[0];
+    int k = 0;
+    while (true) {  // lanczos.py:121-150
+        if (k == max_iterations - 1) {
+            if (converged) *converged = 0;
+            break;
+        }
+        STK_TRY(stk_axpby(stream, n, -al[k], w, 1.0, v));  // v -= alpha_k w
+        STK_TRY(apply(A, A_ctx, v, u, "A"));
+        double b2 = 0.0;
+        STK_TRY(dot(u, v, &b2));
+        be[k] = std::sqrt(std::max(b2, 0.0));
+        if (be[k] == 0.0) {  // invariant subspace: the Ritz values are final
+            ++k;
+            al[k] = al[k - 1];
+            break;
+        }
+        // w_prev, w = w, v / beta ; v = -beta w_prev
+        STK_TRY(stk_axpbyz(stream, n, 1.0, w, 0.0, w, wprev));
+        STK_TRY(stk_axpbyz(stream, n, 1.0 / be[k], v, 0.0, v, w));
+        STK_TRY(stk_axpbyz(stream, n, -be[k], wprev, 0.0, wprev, v));
+        STK_TRY(apply(A, A_ctx, w, u, "A"));
+        STK_TRY(apply(P, P_ctx, u, t, "P"));
+        STK_TRY(stk_axpby(stream, n, 1.0, t, 1.0, v));  // v += P A w
+        ++k;
+        STK_TRY(apply(A, A_ctx, v, u, "A"));
+        STK_TRY(dot(u, w, &al[k]));
+        const double hi_prev = hi, lo_prev = lo;
+        lz_bisec(al, be, k, tol_bisec, &hi, &lo);
+        if ((hi - hi_prev) < tol * hi_prev && (lo_prev - lo) < tol * lo) break;
+    }
+#undef STK_TRY
+    *iterations = k + 1;
+    *lmax = hi;
+    *lmin = lo;
+    if (alpha_host)
+        for (int i = 0; i <= k && i < max_iterations; ++i) alpha_host[i] = al[i];
+    if (beta_host)
+        for (int i = 0; i < k && i < max_iterations - 1; ++i) beta_host[i] = be[i];
     return 0;
 }

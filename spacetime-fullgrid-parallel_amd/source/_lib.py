@@ -95,6 +95,11 @@ _PROTOTYPES = {
         c_p, c_i64, OPERATOR_FN, c_p, OPERATOR_FN, c_p, ALLREDUCE_FN, c_p, c_p,
         c_p, c_f64, c_i32, c_p, c_p, c_p
     ]),
+    'stk_lanczos_work_size': (c_i64, [c_i64]),
+    'stk_lanczos': (ctypes.c_int, [
+        c_p, c_i64, OPERATOR_FN, c_p, OPERATOR_FN, c_p, ALLREDUCE_FN, c_p, c_p,
+        c_i32, c_f64, c_f64, c_p, c_p, c_p, c_p, c_p, c_p, c_p
+    ]),
     'stk_kron_sum_apply': (ctypes.c_int, [
         c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_i32,
         ctypes.POINTER(KronTerm), c_f64, c_p

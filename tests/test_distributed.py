@@ -72,6 +72,23 @@ def test_rccl_backend_executes_on_one_rank():
 
 
 @pytest.mark.gpu
+def test_distributed_solve_over_rccl_on_two_gpus():
+    """The same worker with one rank per GPU and backend nccl (= RCCL over xGMI):
+    ghost-row send/recv, wavelet partner exchange and the scalar all-reduce on
+    device buffers.  Needs a node with two GPUs; the one-GPU test box skips it
+    (the driver's 8-GPU bench is then the first execution of this transport
+    across devices)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs')
+    out = _run('mp_gpu_worker.py', 2, {'STK_BACKEND': 'nccl',
+                                       'STK_TEST_PROBLEM': 'square'})
+    assert 'mp_gpu_worker ok' in out
+    out = _run('mp_ops_worker.py', 2, {'STK_BACKEND': 'nccl'})
+    assert 'mp_ops_worker ok' in out
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('nproc,backend', [(1, 'nccl'), (2, 'gloo'), (4, 'gloo')])
 def test_bench_runs_as_the_driver_launches_it(nproc, backend):
     """bench.py itself (kron steps + a short solve), launched as the driver

@@ -800,6 +800,70 @@ def test_c_pcg_solve_matches_python_pcg(stk):
     assert relerr(_np(w), _np(w_py)) < 1e-9
 
 
+def test_c_lanczos_matches_python_lanczos(stk):
+    """stk_lanczos (C ABI, reference lanczos.py:87-159) driven through ctypes
+    callbacks into the same operators as the Python Lanczos: identical iteration
+    count, recurrence coefficients and eigenvalue brackets."""
+    import ctypes
+    import heateq_mpi as hm
+    from source.lanczos import Lanczos
+    from source.mpi_vector import KronVectorMPI
+    h = hm.HeatEquationMPI(J_space=3, J_time=3)
+    dd = h.dofs_distr
+    rng = np.random.default_rng(11)
+    start = KronVectorMPI(dd)
+    start.buf[:, :dd.n_loc] = torch.from_numpy(
+        2.0 * rng.random((h.M, dd.n_loc)) - 1.0).cuda()
+    w_py = KronVectorMPI(dd)
+    w_py.buf.copy_(start.buf)
+    lz = Lanczos(h.WT_S_W, h.P, w=w_py)
+
+    lib = stk.lib()
+    n = start.buf.numel()
+    work = torch.zeros(lib.stk_lanczos_work_size(n), dtype=torch.float64, device='cuda')
+    known = {start.buf.data_ptr(): start.buf}
+    for k in range(4):
+        view = work[k * n:(k + 1) * n].view(h.M, -1)
+        known[view.data_ptr()] = view
+
+    def wrap(op):
+        def fn(ctx, stream, x_ptr, y_ptr):
+            try:
+                vin = KronVectorMPI(dd)
+                vin._buf = known[x_ptr]
+                known[y_ptr].copy_((op @ vin).buf)
+                return 0
+            except Exception:  # never let an exception cross the C frame
+                return 1
+        return stk.OPERATOR_FN(fn)
+
+    A_cb, P_cb = wrap(h.WT_S_W), wrap(h.P)
+    kmax = 200
+    alpha = (ctypes.c_double * kmax)()
+    beta = (ctypes.c_double * (kmax - 1))()
+    lmax, lmin = ctypes.c_double(), ctypes.c_double()
+    its, conv = ctypes.c_int32(), ctypes.c_int32()
+    stk.check(lib.stk_lanczos(stk.stream(), n, A_cb, None, P_cb, None,
+                              stk.ALLREDUCE_FN(), None, stk.ptr(start.buf), kmax,
+                              Lanczos.TOL, Lanczos.TOLBISEC, stk.ptr(work), alpha, beta,
+                              ctypes.byref(lmax), ctypes.byref(lmin),
+                              ctypes.byref(its), ctypes.byref(conv)))
+    assert conv.value == 1 and lz.converged
+    assert its.value == lz.iterations
+    k = its.value - 1
+    assert np.allclose(list(alpha)[:k], lz.alpha, rtol=1e-8)
+    assert np.allclose(list(beta)[:k - 1], lz.beta, rtol=1e-7)
+    assert abs(lmax.value - lz.lmax) < 1e-8 * lz.lmax
+    assert abs(lmin.value - lz.lmin) < 1e-8 * lz.lmin
+    # a failing callback is reported, not swallowed
+    bad = stk.OPERATOR_FN(lambda ctx, stream, x, y: 7)
+    rc = lib.stk_lanczos(stk.stream(), n, bad, None, P_cb, None, stk.ALLREDUCE_FN(),
+                         None, stk.ptr(start.buf), kmax, 1e-4, 1e-6, stk.ptr(work),
+                         None, None, ctypes.byref(lmax), ctypes.byref(lmin),
+                         ctypes.byref(its), ctypes.byref(conv))
+    assert rc == 7 and b'operator A failed' in lib.stk_last_error()
+
+
 def test_restricted_residual_variants_agree(stk):
     """d = R (A u - f) in two steps, or as (R A) u - R f with the precomputed
     product R A (stk_mg_level.ell_ra): same V-cycle up to rounding."""
