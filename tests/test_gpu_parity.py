@@ -812,8 +812,8 @@ def test_c_lanczos_matches_python_lanczos(stk):
     dd = h.dofs_distr
     rng = np.random.default_rng(11)
     start = KronVectorMPI(dd)
-    start.buf[:, :dd.n_loc] = torch.from_numpy(
-        2.0 * rng.random((h.M, dd.n_loc)) - 1.0).cuda()
+    start.buf[:, :start.n_loc] = torch.from_numpy(
+        2.0 * rng.random((h.M, start.n_loc)) - 1.0).cuda()
     w_py = KronVectorMPI(dd)
     w_py.buf.copy_(start.buf)
     lz = Lanczos(h.WT_S_W, h.P, w=w_py)
