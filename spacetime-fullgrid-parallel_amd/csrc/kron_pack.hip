@@ -97,13 +97,10 @@ __global__ __launch_bounds__(BS, K >= 12 ? 4 : 6) void kron_pack_kernel(const Pa
     const bool ghost_lane = GHOST && p == a.P;
     const int t0 = 2 * p;  // own lanes: first time step of the pair
     const bool has1 = t0 + 1 < a.n_loc;
-    // what distinguishes the lanes of a row: where their 16 bytes of a column start.
-    // Split layout (ld == n_loc - 1, stk.h): the last step of every row lives in the
-    // tail block behind the M x ld main block, 16 bytes per row like a ghost pair.
-    const bool tail_lane = !ghost_lane && t0 >= a.ld;
-    const size_t off_lane = ghost_lane ? 0 : tail_lane ? (size_t)a.M * a.ld * 8 : (size_t)t0 * 8;
-    const char *base_lane = reinterpret_cast<const char *>(ghost_lane ? a.gh : a.x) + off_lane;
-    const uint32_t stride_lane = (ghost_lane || tail_lane) ? 16u : (uint32_t)a.ld * 8u;
+    // what distinguishes the lanes of a row: where their 16 bytes of a column start
+    const char *base_lane = ghost_lane ? reinterpret_cast<const char *>(a.gh)
+                                       : reinterpret_cast<const char *>(a.x) + (size_t)t0 * 8;
+    const uint32_t stride_lane = ghost_lane ? 16u : (uint32_t)a.ld * 8u;
     const uint32_t col_mask = (1u << a.col_bits) - 1u;
     // where a lane leaves its two sums in s_w (index q = t + 1)
     const int wq0 = ghost_lane ? 0 : t0 + 1;
@@ -297,8 +294,8 @@ __global__ __launch_bounds__(BS, K >= 12 ? 4 : 6) void kron_pack_kernel(const Pa
         }
         if (active && !ghost_lane) {
             if (!has1) y1 = 0.0;  // padding slot stays zero
-            double2 *dst =
-                reinterpret_cast<double2 *>(reinterpret_cast<char *>(a.y) + off_lane + (size_t)yrow * stride_lane);
+            double2 *dst = reinterpret_cast<double2 *>(reinterpret_cast<char *>(a.y) +
+                                                        (size_t)yrow * ((size_t)a.ld * 8) + (size_t)t0 * 8);
             if (a.beta != 0.0) {
                 const double2 old = *dst;
                 y0 = fma(a.beta, old.x, y0);
@@ -457,9 +454,8 @@ extern "C" int stk_kron_pack_apply(void *stream, const stk_pack_pattern *pat, in
                 "stk_kron_pack_apply: col_bits=%d cannot address %d columns", pat->col_bits, pat->M);
     STK_REQUIRE(pat->n_codes >= 1 && (int64_t)pat->n_codes <= ((int64_t)1 << (32 - pat->col_bits)),
                 "stk_kron_pack_apply: %d codes do not fit %d bits", pat->n_codes, 32 - pat->col_bits);
-    STK_REQUIRE(n_loc > 0 && (ld >= n_loc || (ld == n_loc - 1 && ld >= 2)) && (ld & 1) == 0,
-                "stk_kron_pack_apply: bad sizes n_loc=%d ld=%d (ld must be even; n_loc - 1 = split layout)", n_loc,
-                ld);
+    STK_REQUIRE(n_loc > 0 && ld >= n_loc && (ld & 1) == 0,
+                "stk_kron_pack_apply: bad sizes n_loc=%d ld=%d (ld must be even)", n_loc, ld);
     STK_REQUIRE(n_terms >= 1 && n_terms <= 3, "stk_kron_pack_apply: n_terms=%d not in 1..3", n_terms);
     STK_REQUIRE((n_loc + 1) / 2 + 2 <= 512, "stk_kron_pack_apply: n_loc=%d too large", n_loc);
     STK_REQUIRE(x != y, "stk_kron_pack_apply: input aliases output");

@@ -26,8 +26,6 @@ ap.add_argument('--problem', default='square')
 ap.add_argument('--n_loc', type=int, default=65)
 ap.add_argument('--ghosts', type=int, default=0)
 ap.add_argument('--ld', type=int, default=0, help='row stride in doubles (0: n_loc rounded up to even)')
-ap.add_argument('--split', type=int, default=0,
-                help='1: split layout (M x (n_loc-1) main block + one 16-byte tail pair per row), checked against the classic one')
 ap.add_argument('--rounds', type=int, default=9)
 ap.add_argument('--reps', type=int, default=20)
 ap.add_argument('--variants', default='plain;pack;pack,pack_flags=1;pack,pack_flags=2;pack,pack_flags=3')
@@ -48,13 +46,6 @@ ld = args.ld or (n_loc + (n_loc & 1))
 rng = np.random.RandomState(0)
 x = torch.rand((M, ld), dtype=torch.float64, device='cuda')
 x[:, n_loc:] = 0
-if args.split:
-    assert n_loc % 2 == 1 and not args.ld
-    ld = n_loc - 1
-    x_classic = x
-    x = torch.zeros(M * (n_loc + 1), dtype=torch.float64, device='cuda')
-    x[:M * ld].view(M, ld).copy_(x_classic[:, :ld])
-    x[M * ld:].view(M, 2)[:, 0] = x_classic[:, ld]
 y = torch.empty_like(x)
 tri = [_lib.to_dev(rng.rand(3, n_loc)) for _ in range(2)]
 g = torch.rand((2, M), dtype=torch.float64, device='cuda') if args.ghosts else None
@@ -79,16 +70,6 @@ def run(variant):
     return lambda: ell.packed.apply([(tri[0], 0), (tri[1], 1)], x, gh, n_loc, ld, 0.0, y)
 
 
-if args.split:
-    y_classic = torch.empty_like(x_classic)
-    ell.packed.apply([(tri[0], 0), (tri[1], 1)], x_classic, gh, n_loc, n_loc + 1, 0.0, y_classic)
-    y.fill_(7.0)
-    ell.packed.apply([(tri[0], 0), (tri[1], 1)], x, gh, n_loc, ld, 0.0, y)
-    torch.cuda.synchronize()
-    same = (torch.equal(y[:M * ld].view(M, ld), y_classic[:, :ld])
-            and torch.equal(y[M * ld:].view(M, 2), y_classic[:, ld:ld + 2]))
-    print('split layout bit-identical with the classic layout: %s' % same, flush=True)
-    assert same
 variants = args.variants.split(';')
 times = {v: [] for v in variants}
 for rnd in range(args.rounds):
