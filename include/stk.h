@@ -191,10 +191,20 @@ typedef struct {
     int32_t col_bits; /* 2^col_bits >= M */
     int32_t n_codes;  /* <= 2^(32 - col_bits) */
     int32_t n_mats;
-    const uint32_t *slots;  /* M*K */
-    const int32_t *row_ids; /* M or NULL */
-    const double *dict;     /* n_mats*n_codes */
+    int32_t rows_per_unit;  /* 1, or 2 = row pairs (below) */
+    int32_t n_units;        /* slot rows: M when rows_per_unit = 1 */
+    const uint32_t *slots;  /* n_units*K */
+    const int32_t *row_ids; /* n_units*rows_per_unit; NULL (index order) only when rows_per_unit = 1 */
+    const double *dict;     /* n_mats*n_codes*rows_per_unit */
 } stk_pack_pattern;
+/* Row pairs (rows_per_unit = 2): slot row u serves the matrix rows
+ * row_ids[2u] and row_ids[2u + 1] (-1: none); its K slots (K one of 8, 10, 12)
+ * list the UNION of their columns in ascending order, and matrix m has the
+ * values dict[(m*n_codes + code)*2 + j] for row j of the pair (zero where that
+ * row has no entry in the column).  Two neighbouring vertices of a P1
+ * triangulation share 4 of their 7 columns, so a pair costs 10 gathers
+ * instead of 14; every row's sum is still accumulated in ascending column
+ * order, so the results are bit-identical with rows_per_unit = 1. */
 
 typedef struct {
     const double *tri; /* as in stk_kron_term */

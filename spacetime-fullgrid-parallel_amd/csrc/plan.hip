@@ -140,7 +140,7 @@ int build(stk_kron_plan *p, int32_t M, int32_t n_mats, const int32_t *const *ind
     uint32_t *d_slots;
     double *d_dict;
     if (upload(p, slots_w, &d_slots) || upload(p, table, &d_dict)) return 1;
-    p->pack = stk_pack_pattern{M, K, col_bits, n_codes, n_mats, d_slots, order ? d_rows : nullptr, d_dict};
+    p->pack = stk_pack_pattern{M, K, col_bits, n_codes, n_mats, 1, M, d_slots, order ? d_rows : nullptr, d_dict};
     p->packed = true;
     return 0;
 }

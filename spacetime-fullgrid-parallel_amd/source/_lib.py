@@ -42,7 +42,8 @@ class KronEllTerm(ctypes.Structure):
 
 class PackPattern(ctypes.Structure):
     _fields_ = [('M', c_i32), ('K', c_i32), ('col_bits', c_i32),
-                ('n_codes', c_i32), ('n_mats', c_i32), ('slots', c_p),
+                ('n_codes', c_i32), ('n_mats', c_i32),
+                ('rows_per_unit', c_i32), ('n_units', c_i32), ('slots', c_p),
                 ('row_ids', c_p), ('dict', c_p)]
 
 

@@ -14,6 +14,7 @@ KronLinOp / BlockDiagLinOp are the serial (single-rank, flat NumPy vector in /
 out) operators of reference linop.py:6-15, 29-44, run on the device.
 """
 import ctypes
+import os
 import threading
 import weakref
 
@@ -325,8 +326,17 @@ class EllMatrices:
                                        _lib.ptr(self.row_ids),
                                        _lib.ptr(self.ovf_indptr),
                                        _lib.ptr(self.ovf_indices))
-        self.packed = PackedEllMatrices(M, K, ell_idx, ell_vals, self.row_ids,
-                                        not main.all())
+        self._pack_args = (M, K, ell_idx, ell_vals, self.row_ids,
+                           not main.all(), counts, own)
+        self.packed = self.packed_variant(PackedEllMatrices.ROWS_PER_UNIT)
+
+    def packed_variant(self, rows_per_unit):
+        """The packed form with 1 or 2 matrix rows per slot row (falls back to 1
+        where rows cannot be paired)."""
+        packed = PackedEllMatrices(*self._pack_args, rows_per_unit=rows_per_unit)
+        if not packed.ok and rows_per_unit > 1:
+            packed = PackedEllMatrices(*self._pack_args, rows_per_unit=1)
+        return packed
 
     def _terms(self, specs, ghosts):
         terms = (_lib.KronEllTerm * len(specs))()
@@ -364,14 +374,22 @@ class PackedEllMatrices:
     """The matrices of an EllMatrices plan in the packed form of
     ``stk_kron_pack_apply`` (include/stk.h): one 32-bit word per slot,
     ``code << col_bits | column``, plus the dictionary of the distinct value
-    tuples of the union pattern.  ``ok`` is False when the plan does not fit
-    (overflow rows, or more distinct tuples than the free bits can name); the
-    caller then keeps the plain form."""
-    MAX_CODES = 512  # the dictionary lives in LDS next to the exchange buffers
+    tuples of the union pattern.  With ``rows_per_unit = 2`` rows that follow
+    each other in the processing order and share columns (mesh neighbours) are
+    served by ONE slot row listing the union of their columns.  ``ok`` is False
+    when the plan does not fit (overflow rows, more distinct tuples than the
+    free bits can name, a slot count without a pair instantiation); the caller
+    then keeps the plain form."""
+    MAX_CODES = 512  # dictionary entries (codes x rows per unit) in LDS next to the exchange buffers
+    ROWS_PER_UNIT = int(os.environ.get('STK_PACK_ROWS', '2'))
+    PAIR_SLOTS = {5: 8, 7: 10, 9: 12}  # slots of a pair of rows with K slots each (csrc/kron_pack.hip)
 
-    def __init__(self, M, K, ell_idx, ell_vals, row_ids, has_overflow):
+    def __init__(self, M, K, ell_idx, ell_vals, row_ids, has_overflow,
+                 counts=None, own=None, rows_per_unit=1):
         self.ok = False
         if has_overflow or M < 1:
+            return
+        if rows_per_unit == 2 and (K not in self.PAIR_SLOTS or counts is None):
             return
         col_bits = max(1, int(M - 1).bit_length())
         # distinct value tuples, by bit pattern (+0.0 and -0.0 stay distinct):
@@ -387,22 +405,105 @@ class PackedEllMatrices:
             col = u[uc % len(u)][:, None]
             table = col if table is None else np.hstack(
                 [table[uc // len(u)], col])
-        uniq = table
+        uniq = table  # (n_codes, n_mats) bit patterns
+        cols = ell_idx.reshape(M, K)
+        unit_rows = None
+        if rows_per_unit == 2:
+            paired = self._pair_rows(M, K, cols, codes.reshape(M, K), uniq,
+                                     np.asarray(counts), np.asarray(own))
+            if paired is None:
+                return
+            cols, codes, uniq, unit_rows = paired
         if len(uniq) > (1 << (32 - col_bits)):
             return
         self.ok = True
-        self.M, self.K, self.col_bits, self.n_codes = M, K, col_bits, len(uniq)
+        self.rows_per_unit = rows_per_unit
+        self.n_units, self.K = cols.shape
+        self.M, self.col_bits, self.n_codes = M, col_bits, len(uniq)
         self.n_mats = len(ell_vals)
         slots = (codes.reshape(-1).astype(np.uint32) << np.uint32(col_bits)
-                 ) | ell_idx.reshape(-1).astype(np.uint32)
-        self.slots = _lib.to_dev(slots.view(np.int32).reshape(M, K))
-        # dict[m][code]
-        self.dict = _lib.to_dev(
-            np.ascontiguousarray(uniq.view(np.float64).T.copy()))
-        self.row_ids = row_ids
-        self.pattern = _lib.PackPattern(M, K, col_bits, self.n_codes,
-                                        len(ell_vals), _lib.ptr(self.slots),
-                                        _lib.ptr(row_ids), _lib.ptr(self.dict))
+                 ) | cols.reshape(-1).astype(np.uint32)
+        self.slots = _lib.to_dev(slots.view(np.int32).reshape(cols.shape))
+        # dict[m][code][row of the unit]
+        self.dict = _lib.to_dev(np.ascontiguousarray(
+            uniq.reshape(len(uniq), rows_per_unit, self.n_mats).transpose(
+                2, 0, 1)).view(np.float64))
+        self.row_ids = row_ids if unit_rows is None else _lib.to_dev(unit_rows)
+        self.pattern = _lib.PackPattern(M, self.K, col_bits, self.n_codes,
+                                        self.n_mats, rows_per_unit,
+                                        self.n_units, _lib.ptr(self.slots),
+                                        _lib.ptr(self.row_ids),
+                                        _lib.ptr(self.dict))
+
+    def _pair_rows(self, M, K, cols, codes, uniq, counts, own):
+        """Rows p, p + 1 of the processing order whose union of columns fits the
+        pair's slot count become one unit (greedily, left to right); the others
+        stay alone in theirs.  Returns (columns, codes, dictionary, rows) of the
+        units; the dictionary rows are (values of row 0 | values of row 1)."""
+        K2 = self.PAIR_SLOTS[K]
+        n_mats = uniq.shape[1]
+        BIG = np.int64(1) << 40
+        zero = np.flatnonzero((uniq == 0).all(axis=1))  # code of "no entry" (+0.0 everywhere)
+        if len(zero) == 0:
+            uniq = np.vstack([uniq, np.zeros((1, n_mats), dtype=uniq.dtype)])
+            zero = [len(uniq) - 1]
+        zero = int(zero[0])
+        real = np.arange(K)[None, :] < counts[:, None]
+        c = np.where(real, cols.astype(np.int64), BIG)
+        if M > 1:
+            shared = ((c[:-1, :, None] == c[1:, None, :]) &
+                      real[:-1, :, None]).sum(axis=(1, 2))
+            fits = counts[:-1] + counts[1:] - shared <= K2
+        else:
+            fits = np.zeros(0, dtype=bool)
+        idx = np.arange(M - 1)
+        last_break = np.maximum.accumulate(np.where(fits, -1, idx)) if M > 1 else idx
+        first = np.zeros(M, dtype=bool)
+        first[:-1] = fits & ((idx - last_break - 1) % 2 == 0)
+        second = np.zeros(M, dtype=bool)
+        second[1:] = first[:-1]
+        head = np.flatnonzero(~second)             # first (or only) row of every unit
+        mate = np.where(first[head], head + 1, -1)  # its partner or -1
+        has = mate >= 0
+        U = len(head)
+        if 2 * U > 1.9 * M:  # hardly any pairs: not worth the wider slot rows
+            return None
+        ca = np.where(real[head], codes[head], zero)
+        cb = np.full((U, K), zero, dtype=np.int64)
+        cb[has] = np.where(real[mate[has]], codes[mate[has]], zero)
+        colb = np.full((U, K), BIG, dtype=np.int64)
+        colb[has] = c[mate[has]]
+        ucol = np.concatenate([c[head], colb], axis=1)
+        uca = np.concatenate([ca, np.full((U, K), zero, dtype=np.int64)], axis=1)
+        ucb = np.concatenate([np.full((U, K), zero, dtype=np.int64), cb], axis=1)
+        order = np.argsort(ucol, axis=1, kind='stable')
+        ucol = np.take_along_axis(ucol, order, axis=1)
+        uca = np.take_along_axis(uca, order, axis=1)
+        ucb = np.take_along_axis(ucb, order, axis=1)
+        # a column both rows have: row 0's entry comes first (stable sort)
+        dup = (ucol[:, 1:] == ucol[:, :-1]) & (ucol[:, 1:] < BIG)
+        ucb[:, :-1][dup] = ucb[:, 1:][dup]
+        ucol[:, 1:][dup] = BIG
+        uca[:, 1:][dup] = zero
+        ucb[:, 1:][dup] = zero
+        order = np.argsort(ucol, axis=1, kind='stable')
+        ucol = np.take_along_axis(ucol, order, axis=1)
+        uca = np.take_along_axis(uca, order, axis=1)
+        ucb = np.take_along_axis(ucb, order, axis=1)
+        assert (ucol[:, K2:] == BIG).all()
+        ucol, uca, ucb = ucol[:, :K2], uca[:, :K2], ucb[:, :K2]
+        pad = ucol == BIG
+        assert (uca[pad] == zero).all() and (ucb[pad] == zero).all()
+        ucol = np.where(pad, own[head].astype(np.int64)[:, None], ucol)
+        n1 = len(uniq)
+        upair, ucode = np.unique(uca * n1 + ucb, return_inverse=True)
+        if 2 * len(upair) > self.MAX_CODES:
+            return None
+        pair_dict = np.hstack([uniq[upair // n1], uniq[upair % n1]])
+        rows = np.stack([own[head], np.where(has, own[np.maximum(mate, 0)], -1)],
+                        axis=1).astype(np.int32)
+        return (ucol.astype(np.int64), ucode.reshape(U, K2), pair_dict,
+                np.ascontiguousarray(rows))
 
     def apply(self, specs, x, ghosts, n_loc, ld, beta, out):
         """y = beta*y + sum over specs (tri, matrix index) applied to x;

@@ -67,7 +67,19 @@ def run(variant):
         _lib.check(_lib.lib().stk_set_tuning(k.encode(), int(v)))
     if parts[0] == 'plain':
         return lambda: ell.apply([(tri[0], 0, x, lo, hi), (tri[1], 1, x, lo, hi)], n_loc, ld, 0.0, y)
-    return lambda: ell.packed.apply([(tri[0], 0), (tri[1], 1)], x, gh, n_loc, ld, 0.0, y)
+    form = {'pack': ell.packed, 'pack1': packed1, 'pack2': packed2}[parts[0]]
+    return lambda: form.apply([(tri[0], 0), (tri[1], 1)], x, gh, n_loc, ld, 0.0, y)
+
+
+packed1, packed2 = ell.packed_variant(1), ell.packed_variant(2)
+print('packed forms: default %d row(s) per unit; pairs: %d units for %d rows, K=%d, %d codes'
+      % (ell.packed.rows_per_unit, packed2.n_units, M, packed2.K, packed2.n_codes), flush=True)
+y1, y2 = torch.full_like(x, 3.0), torch.full_like(x, 5.0)
+packed1.apply([(tri[0], 0), (tri[1], 1)], x, gh, n_loc, ld, 0.0, y1)
+packed2.apply([(tri[0], 0), (tri[1], 1)], x, gh, n_loc, ld, 0.0, y2)
+torch.cuda.synchronize()
+print('pairs bit-identical with single rows: %s' % torch.equal(y1, y2), flush=True)
+assert torch.equal(y1, y2)
 
 
 variants = args.variants.split(';')
@@ -96,7 +108,7 @@ if args.phases and g is None:
         _lib.check(_lib.lib().stk_set_tuning(k.encode(), v))
     buf = torch.zeros((4096 * 8, 4), dtype=torch.int64, device='cuda')
     _lib.check(_lib.lib().stk_kron_pack_set_diag(buf.data_ptr()))
-    fn = run('pack')
+    fn = run('pack1')
     for _ in range(3):
         buf.zero_()
         fn()
