@@ -237,9 +237,13 @@ int stk_kron_plan_create(int32_t M, int32_t n_mats,
                          const double *const *data_host,
                          const int32_t *row_order_host, stk_kron_plan **out);
 int stk_kron_plan_destroy(stk_kron_plan *plan);
-/* Any output may be NULL.  packed = 1 if the dictionary form was built. */
+/* Any output may be NULL.  K: slots per row of the sliced-ELL copy; packed = 1
+ * if the dictionary form was built; rows_per_unit = 2 if it serves row pairs
+ * (tuning key "pack_rows" = 1 keeps one row per slot row in plans created
+ * afterwards). */
 int stk_kron_plan_info(const stk_kron_plan *plan, int32_t *K, int32_t *n_codes,
-                       int32_t *packed, int64_t *nnz_union);
+                       int32_t *packed, int64_t *nnz_union,
+                       int32_t *rows_per_unit);
 int stk_kron_plan_apply(stk_kron_plan *plan, void *stream, int32_t n_loc,
                         int32_t ld, int32_t n_terms,
                         const stk_kron_pack_term *terms_host, const double *x,

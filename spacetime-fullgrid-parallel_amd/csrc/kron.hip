@@ -20,6 +20,7 @@
 
 int stk_kron_ell_set_tuning(const char *key, int32_t value);  // kron_ell.hip
 int stk_kron_pack_set_tuning(const char *key, int32_t value);  // kron_pack.hip
+extern int g_plan_pack_rows;                                   // plan.hip
 int stk_rows_ell_set_tuning(const char *key, int32_t value);  // rows_ell.hip
 int stk_wavelet_set_tuning(const char *key, int32_t value);   // wavelet.hip
 extern int g_mg_fuse_coarse, g_mg_coarse_max_rows, g_mg_fuse_restrict, g_mg_zero_start, g_mg_strip_mb, g_mg_strips_used, g_mg_strip_width;  // mg.hip
@@ -410,6 +411,10 @@ extern "C" int stk_set_tuning(const char *key, int32_t value)
     if (stk_kron_pack_set_tuning(key, value) == 0) return 0;
     if (stk_rows_ell_set_tuning(key, value) == 0) return 0;
     if (stk_wavelet_set_tuning(key, value) == 0) return 0;
+    if (std::strcmp(key, "pack_rows") == 0) {  // plans created from now on: matrix rows per slot row (1 or 2)
+        g_plan_pack_rows = value >= 2 ? 2 : 1;
+        return 0;
+    }
     if (std::strcmp(key, "mg_strip_mb") == 0) {
         g_mg_strip_mb = value;
         return 0;

@@ -10,6 +10,8 @@
 // compare the results of the two bit for bit (the numbering of the dictionary
 // codes may differ, the products and their order do not).
 #include <algorithm>
+#include <climits>
+#include <cstdint>
 #include <cstring>
 #include <map>
 #include <vector>
@@ -27,6 +29,8 @@ struct stk_kron_plan {
     std::vector<void *> owned;  // every device allocation
     int64_t nnz_union = 0;
 };
+
+int g_plan_pack_rows = 2;  // tuning key "pack_rows": matrix rows per slot row of the packed form (1 or 2)
 
 namespace {
 
@@ -142,6 +146,87 @@ int build(stk_kron_plan *p, int32_t M, int32_t n_mats, const int32_t *const *ind
     if (upload(p, slots_w, &d_slots) || upload(p, table, &d_dict)) return 1;
     p->pack = stk_pack_pattern{M, K, col_bits, n_codes, n_mats, 1, M, d_slots, order ? d_rows : nullptr, d_dict};
     p->packed = true;
+    // ---- row pairs: rows pos, pos + 1 whose union of columns fits the pair's slot
+    // count share one slot row (greedily, left to right; source/linop.py does the
+    // same with NumPy) ------------------------------------------------------------
+    const int K2 = K == 5 ? 8 : K == 7 ? 10 : K == 9 ? 12 : 0;
+    if (K2 == 0 || g_plan_pack_rows < 2) return 0;
+    uint32_t zero_code = (uint32_t)n_codes;  // the tuple "no entry": +0.0 in every matrix
+    {
+        std::fill(key.begin(), key.end(), (uint64_t)0);
+        auto it = dict.find(key);
+        if (it != dict.end()) zero_code = rank[it->second];
+    }
+    const int n1 = zero_code == (uint32_t)n_codes ? n_codes + 1 : n_codes;
+    struct Unit {
+        int32_t a, b;
+    };
+    std::vector<Unit> units;
+    auto row_len = [&](int pos) { return u_ptr[pos + 1] - u_ptr[pos]; };
+    auto union_len = [&](int pa, int pb) {
+        int ia = u_ptr[pa], ib = u_ptr[pb], n = 0;
+        while (ia < u_ptr[pa + 1] && ib < u_ptr[pb + 1]) {
+            const int32_t ca = u_idx[ia], cb = u_idx[ib];
+            ia += ca <= cb, ib += cb <= ca, ++n;
+        }
+        return n + (u_ptr[pa + 1] - ia) + (u_ptr[pb + 1] - ib);
+    };
+    for (int pos = 0; pos < M;) {
+        if (pos + 1 < M && row_len(pos) + row_len(pos + 1) > 0 && union_len(pos, pos + 1) <= K2) {
+            units.push_back({pos, pos + 1});
+            pos += 2;
+        } else {
+            units.push_back({pos, -1});
+            pos += 1;
+        }
+    }
+    const size_t U = units.size();
+    if (2 * U > (size_t)(1.9 * M)) return 0;  // hardly any pairs: the one-row form stays
+    std::vector<uint32_t> ucol(U * K2), uab(U * K2);
+    std::vector<int32_t> urows(U * 2);
+    std::map<uint32_t, uint32_t> pair_codes;  // code_a * n1 + code_b -> number (assigned below, in key order)
+    auto code_at = [&](int pos, int e) { return rank[code[(size_t)pos * K + e]]; };
+    for (size_t u = 0; u < U; ++u) {
+        const int pa = units[u].a, pb = units[u].b;
+        urows[2 * u] = row_ids[pa];
+        urows[2 * u + 1] = pb >= 0 ? row_ids[pb] : -1;
+        const int na = row_len(pa), nb = pb >= 0 ? row_len(pb) : 0;
+        int ia = 0, ib = 0, n = 0;
+        while (ia < na || ib < nb) {
+            const int32_t ca = ia < na ? u_idx[u_ptr[pa] + ia] : INT32_MAX;
+            const int32_t cb = ib < nb ? u_idx[u_ptr[pb] + ib] : INT32_MAX;
+            const uint32_t va = ca <= cb ? code_at(pa, ia) : zero_code;
+            const uint32_t vb = cb <= ca ? code_at(pb, ib) : zero_code;
+            ucol[u * K2 + n] = (uint32_t)std::min(ca, cb);
+            uab[u * K2 + n] = va * (uint32_t)n1 + vb;
+            ia += ca <= cb, ib += cb <= ca, ++n;
+        }
+        for (; n < K2; ++n) {  // unused: the first row's own column, no entry in either row
+            ucol[u * K2 + n] = (uint32_t)row_ids[pa];
+            uab[u * K2 + n] = zero_code * (uint32_t)n1 + zero_code;
+        }
+    }
+    for (uint32_t v : uab) pair_codes.emplace(v, 0u);
+    if (2 * pair_codes.size() > 512 || (int64_t)pair_codes.size() > ((int64_t)1 << (32 - col_bits))) return 0;
+    {
+        uint32_t r = 0;
+        for (auto &kv : pair_codes) kv.second = r++;
+    }
+    const int n_pair = (int)pair_codes.size();
+    auto value_of = [&](uint32_t c, int m) { return c < (uint32_t)n_codes ? table[(size_t)m * n_codes + c] : 0.0; };
+    std::vector<double> pair_table((size_t)n_mats * n_pair * 2);
+    for (auto &kv : pair_codes)
+        for (int m = 0; m < n_mats; ++m) {
+            pair_table[((size_t)m * n_pair + kv.second) * 2] = value_of(kv.first / n1, m);
+            pair_table[((size_t)m * n_pair + kv.second) * 2 + 1] = value_of(kv.first % n1, m);
+        }
+    std::vector<uint32_t> pair_slots(U * K2);
+    for (size_t s2 = 0; s2 < U * K2; ++s2) pair_slots[s2] = (pair_codes[uab[s2]] << col_bits) | ucol[s2];
+    uint32_t *d_pslots;
+    int32_t *d_urows;
+    double *d_pdict;
+    if (upload(p, pair_slots, &d_pslots) || upload(p, urows, &d_urows) || upload(p, pair_table, &d_pdict)) return 1;
+    p->pack = stk_pack_pattern{M, K2, col_bits, n_pair, n_mats, 2, (int32_t)U, d_pslots, d_urows, d_pdict};
     return 0;
 }
 
@@ -187,9 +272,10 @@ extern "C" int stk_kron_plan_destroy(stk_kron_plan *p)
 }
 
 extern "C" int stk_kron_plan_info(const stk_kron_plan *p, int32_t *K, int32_t *n_codes, int32_t *packed,
-                                  int64_t *nnz_union)
+                                  int64_t *nnz_union, int32_t *rows_per_unit)
 {
     STK_REQUIRE(p, "stk_kron_plan_info: null plan");
+    if (rows_per_unit) *rows_per_unit = p->packed ? p->pack.rows_per_unit : 1;
     if (K) *K = p->K;
     if (n_codes) *n_codes = p->packed ? p->pack.n_codes : 0;
     if (packed) *packed = p->packed ? 1 : 0;

@@ -123,7 +123,7 @@ _PROTOTYPES = {
         ctypes.POINTER(c_p), c_p, ctypes.POINTER(c_p)
     ]),
     'stk_kron_plan_destroy': (ctypes.c_int, [c_p]),
-    'stk_kron_plan_info': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p]),
+    'stk_kron_plan_info': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p]),
     'stk_kron_plan_apply': (ctypes.c_int, [
         c_p, c_p, c_i32, c_i32, c_i32, ctypes.POINTER(KronPackTerm), c_p, c_p,
         c_p, c_p, c_f64, c_p

@@ -370,6 +370,31 @@ class EllMatrices:
                 len(specs), self._terms(specs, True), _lib.ptr(out)))
 
 
+def _few_unique(v, limit):
+    """np.unique(v, return_inverse=True) for an int64 array that is expected to
+    hold at most `limit` distinct values: candidates from a sample, then binary
+    search of everything (no sort of the whole array).  None if there are more."""
+    v = np.ascontiguousarray(v).reshape(-1)
+    u = np.unique(v[::max(1, len(v) // 65536)])
+    while len(u) <= limit:
+        pos = np.minimum(np.searchsorted(u, v), len(u) - 1)
+        miss = u[pos] != v
+        if not miss.any():
+            return u, pos
+        u = np.union1d(u, np.unique(v[miss][:1 << 20]))
+    return None
+
+
+def _small_unique(v, bound):
+    """np.unique(v, return_inverse=True) for non-negative integers below a small
+    `bound` (a table instead of a sort)."""
+    present = np.zeros(bound, dtype=bool)
+    present[v] = True
+    u = np.flatnonzero(present)
+    lut = np.cumsum(present) - 1
+    return u, lut[v]
+
+
 class PackedEllMatrices:
     """The matrices of an EllMatrices plan in the packed form of
     ``stk_kron_pack_apply`` (include/stk.h): one 32-bit word per slot,
@@ -396,10 +421,11 @@ class PackedEllMatrices:
         # one 1-D unique per matrix, then one over the combined codes
         codes, table = np.zeros(M * K, dtype=np.int64), None
         for e in ell_vals:
-            u, inv = np.unique(e.reshape(-1).view(np.int64), return_inverse=True)
-            if len(u) > self.MAX_CODES:
+            found = _few_unique(e.reshape(-1).view(np.int64), self.MAX_CODES)
+            if found is None:
                 return
-            uc, codes = np.unique(codes * len(u) + inv, return_inverse=True)
+            u, inv = found
+            uc, codes = _small_unique(codes * len(u) + inv, self.MAX_CODES * len(u))
             if len(uc) > self.MAX_CODES:
                 return
             col = u[uc % len(u)][:, None]
@@ -442,14 +468,14 @@ class PackedEllMatrices:
         units; the dictionary rows are (values of row 0 | values of row 1)."""
         K2 = self.PAIR_SLOTS[K]
         n_mats = uniq.shape[1]
-        BIG = np.int64(1) << 40
+        BIG = np.int32(2**31 - 1)
         zero = np.flatnonzero((uniq == 0).all(axis=1))  # code of "no entry" (+0.0 everywhere)
         if len(zero) == 0:
             uniq = np.vstack([uniq, np.zeros((1, n_mats), dtype=uniq.dtype)])
             zero = [len(uniq) - 1]
         zero = int(zero[0])
         real = np.arange(K)[None, :] < counts[:, None]
-        c = np.where(real, cols.astype(np.int64), BIG)
+        c = np.where(real, cols.astype(np.int32), BIG)
         if M > 1:
             shared = ((c[:-1, :, None] == c[1:, None, :]) &
                       real[:-1, :, None]).sum(axis=(1, 2))
@@ -468,14 +494,15 @@ class PackedEllMatrices:
         U = len(head)
         if 2 * U > 1.9 * M:  # hardly any pairs: not worth the wider slot rows
             return None
-        ca = np.where(real[head], codes[head], zero)
-        cb = np.full((U, K), zero, dtype=np.int64)
-        cb[has] = np.where(real[mate[has]], codes[mate[has]], zero)
-        colb = np.full((U, K), BIG, dtype=np.int64)
+        codes = codes.astype(np.int32)
+        ca = np.where(real[head], codes[head], np.int32(zero))
+        cb = np.full((U, K), zero, dtype=np.int32)
+        cb[has] = np.where(real[mate[has]], codes[mate[has]], np.int32(zero))
+        colb = np.full((U, K), BIG, dtype=np.int32)
         colb[has] = c[mate[has]]
         ucol = np.concatenate([c[head], colb], axis=1)
-        uca = np.concatenate([ca, np.full((U, K), zero, dtype=np.int64)], axis=1)
-        ucb = np.concatenate([np.full((U, K), zero, dtype=np.int64), cb], axis=1)
+        uca = np.concatenate([ca, np.full((U, K), zero, dtype=np.int32)], axis=1)
+        ucb = np.concatenate([np.full((U, K), zero, dtype=np.int32), cb], axis=1)
         order = np.argsort(ucol, axis=1, kind='stable')
         ucol = np.take_along_axis(ucol, order, axis=1)
         uca = np.take_along_axis(uca, order, axis=1)
@@ -486,17 +513,18 @@ class PackedEllMatrices:
         ucol[:, 1:][dup] = BIG
         uca[:, 1:][dup] = zero
         ucb[:, 1:][dup] = zero
-        order = np.argsort(ucol, axis=1, kind='stable')
-        ucol = np.take_along_axis(ucol, order, axis=1)
-        uca = np.take_along_axis(uca, order, axis=1)
-        ucb = np.take_along_axis(ucb, order, axis=1)
-        assert (ucol[:, K2:] == BIG).all()
-        ucol, uca, ucb = ucol[:, :K2], uca[:, :K2], ucb[:, :K2]
-        pad = ucol == BIG
-        assert (uca[pad] == zero).all() and (ucb[pad] == zero).all()
-        ucol = np.where(pad, own[head].astype(np.int64)[:, None], ucol)
+        # close the gaps: entry -> its rank among the kept entries of its unit
+        keep = ucol < BIG
+        rank = np.cumsum(keep, axis=1) - 1
+        assert int(rank[:, -1].max()) < K2
+        at = (np.nonzero(keep)[0], rank[keep])
+        packed_col = np.repeat(own[head].astype(np.int32)[:, None], K2, axis=1)  # unused slots: own column
+        packed_ca = np.full((U, K2), zero, dtype=np.int32)
+        packed_cb = np.full((U, K2), zero, dtype=np.int32)
+        packed_col[at], packed_ca[at], packed_cb[at] = ucol[keep], uca[keep], ucb[keep]
+        ucol, uca, ucb = packed_col, packed_ca, packed_cb
         n1 = len(uniq)
-        upair, ucode = np.unique(uca * n1 + ucb, return_inverse=True)
+        upair, ucode = _small_unique((uca * np.int32(n1) + ucb).reshape(-1), n1 * n1)
         if 2 * len(upair) > self.MAX_CODES:
             return None
         pair_dict = np.hstack([uniq[upair // n1], uniq[upair % n1]])

@@ -983,7 +983,9 @@ def test_kron_pack_randomised_shapes(stk):
         if ell.ovf_indptr is not None:
             assert not ell.packed.ok
             continue
-        assert ell.packed.ok and ell.packed.n_codes <= len(palette)**nt + 1
+        # codes: value tuples (+ "no entry"), per row of a unit when rows were paired
+        assert ell.packed.ok
+        assert ell.packed.n_codes <= (len(palette)**nt + 1)**ell.packed.rows_per_unit
         X = rng.rand(M, n_loc)
         lo = rng.rand(M) if rng.randint(2) else None
         hi = rng.rand(M) if rng.randint(2) else None
@@ -1040,6 +1042,82 @@ def test_kron_pack_randomised_shapes(stk):
     m.data = rng.rand(m.nnz)
     e = EllMatrices([m])
     assert e.ovf_indptr is not None or not e.packed.ok or e.packed.n_codes <= 512
+
+
+def test_kron_pack_row_pairs(stk):
+    """The row-pair form of stk_kron_pack_apply (two matrix rows per slot row,
+    the union of their columns gathered once) on the P1 matrices of the square
+    and the L-shape and on banded matrices with 5-entry rows: rows really are
+    paired, the result is bit for bit that of the one-row form (same accumulation
+    order, absent columns add exact zeros) and agrees with dense NumPy; ghost time
+    steps, 1-3 terms, beta, slab lengths through the lane / group / prefetch
+    instances."""
+    from source.assembly import space_matrices
+    from source.linop import EllMatrices
+    from source.problem import problem_helper
+    rng = np.random.RandomState(123)
+    families = []
+    for problem, J in (('square', 2), ('square', 4), ('lshape', 3)):
+        M_x, A_x = space_matrices(problem_helper(problem, J_space=J, J_time=2)[0])
+        families.append((problem, [M_x, A_x, sp.csr_matrix(M_x + 0.3 * A_x)]))
+    n = 23 * 17
+    band = sp.diags([rng.choice([1.0, -2.0, 0.5], size=n - abs(o)) for o in (-17, -1, 0, 1, 17)],
+                    (-17, -1, 0, 1, 17), format='csr')
+    families.append(('band5', [band, sp.csr_matrix(band.T), sp.csr_matrix(band + band.T)]))
+    seen_pairs = 0
+    for name, mats_all in families:
+        for n_loc in (1, 2, 8, 9, 17, 33):
+            nt = int(rng.randint(1, 4))
+            mats = mats_all[:nt]
+            ell = EllMatrices(mats, [mats_all[0]])
+            one, two = ell.packed_variant(1), ell.packed_variant(2)
+            assert one.ok and one.rows_per_unit == 1
+            assert two.ok and two.rows_per_unit == 2, (name, two.ok)
+            M = ell.M
+            assert two.n_units < 0.7 * M and two.K in (8, 10)
+            seen_pairs += M - two.n_units
+            ld = n_loc + (n_loc & 1)
+            X = rng.rand(M, n_loc)
+            lo = rng.rand(M) if rng.randint(2) else None
+            hi = rng.rand(M) if rng.randint(2) else None
+            beta = float(rng.choice([0.0, 0.5]))
+            y0 = rng.rand(M, n_loc)
+            want, specs = beta * y0, []
+            for k in range(nt):
+                t = rng.rand(3, n_loc)
+                T = np.diag(t[1]) + np.diag(t[0, 1:], -1) + np.diag(t[2, :-1], 1)
+                want = want + (mats[k] @ X) @ T.T
+                if lo is not None:
+                    want[:, 0] += t[0, 0] * (mats[k] @ lo)
+                if hi is not None:
+                    want[:, -1] += t[2, -1] * (mats[k] @ hi)
+                specs.append((_lib_dev(t), k))
+
+            def slab(a):
+                s_ = torch.zeros((M, ld), dtype=torch.float64, device='cuda')
+                s_[:, :n_loc] = torch.from_numpy(a).cuda()
+                return s_
+
+            x, gh = slab(X), None
+            if lo is not None or hi is not None:
+                gh = torch.zeros((M, 2), dtype=torch.float64, device='cuda')
+                if lo is not None:
+                    gh[:, 0] = torch.from_numpy(lo).cuda()
+                if hi is not None:
+                    gh[:, 1] = torch.from_numpy(hi).cuda()
+            y1, y2 = slab(y0), slab(y0)
+            one.apply(specs, x, gh, n_loc, ld, beta, y1)
+            two.apply(specs, x, gh, n_loc, ld, beta, y2)
+            assert torch.equal(y1, y2), (name, n_loc, nt)
+            assert relerr(y2[:, :n_loc].cpu().numpy(), want) < 1e-13, (name, n_loc, nt)
+            if ld > n_loc:
+                assert float(y2[:, n_loc:].abs().max()) == 0.0
+    assert seen_pairs > 0
+    # rows that share nothing stay alone: the planner keeps the one-row form
+    circ = lambda k: sp.csr_matrix((np.ones(64), (np.arange(64), (np.arange(64) + k) % 64)), shape=(64, 64))
+    scattered = sp.csr_matrix(circ(0) + circ(13) + circ(-13) + circ(29) + circ(-29))
+    e = EllMatrices([scattered])
+    assert e.packed.ok and e.packed.rows_per_unit == 1
 
 
 def test_row_engine_randomised_shapes(stk):
@@ -1331,8 +1409,10 @@ def test_kron_plan_from_csr_through_ctypes_only(stk):
             None if order is None else order.ctypes.data, ctypes.byref(plan)))
         K, nc, packed = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
         nnz = ctypes.c_int64()
+        rpu = ctypes.c_int32()
         stk.check(lib.stk_kron_plan_info(plan, ctypes.byref(K), ctypes.byref(nc),
-                                         ctypes.byref(packed), ctypes.byref(nnz)))
+                                         ctypes.byref(packed), ctypes.byref(nnz),
+                                         ctypes.byref(rpu)))
         pattern = sum(sp.csr_matrix((np.ones(m.nnz), m.indices, m.indptr), shape=m.shape)
                       for m in mats)
         assert nnz.value == sp.csr_matrix(pattern).nnz
@@ -1378,6 +1458,8 @@ def test_kron_plan_from_csr_through_ctypes_only(stk):
                 m.stk_row_order = order
         ell = EllMatrices(mats)
         assert ell.K == K.value and ell.packed.ok == bool(packed.value)
+        if ell.packed.ok:  # both planners pair the same rows
+            assert ell.packed.rows_per_unit == rpu.value, (case, rpu.value)
         y_py = slab(y0)
         specs = [(keep_tri[k], terms[k].mat) for k in range(nt)]
         if ell.packed.ok:
@@ -1391,6 +1473,45 @@ def test_kron_plan_from_csr_through_ctypes_only(stk):
             ell.apply([(tri, k, x, glo, ghi) for tri, k in specs], n_loc, ld, beta, y_py)
         assert torch.equal(y, y_py), (case, float((y - y_py).abs().max()))
         stk.check(lib.stk_kron_plan_destroy(plan))
+    # mesh matrices in their tile order: the library pairs neighbouring rows, and
+    # keeps one row per slot row when told to ("pack_rows"); same bits either way
+    from source.assembly import space_matrices
+    from source.problem import problem_helper
+    M_x, A_x = space_matrices(problem_helper('lshape', J_space=3, J_time=2)[0])
+    order = np.asarray(M_x.stk_row_order, dtype=np.int32)
+    mats = [sp.csr_matrix(M_x), sp.csr_matrix(A_x)]
+    for m in mats:
+        m.sort_indices()
+    keep = [(m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data.astype(np.float64))
+            for m in mats]
+    arr = lambda j: (ctypes.c_void_p * 2)(*[k[j].ctypes.data for k in keep])
+    M, n_loc, ld = M_x.shape[0], 9, 10
+    x = torch.zeros((M, ld), dtype=torch.float64, device='cuda')
+    x[:, :n_loc] = torch.from_numpy(rng.rand(M, n_loc)).cuda()
+    t = [_lib_dev(rng.rand(3, n_loc)) for _ in range(2)]
+    terms = (stk.KronPackTerm * 2)()
+    for k in range(2):
+        terms[k].tri, terms[k].mat = t[k].data_ptr(), k
+    out = {}
+    for rows in (2, 1):
+        stk.check(lib.stk_set_tuning(b'pack_rows', rows))
+        plan = ctypes.c_void_p()
+        stk.check(lib.stk_kron_plan_create(M, 2, arr(0), arr(1), arr(2), order.ctypes.data,
+                                           ctypes.byref(plan)))
+        rpu, K = ctypes.c_int32(), ctypes.c_int32()
+        stk.check(lib.stk_kron_plan_info(plan, ctypes.byref(K), None, None, None, ctypes.byref(rpu)))
+        assert rpu.value == rows and K.value == 7
+        y = torch.full_like(x, 9.0)
+        stk.check(lib.stk_kron_plan_apply(plan, stk.stream(), n_loc, ld, 2, terms, stk.ptr(x),
+                                          None, None, None, 0.0, stk.ptr(y)))
+        out[rows] = y
+        stk.check(lib.stk_kron_plan_destroy(plan))
+    stk.check(lib.stk_set_tuning(b'pack_rows', 2))
+    assert torch.equal(out[1], out[2])
+    ell = EllMatrices([M_x, A_x], [M_x])
+    y_py = torch.full_like(x, 4.0)
+    ell.packed.apply([(t[0], 0), (t[1], 1)], x, None, n_loc, ld, 0.0, y_py)
+    assert ell.packed.rows_per_unit == 2 and torch.equal(out[2], y_py)
     # argument errors come back as status + message, not as a crash
     plan = ctypes.c_void_p()
     bad = np.array([0, 0, 1], dtype=np.int32)  # not a permutation
