@@ -211,6 +211,21 @@ typedef struct {
     int32_t mat;       /* which matrix of the pattern */
 } stk_kron_pack_term;
 
+/* Host helper of the planners (no device work): groups rows that follow each
+ * other in the processing order into units of up to rp rows whose union of
+ * columns has at most K_out entries (greedily, left to right).  cols / codes:
+ * [M][K], the real entries of position p in the first counts[p] slots, columns
+ * ascending; own[p]: matrix row at position p.  Outputs sized for M units:
+ * ucols [units][K_out], ucodes [units][K_out][rp] (zero_code = "no entry"),
+ * urows [units][rp] (-1 = none).  stk_pack_unit_slots: K_out of the instantiated
+ * kernels for rows of K slots (0: none). */
+int32_t stk_pack_unit_slots(int32_t K, int32_t rp);
+int stk_pack_group_rows(int32_t M, int32_t K, const int32_t *counts,
+                        const int32_t *cols, const int32_t *codes,
+                        const int32_t *own, int32_t zero_code, int32_t rp,
+                        int32_t K_out, int32_t *n_units, int32_t *ucols,
+                        int32_t *ucodes, int32_t *urows);
+
 int stk_kron_pack_apply(void *stream, const stk_pack_pattern *pattern_host,
                         int32_t n_loc, int32_t ld, int32_t n_terms,
                         const stk_kron_pack_term *terms_host, const double *x,

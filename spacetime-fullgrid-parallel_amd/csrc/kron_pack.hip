@@ -38,7 +38,11 @@
 //    per gather instruction of a lane; the columns of a
 //    row keep their ascending order inside the union, so every row's sum is
 //    accumulated in the same order as in the one-row form (an absent column adds
-//    0 * x = 0 exactly) and the results stay bit-identical.
+//    0 * x = 0 exactly) and the results stay bit-identical.  (The kernel is written
+//    for RP rows; three and four rows per slot row -- 4.3 and 4 gathers per row --
+//    were measured slower than pairs, 0.322 and 0.576 ms against 0.301 ms, for
+//    their registers and LDS, and are not instantiated:
+//    profiles/r02_rows_per_unit.log.)
 #include <cstring>
 
 #include "stk_common.h"
@@ -433,7 +437,7 @@ int launch(hipStream_t st, PackArgs<NT> a, int K)
             STK_PACK_CASE(16)
         }
         stk_set_error("stk_kron_pack_apply: K=%d is not one of 5, 7, 9, 12, 16", K);
-    } else {
+    } else if constexpr (RP == 2) {
         switch (K) {
             STK_PACK_CASE(8)
             STK_PACK_CASE(10)

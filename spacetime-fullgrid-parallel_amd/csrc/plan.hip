@@ -32,6 +32,80 @@ struct stk_kron_plan {
 
 int g_plan_pack_rows = 2;  // tuning key "pack_rows": matrix rows per slot row of the packed form (1 or 2)
 
+// Slots of a unit of up to `rp` rows with K slots each (the instantiations of
+// csrc/kron_pack.hip); 0: no such form.
+extern "C" int32_t stk_pack_unit_slots(int32_t K, int32_t rp)
+{
+    if (rp == 1) return K;
+    if (rp == 2) return K == 5 ? 8 : K == 7 ? 10 : K == 9 ? 12 : 0;
+    return 0;  // three / four rows per unit (K = 7 -> 13 / 16): measured slower than pairs, not instantiated
+}
+
+// Rows that follow each other in the processing order and share columns are
+// served by one slot row ("unit") of the packed form: greedily, left to right, a
+// unit takes the next row as long as it has fewer than `rp` rows and the union of
+// the columns still fits K_out slots.  cols/codes: [M][K] with the real entries
+// of position p in the first counts[p] slots, columns ascending.  Outputs (sized
+// for M units): ucols [units][K_out] (ascending union, unused slots = the first
+// row's own column), ucodes [units][K_out][rp] (zero_code where a row has no
+// entry in the column), urows [units][rp] (-1: no row).
+extern "C" int stk_pack_group_rows(int32_t M, int32_t K, const int32_t *counts, const int32_t *cols,
+                                   const int32_t *codes, const int32_t *own, int32_t zero_code, int32_t rp,
+                                   int32_t K_out, int32_t *n_units, int32_t *ucols, int32_t *ucodes, int32_t *urows)
+{
+    STK_REQUIRE(M > 0 && K >= 1 && counts && cols && codes && own && n_units && ucols && ucodes && urows,
+                "stk_pack_group_rows: bad arguments");
+    STK_REQUIRE(rp >= 1 && rp <= 4 && K_out >= K && K_out <= 64, "stk_pack_group_rows: rp=%d K_out=%d (K=%d)", rp,
+                K_out, K);
+    std::vector<int32_t> ucol(K_out), next(K_out);
+    std::vector<int32_t> ucode((size_t)K_out * rp), ncode((size_t)K_out * rp);
+    int32_t units = 0;
+    for (int32_t pos = 0; pos < M;) {
+        STK_REQUIRE(counts[pos] >= 0 && counts[pos] <= K, "stk_pack_group_rows: counts[%d]=%d", pos, counts[pos]);
+        int n = counts[pos], rows = 1;
+        for (int e = 0; e < n; ++e) {
+            ucol[e] = cols[(size_t)pos * K + e];
+            for (int j = 0; j < rp; ++j) ucode[(size_t)e * rp + j] = j == 0 ? codes[(size_t)pos * K + e] : zero_code;
+        }
+        while (rows < rp && pos + rows < M) {
+            const int32_t q = pos + rows;
+            const int nb = counts[q];
+            if (nb < 0 || nb > K) break;
+            // merge the union so far with row q
+            int ia = 0, ib = 0, m = 0;
+            bool fits = true;
+            while (ia < n || ib < nb) {
+                if (m == K_out) {
+                    fits = false;
+                    break;
+                }
+                const int32_t ca = ia < n ? ucol[ia] : INT32_MAX;
+                const int32_t cb = ib < nb ? cols[(size_t)q * K + ib] : INT32_MAX;
+                next[m] = std::min(ca, cb);
+                for (int j = 0; j < rp; ++j)
+                    ncode[(size_t)m * rp + j] = ca <= cb ? ucode[(size_t)ia * rp + j] : zero_code;
+                if (cb <= ca) ncode[(size_t)m * rp + rows] = codes[(size_t)q * K + ib];
+                ia += ca <= cb, ib += cb <= ca, ++m;
+            }
+            if (!fits) break;
+            n = m;
+            std::copy(next.begin(), next.begin() + n, ucol.begin());
+            std::copy(ncode.begin(), ncode.begin() + (size_t)n * rp, ucode.begin());
+            ++rows;
+        }
+        int32_t *oc = ucols + (size_t)units * K_out, *od = ucodes + (size_t)units * K_out * rp;
+        for (int e = 0; e < K_out; ++e) {
+            oc[e] = e < n ? ucol[e] : own[pos];
+            for (int j = 0; j < rp; ++j) od[(size_t)e * rp + j] = e < n ? ucode[(size_t)e * rp + j] : zero_code;
+        }
+        for (int j = 0; j < rp; ++j) urows[(size_t)units * rp + j] = j < rows ? own[pos + j] : -1;
+        ++units;
+        pos += rows;
+    }
+    *n_units = units;
+    return 0;
+}
+
 namespace {
 
 template <typename T>
@@ -146,87 +220,60 @@ int build(stk_kron_plan *p, int32_t M, int32_t n_mats, const int32_t *const *ind
     if (upload(p, slots_w, &d_slots) || upload(p, table, &d_dict)) return 1;
     p->pack = stk_pack_pattern{M, K, col_bits, n_codes, n_mats, 1, M, d_slots, order ? d_rows : nullptr, d_dict};
     p->packed = true;
-    // ---- row pairs: rows pos, pos + 1 whose union of columns fits the pair's slot
-    // count share one slot row (greedily, left to right; source/linop.py does the
-    // same with NumPy) ------------------------------------------------------------
-    const int K2 = K == 5 ? 8 : K == 7 ? 10 : K == 9 ? 12 : 0;
-    if (K2 == 0 || g_plan_pack_rows < 2) return 0;
+    // ---- several rows per slot row (stk_pack_group_rows above; source/linop.py
+    // calls the same function) -----------------------------------------------------
+    const int rp = g_plan_pack_rows;
+    const int K2 = stk_pack_unit_slots(K, rp);
+    if (K2 == 0 || rp < 2) return 0;
     uint32_t zero_code = (uint32_t)n_codes;  // the tuple "no entry": +0.0 in every matrix
     {
         std::fill(key.begin(), key.end(), (uint64_t)0);
         auto it = dict.find(key);
         if (it != dict.end()) zero_code = rank[it->second];
     }
-    const int n1 = zero_code == (uint32_t)n_codes ? n_codes + 1 : n_codes;
-    struct Unit {
-        int32_t a, b;
-    };
-    std::vector<Unit> units;
-    auto row_len = [&](int pos) { return u_ptr[pos + 1] - u_ptr[pos]; };
-    auto union_len = [&](int pa, int pb) {
-        int ia = u_ptr[pa], ib = u_ptr[pb], n = 0;
-        while (ia < u_ptr[pa + 1] && ib < u_ptr[pb + 1]) {
-            const int32_t ca = u_idx[ia], cb = u_idx[ib];
-            ia += ca <= cb, ib += cb <= ca, ++n;
-        }
-        return n + (u_ptr[pa + 1] - ia) + (u_ptr[pb + 1] - ib);
-    };
-    for (int pos = 0; pos < M;) {
-        if (pos + 1 < M && row_len(pos) + row_len(pos + 1) > 0 && union_len(pos, pos + 1) <= K2) {
-            units.push_back({pos, pos + 1});
-            pos += 2;
-        } else {
-            units.push_back({pos, -1});
-            pos += 1;
-        }
+    const int64_t n1 = zero_code == (uint32_t)n_codes ? n_codes + 1 : n_codes;
+    std::vector<int32_t> counts(M), rcode((size_t)M * K);
+    for (int pos = 0; pos < M; ++pos) counts[pos] = u_ptr[pos + 1] - u_ptr[pos];
+    for (size_t s2 = 0; s2 < (size_t)M * K; ++s2) rcode[s2] = (int32_t)rank[code[s2]];
+    std::vector<int32_t> ucol((size_t)M * K2), ucode((size_t)M * K2 * rp), urows((size_t)M * rp);
+    int32_t n_units = 0;
+    if (stk_pack_group_rows(M, K, counts.data(), ell_idx.data(), rcode.data(), row_ids.data(), (int32_t)zero_code, rp,
+                            K2, &n_units, ucol.data(), ucode.data(), urows.data()))
+        return 1;
+    const size_t U = (size_t)n_units;
+    if (U > (size_t)(0.95 * M)) return 0;  // hardly any rows share a unit: the one-row form stays
+    std::map<int64_t, uint32_t> unit_codes;  // sum_j code_j * n1^(rp-1-j) -> number (assigned below, in key order)
+    std::vector<int64_t> combined(U * K2);
+    for (size_t s2 = 0; s2 < U * K2; ++s2) {
+        int64_t c = 0;
+        for (int j = 0; j < rp; ++j) c = c * n1 + ucode[s2 * rp + j];
+        combined[s2] = c;
+        unit_codes.emplace(c, 0u);
     }
-    const size_t U = units.size();
-    if (2 * U > (size_t)(1.9 * M)) return 0;  // hardly any pairs: the one-row form stays
-    std::vector<uint32_t> ucol(U * K2), uab(U * K2);
-    std::vector<int32_t> urows(U * 2);
-    std::map<uint32_t, uint32_t> pair_codes;  // code_a * n1 + code_b -> number (assigned below, in key order)
-    auto code_at = [&](int pos, int e) { return rank[code[(size_t)pos * K + e]]; };
-    for (size_t u = 0; u < U; ++u) {
-        const int pa = units[u].a, pb = units[u].b;
-        urows[2 * u] = row_ids[pa];
-        urows[2 * u + 1] = pb >= 0 ? row_ids[pb] : -1;
-        const int na = row_len(pa), nb = pb >= 0 ? row_len(pb) : 0;
-        int ia = 0, ib = 0, n = 0;
-        while (ia < na || ib < nb) {
-            const int32_t ca = ia < na ? u_idx[u_ptr[pa] + ia] : INT32_MAX;
-            const int32_t cb = ib < nb ? u_idx[u_ptr[pb] + ib] : INT32_MAX;
-            const uint32_t va = ca <= cb ? code_at(pa, ia) : zero_code;
-            const uint32_t vb = cb <= ca ? code_at(pb, ib) : zero_code;
-            ucol[u * K2 + n] = (uint32_t)std::min(ca, cb);
-            uab[u * K2 + n] = va * (uint32_t)n1 + vb;
-            ia += ca <= cb, ib += cb <= ca, ++n;
-        }
-        for (; n < K2; ++n) {  // unused: the first row's own column, no entry in either row
-            ucol[u * K2 + n] = (uint32_t)row_ids[pa];
-            uab[u * K2 + n] = zero_code * (uint32_t)n1 + zero_code;
-        }
-    }
-    for (uint32_t v : uab) pair_codes.emplace(v, 0u);
-    if (2 * pair_codes.size() > 512 || (int64_t)pair_codes.size() > ((int64_t)1 << (32 - col_bits))) return 0;
+    if ((int64_t)unit_codes.size() * rp > 1024 || (int64_t)unit_codes.size() > ((int64_t)1 << (32 - col_bits)))
+        return 0;
     {
         uint32_t r = 0;
-        for (auto &kv : pair_codes) kv.second = r++;
+        for (auto &kv : unit_codes) kv.second = r++;
     }
-    const int n_pair = (int)pair_codes.size();
-    auto value_of = [&](uint32_t c, int m) { return c < (uint32_t)n_codes ? table[(size_t)m * n_codes + c] : 0.0; };
-    std::vector<double> pair_table((size_t)n_mats * n_pair * 2);
-    for (auto &kv : pair_codes)
-        for (int m = 0; m < n_mats; ++m) {
-            pair_table[((size_t)m * n_pair + kv.second) * 2] = value_of(kv.first / n1, m);
-            pair_table[((size_t)m * n_pair + kv.second) * 2 + 1] = value_of(kv.first % n1, m);
-        }
+    const int n_pair = (int)unit_codes.size();
+    auto value_of = [&](int64_t c, int m) { return c < n_codes ? table[(size_t)m * n_codes + c] : 0.0; };
+    std::vector<double> pair_table((size_t)n_mats * n_pair * rp);
+    for (auto &kv : unit_codes) {
+        int64_t c = kv.first;
+        for (int j = rp - 1; j >= 0; --j, c /= n1)
+            for (int m = 0; m < n_mats; ++m)
+                pair_table[((size_t)m * n_pair + kv.second) * rp + j] = value_of(c % n1, m);
+    }
     std::vector<uint32_t> pair_slots(U * K2);
-    for (size_t s2 = 0; s2 < U * K2; ++s2) pair_slots[s2] = (pair_codes[uab[s2]] << col_bits) | ucol[s2];
+    for (size_t s2 = 0; s2 < U * K2; ++s2)
+        pair_slots[s2] = (unit_codes[combined[s2]] << col_bits) | (uint32_t)ucol[s2];
+    urows.resize(U * rp);
     uint32_t *d_pslots;
     int32_t *d_urows;
     double *d_pdict;
     if (upload(p, pair_slots, &d_pslots) || upload(p, urows, &d_urows) || upload(p, pair_table, &d_pdict)) return 1;
-    p->pack = stk_pack_pattern{M, K2, col_bits, n_pair, n_mats, 2, (int32_t)U, d_pslots, d_urows, d_pdict};
+    p->pack = stk_pack_pattern{M, K2, col_bits, n_pair, n_mats, rp, (int32_t)U, d_pslots, d_urows, d_pdict};
     return 0;
 }
 

@@ -60,7 +60,7 @@ class SchurMPI(LinearOperatorMPI):
         self._factors = (A_t, L_t, M_t, G_t, M_x, A_x)
         self._linops = None
         self.Kinv_x = as_space_op(Kinv_x)
-        self.ell = EllMatrices([M_x, A_x])  # matrix 0 = M_x, 1 = A_x
+        self.ell = EllMatrices.shared([M_x, A_x])  # matrix 0 = M_x, 1 = A_x
         self._couples = {}
 
         def tri(T):
@@ -178,7 +178,6 @@ class HeatEquationMPI:
         self.N = self.A_t.shape[0]
         self.M = self.M_x.shape[0]
         assert (len(data['g']) == 0)
-        self.u0_x = space_load(mesh_space, data['u0'])
         self.dofs_distr = DofDistributionMPI(comm, self.N, self.M)
 
         # --- Wavelet transform --- (heateq_mpi.py:126-139)
@@ -205,7 +204,10 @@ class HeatEquationMPI:
             # the two hierarchies (A_x alone; 2^j M_x + alpha A_x, all j in one
             # family) are independent host work (SciPy / NumPy release the GIL)
             from concurrent.futures import ThreadPoolExecutor
-            with ThreadPoolExecutor(max_workers=2) as pool:
+            with ThreadPoolExecutor(max_workers=4) as pool:
+                if schur != 'reference':  # the Kronecker plan S streams: independent of both
+                    pool.submit(EllMatrices.shared, [self.M_x, self.A_x])
+                u0_x = pool.submit(space_load, mesh_space, data['u0'])
                 kinv = pool.submit(MultiGrid, self.A_x, hierarchy,
                                    smoothsteps=smoothsteps, vcycles=vcycles)
                 family = pool.submit(
@@ -213,9 +215,11 @@ class HeatEquationMPI:
                     cms=[2**j for j in range(self.J_time + 1)],
                     smoothsteps=smoothsteps, vcycles=vcycles)
                 self.Kinv_x, self.C_family = kinv.result(), family.result()
+                self.u0_x = u0_x.result()
             self.C_j = self.C_family.members
         else:
             assert (precond == 'direct')
+            self.u0_x = space_load(mesh_space, data['u0'])
             self.Kinv_x = InvLinOp(self.A_x)
             self.C_j = [
                 InvLinOp(2**j * self.M_x + alpha * self.A_x)

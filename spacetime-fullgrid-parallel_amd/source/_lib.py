@@ -113,6 +113,10 @@ _PROTOTYPES = {
         c_p, ctypes.POINTER(EllPattern), c_i32, c_i32, c_i32,
         ctypes.POINTER(KronEllTerm), c_p
     ]),
+    'stk_pack_unit_slots': (c_i32, [c_i32, c_i32]),
+    'stk_pack_group_rows': (ctypes.c_int, [
+        c_i32, c_i32, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p
+    ]),
     'stk_kron_pack_apply': (ctypes.c_int, [
         c_p, ctypes.POINTER(PackPattern), c_i32, c_i32, c_i32,
         ctypes.POINTER(KronPackTerm), c_p, c_p, c_f64, c_p

@@ -286,6 +286,27 @@ class EllMatrices:
     row, rows in processing order, overflow CSR for rows longer than K."""
     MAXK = 16
     SLOTS = (5, 7, 9, 12, 16)  # instantiated in csrc/kron_ell.hip
+    _shared, _shared_lock = [], threading.Lock()
+
+    @classmethod
+    def shared(cls, mats, order_hints=()):
+        """The plan of exactly these matrix objects, built once: S and the
+        metric's operator both stream (M_x, A_x).  Keyed by the CSR arrays (not
+        their values: matrices are not modified in place anywhere); the few most
+        recent plans are kept together with their matrices, so the arrays stay
+        alive."""
+        mats = [sp.csr_matrix(m) for m in mats]  # shares the arrays of a CSR input
+        key = tuple((m.indptr.ctypes.data, m.indices.ctypes.data,
+                     m.data.ctypes.data, m.nnz) for m in mats)
+        with cls._shared_lock:
+            for k, _, plan in cls._shared:
+                if k == key:
+                    return plan
+        plan = cls(mats, order_hints)
+        with cls._shared_lock:
+            cls._shared.append((key, list(mats), plan))
+            del cls._shared[:-4]
+        return plan
 
     def __init__(self, mats, order_hints=()):
         indptr, indices, vals = union_pattern(mats)
@@ -331,8 +352,8 @@ class EllMatrices:
         self.packed = self.packed_variant(PackedEllMatrices.ROWS_PER_UNIT)
 
     def packed_variant(self, rows_per_unit):
-        """The packed form with 1 or 2 matrix rows per slot row (falls back to 1
-        where rows cannot be paired)."""
+        """The packed form with 1..4 matrix rows per slot row (falls back to 1
+        where rows cannot share slot rows)."""
         packed = PackedEllMatrices(*self._pack_args, rows_per_unit=rows_per_unit)
         if not packed.ok and rows_per_unit > 1:
             packed = PackedEllMatrices(*self._pack_args, rows_per_unit=1)
@@ -399,7 +420,7 @@ class PackedEllMatrices:
     """The matrices of an EllMatrices plan in the packed form of
     ``stk_kron_pack_apply`` (include/stk.h): one 32-bit word per slot,
     ``code << col_bits | column``, plus the dictionary of the distinct value
-    tuples of the union pattern.  With ``rows_per_unit = 2`` rows that follow
+    tuples of the union pattern.  With ``rows_per_unit`` = 2..4, rows that follow
     each other in the processing order and share columns (mesh neighbours) are
     served by ONE slot row listing the union of their columns.  ``ok`` is False
     when the plan does not fit (overflow rows, more distinct tuples than the
@@ -407,15 +428,17 @@ class PackedEllMatrices:
     then keeps the plain form."""
     MAX_CODES = 512  # dictionary entries (codes x rows per unit) in LDS next to the exchange buffers
     ROWS_PER_UNIT = int(os.environ.get('STK_PACK_ROWS', '2'))
-    PAIR_SLOTS = {5: 8, 7: 10, 9: 12}  # slots of a pair of rows with K slots each (csrc/kron_pack.hip)
 
     def __init__(self, M, K, ell_idx, ell_vals, row_ids, has_overflow,
                  counts=None, own=None, rows_per_unit=1):
         self.ok = False
         if has_overflow or M < 1:
             return
-        if rows_per_unit == 2 and (K not in self.PAIR_SLOTS or counts is None):
-            return
+        K_out = K
+        if rows_per_unit > 1:
+            K_out = int(_lib.lib().stk_pack_unit_slots(K, rows_per_unit))
+            if K_out == 0 or counts is None:
+                return
         col_bits = max(1, int(M - 1).bit_length())
         # distinct value tuples, by bit pattern (+0.0 and -0.0 stay distinct):
         # one 1-D unique per matrix, then one over the combined codes
@@ -434,12 +457,13 @@ class PackedEllMatrices:
         uniq = table  # (n_codes, n_mats) bit patterns
         cols = ell_idx.reshape(M, K)
         unit_rows = None
-        if rows_per_unit == 2:
-            paired = self._pair_rows(M, K, cols, codes.reshape(M, K), uniq,
-                                     np.asarray(counts), np.asarray(own))
-            if paired is None:
+        if rows_per_unit > 1:
+            grouped = self._group_rows(M, K, K_out, rows_per_unit, cols,
+                                       codes.reshape(M, K), uniq,
+                                       np.asarray(counts), np.asarray(own))
+            if grouped is None:
                 return
-            cols, codes, uniq, unit_rows = paired
+            cols, codes, uniq, unit_rows = grouped
         if len(uniq) > (1 << (32 - col_bits)):
             return
         self.ok = True
@@ -461,77 +485,48 @@ class PackedEllMatrices:
                                         _lib.ptr(self.row_ids),
                                         _lib.ptr(self.dict))
 
-    def _pair_rows(self, M, K, cols, codes, uniq, counts, own):
-        """Rows p, p + 1 of the processing order whose union of columns fits the
-        pair's slot count become one unit (greedily, left to right); the others
-        stay alone in theirs.  Returns (columns, codes, dictionary, rows) of the
-        units; the dictionary rows are (values of row 0 | values of row 1)."""
-        K2 = self.PAIR_SLOTS[K]
+    def _group_rows(self, M, K, K_out, rp, cols, codes, uniq, counts, own):
+        """Units of up to `rp` rows that follow each other in the processing
+        order and whose union of columns fits K_out slots (greedy, left to right:
+        stk_pack_group_rows, host code of libstk shared with the C planner).
+        Returns (columns, codes, dictionary, rows) of the units; a dictionary row
+        holds the value tuples of the unit's rows one after the other."""
         n_mats = uniq.shape[1]
-        BIG = np.int32(2**31 - 1)
         zero = np.flatnonzero((uniq == 0).all(axis=1))  # code of "no entry" (+0.0 everywhere)
         if len(zero) == 0:
             uniq = np.vstack([uniq, np.zeros((1, n_mats), dtype=uniq.dtype)])
             zero = [len(uniq) - 1]
-        zero = int(zero[0])
-        real = np.arange(K)[None, :] < counts[:, None]
-        c = np.where(real, cols.astype(np.int32), BIG)
-        if M > 1:
-            shared = ((c[:-1, :, None] == c[1:, None, :]) &
-                      real[:-1, :, None]).sum(axis=(1, 2))
-            fits = counts[:-1] + counts[1:] - shared <= K2
+        zero, n1 = int(zero[0]), len(uniq)
+        c32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        counts, cols, codes, own = c32(counts), c32(cols), c32(codes), c32(own)
+        ucols = np.empty((M, K_out), dtype=np.int32)
+        ucodes = np.empty((M, K_out, rp), dtype=np.int32)
+        urows = np.empty((M, rp), dtype=np.int32)
+        n_units = ctypes.c_int32()
+        _lib.check(_lib.lib().stk_pack_group_rows(
+            M, K, counts.ctypes.data, cols.ctypes.data, codes.ctypes.data,
+            own.ctypes.data, zero, rp, K_out, ctypes.byref(n_units),
+            ucols.ctypes.data, ucodes.ctypes.data, urows.ctypes.data))
+        U = n_units.value
+        if U > 0.95 * M:  # hardly any rows share a unit: not worth the wider slot rows
+            return None
+        ucols, ucodes, urows = ucols[:U], ucodes[:U], urows[:U]
+        combined = np.zeros((U, K_out), dtype=np.int64)
+        for j in range(rp):
+            combined = combined * n1 + ucodes[:, :, j]
+        if n1**rp <= 1 << 24:
+            ucomb, ucode = _small_unique(combined.reshape(-1), n1**rp)
         else:
-            fits = np.zeros(0, dtype=bool)
-        idx = np.arange(M - 1)
-        last_break = np.maximum.accumulate(np.where(fits, -1, idx)) if M > 1 else idx
-        first = np.zeros(M, dtype=bool)
-        first[:-1] = fits & ((idx - last_break - 1) % 2 == 0)
-        second = np.zeros(M, dtype=bool)
-        second[1:] = first[:-1]
-        head = np.flatnonzero(~second)             # first (or only) row of every unit
-        mate = np.where(first[head], head + 1, -1)  # its partner or -1
-        has = mate >= 0
-        U = len(head)
-        if 2 * U > 1.9 * M:  # hardly any pairs: not worth the wider slot rows
+            ucomb, ucode = np.unique(combined.reshape(-1), return_inverse=True)
+        if len(ucomb) * rp > 2 * self.MAX_CODES:
             return None
-        codes = codes.astype(np.int32)
-        ca = np.where(real[head], codes[head], np.int32(zero))
-        cb = np.full((U, K), zero, dtype=np.int32)
-        cb[has] = np.where(real[mate[has]], codes[mate[has]], np.int32(zero))
-        colb = np.full((U, K), BIG, dtype=np.int32)
-        colb[has] = c[mate[has]]
-        ucol = np.concatenate([c[head], colb], axis=1)
-        uca = np.concatenate([ca, np.full((U, K), zero, dtype=np.int32)], axis=1)
-        ucb = np.concatenate([np.full((U, K), zero, dtype=np.int32), cb], axis=1)
-        order = np.argsort(ucol, axis=1, kind='stable')
-        ucol = np.take_along_axis(ucol, order, axis=1)
-        uca = np.take_along_axis(uca, order, axis=1)
-        ucb = np.take_along_axis(ucb, order, axis=1)
-        # a column both rows have: row 0's entry comes first (stable sort)
-        dup = (ucol[:, 1:] == ucol[:, :-1]) & (ucol[:, 1:] < BIG)
-        ucb[:, :-1][dup] = ucb[:, 1:][dup]
-        ucol[:, 1:][dup] = BIG
-        uca[:, 1:][dup] = zero
-        ucb[:, 1:][dup] = zero
-        # close the gaps: entry -> its rank among the kept entries of its unit
-        keep = ucol < BIG
-        rank = np.cumsum(keep, axis=1) - 1
-        assert int(rank[:, -1].max()) < K2
-        at = (np.nonzero(keep)[0], rank[keep])
-        packed_col = np.repeat(own[head].astype(np.int32)[:, None], K2, axis=1)  # unused slots: own column
-        packed_ca = np.full((U, K2), zero, dtype=np.int32)
-        packed_cb = np.full((U, K2), zero, dtype=np.int32)
-        packed_col[at], packed_ca[at], packed_cb[at] = ucol[keep], uca[keep], ucb[keep]
-        ucol, uca, ucb = packed_col, packed_ca, packed_cb
-        n1 = len(uniq)
-        upair, ucode = _small_unique((uca * np.int32(n1) + ucb).reshape(-1), n1 * n1)
-        if 2 * len(upair) > self.MAX_CODES:
-            return None
-        pair_dict = np.hstack([uniq[upair // n1], uniq[upair % n1]])
-        rows = np.stack([own[head], np.where(has, own[np.maximum(mate, 0)], -1)],
-                        axis=1).astype(np.int32)
-        return (ucol.astype(np.int64), ucode.reshape(U, K2), pair_dict,
-                np.ascontiguousarray(rows))
+        parts, rest = [], ucomb
+        for j in range(rp):
+            parts.append(uniq[rest % n1])
+            rest = rest // n1
+        unit_dict = np.hstack(parts[::-1])
+        return (ucols.astype(np.int64), ucode.reshape(U, K_out), unit_dict,
+                np.ascontiguousarray(urows))
 
     def apply(self, specs, x, ghosts, n_loc, ld, beta, out):
         """y = beta*y + sum over specs (tri, matrix index) applied to x;

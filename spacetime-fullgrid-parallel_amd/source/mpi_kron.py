@@ -398,7 +398,7 @@ class _FusedKronSum:
         self.n_terms = len(ops)
         if self.use_ell:
             from .linop import EllMatrices
-            self.ell = EllMatrices(mats, hints)
+            self.ell = EllMatrices.shared(mats, hints)
             self.row_ids = self.ell.row_ids
         else:
             indptr, indices, vals = union_pattern(mats)
@@ -467,8 +467,10 @@ class _FusedKronSum:
             return 'kron_sum_kernel<%d>' % self.n_terms
         if type(self).use_pack and self.ell.packed.ok:
             ghost = self.dofs_distr.size > 1 and (self.needs_lo or self.needs_hi)
-            return 'kron_pack_kernel<%d, %d, %s>' % (
-                self.n_terms, self.ell.K, 'ghost lanes' if ghost else 'no ghosts')
+            pk = self.ell.packed
+            return 'kron_pack_kernel<%d, %d, %s, %s>' % (
+                self.n_terms, pk.K, 'ghost lanes' if ghost else 'no ghosts',
+                'row pairs' if pk.rows_per_unit == 2 else 'single rows')
         return 'kron_ell_kernel<%d, shared input, %d>' % (self.n_terms, self.ell.K)
 
     def algorithmic_bytes(self, n_loc, M):

@@ -67,19 +67,26 @@ def run(variant):
         _lib.check(_lib.lib().stk_set_tuning(k.encode(), int(v)))
     if parts[0] == 'plain':
         return lambda: ell.apply([(tri[0], 0, x, lo, hi), (tri[1], 1, x, lo, hi)], n_loc, ld, 0.0, y)
-    form = {'pack': ell.packed, 'pack1': packed1, 'pack2': packed2}[parts[0]]
+    form = {'pack': ell.packed, 'pack1': forms[1], 'pack2': forms[2]}[parts[0]]
     return lambda: form.apply([(tri[0], 0), (tri[1], 1)], x, gh, n_loc, ld, 0.0, y)
 
 
-packed1, packed2 = ell.packed_variant(1), ell.packed_variant(2)
-print('packed forms: default %d row(s) per unit; pairs: %d units for %d rows, K=%d, %d codes'
-      % (ell.packed.rows_per_unit, packed2.n_units, M, packed2.K, packed2.n_codes), flush=True)
-y1, y2 = torch.full_like(x, 3.0), torch.full_like(x, 5.0)
-packed1.apply([(tri[0], 0), (tri[1], 1)], x, gh, n_loc, ld, 0.0, y1)
-packed2.apply([(tri[0], 0), (tri[1], 1)], x, gh, n_loc, ld, 0.0, y2)
-torch.cuda.synchronize()
-print('pairs bit-identical with single rows: %s' % torch.equal(y1, y2), flush=True)
-assert torch.equal(y1, y2)
+forms = {rp: ell.packed_variant(rp) for rp in (1, 2)}
+print('packed forms: default %d row(s) per unit' % ell.packed.rows_per_unit, flush=True)
+y1 = torch.full_like(x, 3.0)
+forms[1].apply([(tri[0], 0), (tri[1], 1)], x, gh, n_loc, ld, 0.0, y1)
+for rp in (2,):
+    f = forms[rp]
+    if f.rows_per_unit != rp:
+        print('   %d rows per unit: not available for these matrices' % rp)
+        continue
+    y2 = torch.full_like(x, 5.0)
+    f.apply([(tri[0], 0), (tri[1], 1)], x, gh, n_loc, ld, 0.0, y2)
+    torch.cuda.synchronize()
+    same = torch.equal(y1, y2)
+    print('   %d rows per unit: %d units for %d rows, K=%d, %d codes; bit-identical with single rows: %s'
+          % (rp, f.n_units, M, f.K, f.n_codes, same), flush=True)
+    assert same
 
 
 variants = args.variants.split(';')
