@@ -115,7 +115,7 @@ def cpu_baseline(A_t, M_t, M_x, A_x, N, M, nbytes, budget_s=10.0):
 
 
 KERNEL_SOURCES = ('csrc/kron_pack.hip', 'csrc/kron_ell.hip', 'csrc/stk_common.h',
-                  'source/linop.py')
+                  'csrc/plan.hip', 'source/linop.py')
 
 
 def kernel_source_sha():

@@ -253,9 +253,10 @@ int stk_kron_plan_create(int32_t M, int32_t n_mats,
                          const int32_t *row_order_host, stk_kron_plan **out);
 int stk_kron_plan_destroy(stk_kron_plan *plan);
 /* Any output may be NULL.  K: slots per row of the sliced-ELL copy; packed = 1
- * if the dictionary form was built; rows_per_unit = 2 if it serves row pairs
- * (tuning key "pack_rows" = 1 keeps one row per slot row in plans created
- * afterwards). */
+ * if the dictionary form was built; rows_per_unit = 2 if a row-pair form was
+ * built as well -- stk_kron_plan_apply uses it for slabs of 24 time steps and
+ * more, the one-row form below (tuning key "pack_rows" = 1: no pairs in plans
+ * created afterwards). */
 int stk_kron_plan_info(const stk_kron_plan *plan, int32_t *K, int32_t *n_codes,
                        int32_t *packed, int64_t *nnz_union,
                        int32_t *rows_per_unit);

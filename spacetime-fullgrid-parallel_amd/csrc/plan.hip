@@ -24,8 +24,9 @@ struct stk_kron_plan {
     // plain ELL form
     stk_ell_pattern ell{};
     std::vector<double *> ell_vals, ovf_vals;
-    // packed form
-    stk_pack_pattern pack{};
+    // packed form: one row per slot row, and row pairs (slabs of >= PAIR_MIN_STEPS steps)
+    stk_pack_pattern pack{}, pack_pairs{};
+    bool paired = false;
     std::vector<void *> owned;  // every device allocation
     int64_t nnz_union = 0;
 };
@@ -273,7 +274,8 @@ int build(stk_kron_plan *p, int32_t M, int32_t n_mats, const int32_t *const *ind
     int32_t *d_urows;
     double *d_pdict;
     if (upload(p, pair_slots, &d_pslots) || upload(p, urows, &d_urows) || upload(p, pair_table, &d_pdict)) return 1;
-    p->pack = stk_pack_pattern{M, K2, col_bits, n_pair, n_mats, rp, (int32_t)U, d_pslots, d_urows, d_pdict};
+    p->pack_pairs = stk_pack_pattern{M, K2, col_bits, n_pair, n_mats, rp, (int32_t)U, d_pslots, d_urows, d_pdict};
+    p->paired = true;
     return 0;
 }
 
@@ -322,7 +324,7 @@ extern "C" int stk_kron_plan_info(const stk_kron_plan *p, int32_t *K, int32_t *n
                                   int64_t *nnz_union, int32_t *rows_per_unit)
 {
     STK_REQUIRE(p, "stk_kron_plan_info: null plan");
-    if (rows_per_unit) *rows_per_unit = p->packed ? p->pack.rows_per_unit : 1;
+    if (rows_per_unit) *rows_per_unit = p->paired ? p->pack_pairs.rows_per_unit : 1;
     if (K) *K = p->K;
     if (n_codes) *n_codes = p->packed ? p->pack.n_codes : 0;
     if (packed) *packed = p->packed ? 1 : 0;
@@ -346,8 +348,9 @@ extern "C" int stk_kron_plan_apply(stk_kron_plan *p, void *stream, int32_t n_loc
             int rc = stk_interleave_ghosts(stream, p->M, x_lo, x_hi, ghost_work);
             if (rc) return rc;
         }
-        return stk_kron_pack_apply(stream, &p->pack, n_loc, ld, n_terms, t, x, ghosts ? ghost_work : nullptr, beta,
-                                   y);
+        // short slabs keep one row per slot row (measured: source/linop.py PAIR_MIN_STEPS)
+        const stk_pack_pattern *form = p->paired && n_loc >= 24 ? &p->pack_pairs : &p->pack;
+        return stk_kron_pack_apply(stream, form, n_loc, ld, n_terms, t, x, ghosts ? ghost_work : nullptr, beta, y);
     }
     stk_kron_ell_term terms[3];
     for (int k = 0; k < n_terms; ++k)

@@ -106,18 +106,19 @@ class SchurMPI(LinearOperatorMPI):
         x = vec_in.buf
         n_loc, ld = vec_in.n_loc, vec_in.ld
         u = torch.empty_like(x)
-        if self.ell.packed.ok:
+        packed = self.ell.packed_for(n_loc)
+        if packed.ok:
             # packed matrix stream, ghost time steps fused into the one pass
             # (csrc/kron_pack.hip); the halo has to be there first
             ghosts = None
             if self.dofs_distr.size > 1:
                 self.time_communication = vec_in.communicate_bdr()
                 ghosts = vec_in.ghost_interleaved()
-            self.ell.packed.apply([(self.tA, 0), (self.tL, 1)], x, ghosts,
-                                  n_loc, ld, 0.0, u)
+            packed.apply([(self.tA, 0), (self.tL, 1)], x, ghosts, n_loc, ld,
+                         0.0, u)
             v1 = self.Kinv_x.apply(u, n_loc=n_loc)
-            self.ell.packed.apply([(self.tLT, 0), (self.tM, 1)], x, ghosts,
-                                  n_loc, ld, 0.0, u)
+            packed.apply([(self.tLT, 0), (self.tM, 1)], x, ghosts, n_loc, ld,
+                         0.0, u)
             v2 = self.Kinv_x.apply(u, n_loc=n_loc)
         else:
             first = [(self.tA, 0, x, None, None), (self.tL, 1, x, None, None)]
@@ -206,7 +207,9 @@ class HeatEquationMPI:
             from concurrent.futures import ThreadPoolExecutor
             with ThreadPoolExecutor(max_workers=4) as pool:
                 if schur != 'reference':  # the Kronecker plan S streams: independent of both
-                    pool.submit(EllMatrices.shared, [self.M_x, self.A_x])
+                    n_steps = self.dofs_distr.t_end - self.dofs_distr.t_begin
+                    pool.submit(lambda: EllMatrices.shared(
+                        [self.M_x, self.A_x]).packed_for(n_steps))
                 u0_x = pool.submit(space_load, mesh_space, data['u0'])
                 kinv = pool.submit(MultiGrid, self.A_x, hierarchy,
                                    smoothsteps=smoothsteps, vcycles=vcycles)

@@ -349,15 +349,36 @@ class EllMatrices:
                                        _lib.ptr(self.ovf_indices))
         self._pack_args = (M, K, ell_idx, ell_vals, self.row_ids,
                            not main.all(), counts, own)
-        self.packed = self.packed_variant(PackedEllMatrices.ROWS_PER_UNIT)
+        self._packed, self._packed_lock = {}, threading.Lock()
+
+    # Slabs of fewer time steps than this keep one row per slot row: measured on
+    # the slab shapes of 2-, 4- and 8-GPU runs (profiles/r02_slab_shapes2.log),
+    # pairs win from 32 steps on (0.182 -> 0.175 ms) and lose below (17 steps:
+    # 0.089 -> 0.096 ms; 8 steps: 0.046 -> 0.048 ms).
+    PAIR_MIN_STEPS = 24
+
+    @property
+    def packed(self):
+        """The packed form long slabs use (row pairs where the matrices allow)."""
+        return self.packed_variant(PackedEllMatrices.ROWS_PER_UNIT)
+
+    def packed_for(self, n_loc):
+        """The packed form for a slab of n_loc time steps."""
+        rows = PackedEllMatrices.ROWS_PER_UNIT if n_loc >= self.PAIR_MIN_STEPS else 1
+        return self.packed_variant(rows)
 
     def packed_variant(self, rows_per_unit):
-        """The packed form with 1..4 matrix rows per slot row (falls back to 1
-        where rows cannot share slot rows)."""
-        packed = PackedEllMatrices(*self._pack_args, rows_per_unit=rows_per_unit)
-        if not packed.ok and rows_per_unit > 1:
-            packed = PackedEllMatrices(*self._pack_args, rows_per_unit=1)
-        return packed
+        """The packed form with 1 or 2 matrix rows per slot row (falls back to 1
+        where rows cannot share slot rows); built on first use."""
+        with self._packed_lock:
+            if rows_per_unit not in self._packed:
+                packed = PackedEllMatrices(*self._pack_args, rows_per_unit=rows_per_unit)
+                if not packed.ok and rows_per_unit > 1:
+                    packed = self._packed.get(1) or PackedEllMatrices(
+                        *self._pack_args, rows_per_unit=1)
+                    self._packed.setdefault(1, packed)
+                self._packed[rows_per_unit] = packed
+            return self._packed[rows_per_unit]
 
     def _terms(self, specs, ghosts):
         terms = (_lib.KronEllTerm * len(specs))()

@@ -413,16 +413,18 @@ class _FusedKronSum:
 
     def apply(self, vec_in, vec_out, beta=0.0):
         time_comm = 0.0
-        if self.use_ell and type(self).use_pack and self.ell.packed.ok:
+        packed = (self.ell.packed_for(vec_in.n_loc)
+                  if self.use_ell and type(self).use_pack else None)
+        if packed is not None and packed.ok:
             # one pass: matrix stream packed, ghost time steps handled by an extra
             # lane per row (csrc/kron_pack.hip); the halo has to be there first
             ghosts = None
             if self.dofs_distr.size > 1 and (self.needs_lo or self.needs_hi):
                 time_comm = vec_in.communicate_bdr()
                 ghosts = vec_in.ghost_interleaved()
-            self.ell.packed.apply([(self.tri[k], k) for k in range(self.n_terms)],
-                                  vec_in.buf, ghosts, vec_in.n_loc, vec_in.ld,
-                                  beta, vec_out.buf)
+            packed.apply([(self.tri[k], k) for k in range(self.n_terms)],
+                         vec_in.buf, ghosts, vec_in.n_loc, vec_in.ld, beta,
+                         vec_out.buf)
             return time_comm
         if self.use_ell:
             # the slab-local part runs while the halo exchange is in flight
@@ -465,9 +467,9 @@ class _FusedKronSum:
         line and for matching a PMC record to the build)."""
         if not self.use_ell:
             return 'kron_sum_kernel<%d>' % self.n_terms
-        if type(self).use_pack and self.ell.packed.ok:
+        if type(self).use_pack and self.ell.packed_for(n_loc).ok:
             ghost = self.dofs_distr.size > 1 and (self.needs_lo or self.needs_hi)
-            pk = self.ell.packed
+            pk = self.ell.packed_for(n_loc)
             return 'kron_pack_kernel<%d, %d, %s, %s>' % (
                 self.n_terms, pk.K, 'ghost lanes' if ghost else 'no ghosts',
                 'row pairs' if pk.rows_per_unit == 2 else 'single rows')

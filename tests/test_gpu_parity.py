@@ -1485,7 +1485,7 @@ def test_kron_plan_from_csr_through_ctypes_only(stk):
     keep = [(m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data.astype(np.float64))
             for m in mats]
     arr = lambda j: (ctypes.c_void_p * 2)(*[k[j].ctypes.data for k in keep])
-    M, n_loc, ld = M_x.shape[0], 9, 10
+    M, n_loc, ld = M_x.shape[0], 33, 34  # long enough for the plan to use its pair form
     x = torch.zeros((M, ld), dtype=torch.float64, device='cuda')
     x[:, :n_loc] = torch.from_numpy(rng.rand(M, n_loc)).cuda()
     t = [_lib_dev(rng.rand(3, n_loc)) for _ in range(2)]

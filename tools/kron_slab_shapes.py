@@ -72,9 +72,12 @@ for shape in args.shapes.split(','):
     pspecs = [(tri[0], 0), (tri[1], 1)]
     for flags in [int(v) for v in args.flags.split(',')]:
         _lib.check(_lib.lib().stk_set_tuning(b'pack_flags', flags))
+        one = ell.packed_variant(1)
+        ms1 = timed(lambda: one.apply(pspecs, x, gh, n_loc, ld, 0.0, y2))
         msp = timed(lambda: ell.packed.apply(pspecs, x, gh, n_loc, ld, 0.0, y2))
         ell.apply(specs, n_loc, ld, 0.0, y)
         err = float((y2 - y).abs().max())
+        print('                     packed, one row per slot row: %.3f ms' % ms1)
         print('                     packed flags=%d: %.3f ms  %.0f GB/s algorithmic (%.1f%% of 8 TB/s)  max|diff to plain| %.1e  -> x%d ranks: %.2f TB/s aggregate'
               % (flags, msp, nbytes / msp / 1e6, nbytes / msp / 1e6 / 80, err, round(65 / n_loc),
                  round(65 / n_loc) * nbytes / msp / 1e9))
