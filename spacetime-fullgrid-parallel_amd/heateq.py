@@ -92,45 +92,43 @@ class HeatEquation:
         self.u0_x = space_load(mesh_space, data['u0'])
         self.f = self.BT @ (self.K @ self.g_vec) + np.kron(u0_t, self.u0_x)
 
+    def solve(self, callback=None):
+        """PCG on the wavelet-transformed system; returns (u, iterations)."""
+        w, iters = PCG(self.WT_S_W, self.P, self.WT @ self.f, callback=callback)
+        return self.W @ w, iters
 
-def main():
-    parser = argparse.ArgumentParser(
-        description='Solve the heat equation, serial wiring.')
-    parser.add_argument('--problem', default='square',
-                        help='problem type (square, lshape, cube)')
-    parser.add_argument('--J_time', type=int, default=5,
-                        help='number of time refines')
-    parser.add_argument('--J_space', type=int, default=6,
-                        help='number of space refines')
-    parser.add_argument('--precond', default='multigrid',
-                        help='spatial preconditioner: multigrid or direct.')
-    parser.add_argument('--alpha', type=float, default=0.3,
-                        help='Alpha value used in the preconditioner for X.')
-    args = parser.parse_args()
+    def errors(self, u):
+        """(algebraic error of u in the X-norm, error in Y') as the reference's
+        driver reports them (heateq.py:147-153)."""
+        residual = self.f - self.S @ u
+        defect = self.g_vec - self.B @ u
+        return residual @ (self.P @ residual), defect @ (self.K @ defect)
 
-    print('Arguments: {}'.format(args))
-    print('\n\nCreating HeatEquation with {} time refines and {} space refines.'
-          .format(args.J_time, args.J_space))
-    heat_eq = HeatEquation(J_time=args.J_time, J_space=args.J_space,
-                           problem=args.problem, precond=args.precond,
-                           alpha=args.alpha)
-    print('Size of time mesh: {} dofs. Size of space mesh: {} dofs'.format(
-        heat_eq.N, heat_eq.M))
 
-    def cb(w, residual, k):
-        print('.', end='', flush=True)
+_OPTIONS = (
+    ('problem', str, 'square', 'problem type (square, lshape, cube)'),
+    ('J_time', int, 5, 'number of time refines'),
+    ('J_space', int, 6, 'number of space refines'),
+    ('precond', str, 'multigrid', 'spatial preconditioner: multigrid or direct.'),
+    ('alpha', float, 0.3, 'Alpha value used in the preconditioner for X.'),
+)
 
-    print("Solving: ", end='')
-    w, iters = PCG(heat_eq.WT_S_W, heat_eq.P, heat_eq.WT @ heat_eq.f,
-                   callback=cb)
-    u = heat_eq.W @ w
-    res = heat_eq.f - heat_eq.S @ u
-    error_alg = res @ (heat_eq.P @ res)
-    gminBu = heat_eq.g_vec - heat_eq.B @ u
-    error_Yprime = gminBu @ (heat_eq.K @ gminBu)
-    print("Done in {}  PCG steps. "
-          "X-norm algebraic error: {}. "
-          "Error in Yprime: {}\n".format(iters, error_alg, error_Yprime))
+
+def main(argv=None):
+    parser = argparse.ArgumentParser(description='Solve the heat equation, serial wiring.')
+    for flag, kind, default, text in _OPTIONS:
+        parser.add_argument('--' + flag, type=kind, default=default, help=text)
+    args = parser.parse_args(argv)
+    print('Arguments: %s' % args)
+    print('\n\nCreating HeatEquation with %d time refines and %d space refines.'
+          % (args.J_time, args.J_space))
+    heat = HeatEquation(**vars(args))
+    print('Size of time mesh: %d dofs. Size of space mesh: %d dofs' % (heat.N, heat.M))
+    print('Solving: ', end='')
+    u, iters = heat.solve(callback=lambda w, residual, k: print('.', end='', flush=True))
+    print('Done in %d  PCG steps. X-norm algebraic error: %s. Error in Yprime: %s\n'
+          % ((iters,) + heat.errors(u)))
+    return heat, u, iters
 
 
 if __name__ == '__main__':

@@ -7,19 +7,15 @@ Launch one process per GPU:
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 \
         heateq_mpi.py --J_time=6 --J_space=9
 """
-import argparse
-import base64
 import os
-import pickle
 import sys
-import zlib
 
 import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
-from source import _lib
+from source import _lib, driver
 from source.assembly import (prolongation_matrices, space_load,
                              space_matrices, time_matrices)
 from source.comm import MPI
@@ -36,12 +32,7 @@ from source.wavelets import (TransposedWaveletTransformKronIdentityMPI,
                              WaveletTransformOp)
 
 
-def mem():
-    """Device memory in use by this process, MB (the reference reports host
-    RSS, heateq_mpi.py:24-26; the vectors and matrices live in HBM here)."""
-    if torch.cuda.is_available():
-        return torch.cuda.memory_allocated() / 1048576
-    return 0.0
+mem = driver.device_mb
 
 
 class SchurMPI(LinearOperatorMPI):
@@ -268,100 +259,46 @@ class HeatEquationMPI:
         self.mem_after_mpi = mem()
 
     def print_time_per_apply(self):
-        print('W:  {:.5f}\t{:.5f}'.format(*self.W.time_per_apply()))
-        print('S:  {:.5f}\t{:.5f}'.format(*self.S.time_per_apply()))
-        print('WT: {:.5f}\t{:.5f}'.format(*self.WT.time_per_apply()))
-        print('P:  {:.5f}\t{:.5f}'.format(*self.P.time_per_apply()))
+        for name in driver.OPERATORS:
+            print('%-4s%.5f\t%.5f' % ((name + ':',) + tuple(getattr(self, name).time_per_apply())))
         print('')
 
 
 def main(argv=None):
-    parser = argparse.ArgumentParser(
-        description='Solve heatequation on MI355X GPUs, one time slab each.')
-    parser.add_argument('--problem', default='square',
-                        help='problem type (square, lshape, cube)')
-    parser.add_argument('--J_time', type=int, default=7,
-                        help='number of time refines')
-    parser.add_argument('--J_space', type=int, default=7,
-                        help='number of space refines')
-    parser.add_argument('--smoothsteps', type=int, default=3,
-                        help='number of smoothing steps')
-    parser.add_argument('--vcycles', type=int, default=2,
-                        help='number of vcycles')
-    parser.add_argument('--wavelettransform', default='composite',
-                        help='type of wavelettransform')
-    parser.add_argument('--alpha', type=float, default=0.3, help='alpha')
-    parser.add_argument('--schur', default='fused',
-                        help='fused (2 multigrid applies per S) or reference')
-    args = parser.parse_args(argv)
-    J_time, J_space = args.J_time, args.J_space
-
-    comm = MPI.COMM_WORLD
-    rank, size = comm.Get_rank(), comm.Get_size()
-    if size > 2**J_time + 1:
-        print('Too many ranks!')
-        sys.exit('1')
-    if rank == 0:
-        print('\n\nCreating mesh with {} time refines and {} space refines.'.
-              format(J_time, J_space))
-        print('GPU ranks: {} '.format(size))
-        print('Arguments: {}'.format(args))
-
-    heat_eq_mpi = HeatEquationMPI(J_space=J_space,
-                                  J_time=J_time,
-                                  problem=args.problem,
-                                  smoothsteps=args.smoothsteps,
-                                  vcycles=args.vcycles,
-                                  alpha=args.alpha,
-                                  wavelettransform=args.wavelettransform,
-                                  schur=args.schur)
+    args = driver.parse('Solve heatequation on MI355X GPUs, one time slab each.', argv,
+                        extra=[('schur', str, 'fused',
+                                'fused (2 multigrid applies per S) or reference')])
+    comm, rank, size = driver.start(args)
+    heat = HeatEquationMPI(**driver.solver_arguments(args))
     # per-rank record, gathered and printed as one blob at the end
-    # (reference heateq_mpi.py:237, 259-312)
-    data = {'rank': rank, 'mem_after_construction': mem()}
+    record = {'rank': rank, 'mem_after_construction': mem()}
     if rank == 0:
-        data['args'] = vars(args)
-        data['N'], data['M'] = heat_eq_mpi.N, heat_eq_mpi.M
-        print('N = {}. M = {}.'.format(heat_eq_mpi.N, heat_eq_mpi.M))
-        print('Constructed bilinear forms in {} s.'.format(
-            heat_eq_mpi.setup_time))
-        print('Device memory after construction: {}mb.'.format(mem()))
+        record.update(args=vars(args), N=heat.N, M=heat.M)
+        driver.report_construction(heat)
 
-    def cb(w, residual, k):
+    def progress(w, residual, k):
         if rank == 0:
             print('.', end='', flush=True)
 
     LinearOperatorMPI.sync_timing = True
     comm.Barrier()
-    solve_time = MPI.Wtime()
-    hist = []
-    u_mpi_P, iters = PCG(heat_eq_mpi.WT_S_W, heat_eq_mpi.P, heat_eq_mpi.rhs,
-                         callback=cb, history=hist)
+    began = MPI.Wtime()
+    history = []
+    solution, iters = PCG(heat.WT_S_W, heat.P, heat.rhs, callback=progress,
+                          history=history)
     comm.Barrier()
-    solve_time = MPI.Wtime() - solve_time
-    data['solve_time'] = solve_time
-    data['mem_after_solve'] = mem()
-    data['iters'] = iters
-    data['r_dot_Pr'] = list(hist)
-    for name, op in [('W', heat_eq_mpi.W), ('S', heat_eq_mpi.S),
-                     ('WT', heat_eq_mpi.WT), ('P', heat_eq_mpi.P),
-                     ('WT_S_W', heat_eq_mpi.WT_S_W)]:
-        data[name] = {
-            'time_applies': op.time_applies,
-            'time_communication': op.time_communication,
-            'num_applies': op.num_applies
-        }
+    record.update(solve_time=MPI.Wtime() - began, mem_after_solve=mem(),
+                  iters=iters, r_dot_Pr=list(history))
+    for name in driver.OPERATORS + ('WT_S_W',):
+        record[name] = driver.counters(getattr(heat, name))
     if rank == 0:
-        print('')
-        print('Completed in {} PCG steps.'.format(iters))
-        print('Total solve time: {}s.'.format(solve_time))
-        print('Final r.Pr: {}'.format(hist[-1]))
-        heat_eq_mpi.print_time_per_apply()
-        print('Device memory after solve: {}mb.'.format(mem()))
-    data = comm.gather(data, root=0)
-    if rank == 0:
-        print('\ndata: {}'.format(
-            str(base64.b64encode(zlib.compress(pickle.dumps(data))), 'ascii')))
-    return heat_eq_mpi, u_mpi_P, iters, hist
+        print('\nCompleted in %d PCG steps.' % iters)
+        print('Total solve time: %ss.' % record['solve_time'])
+        print('Final r.Pr: %s' % history[-1])
+        heat.print_time_per_apply()
+        print('Device memory after solve: %smb.' % mem())
+    driver.publish(comm, record)
+    return heat, solution, iters, history
 
 
 if __name__ == "__main__":

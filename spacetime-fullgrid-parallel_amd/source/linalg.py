@@ -4,6 +4,12 @@ import numpy as np
 from .mpi_vector import KronVectorMPI
 
 
+def _zero_like(b):
+    if isinstance(b, KronVectorMPI):
+        return KronVectorMPI(b.dofs_distr)
+    return np.zeros(b.shape)
+
+
 def PCG(T, P, b, w0=None, kmax=100000, eps=1e-6, callback=None, history=None):
     """Preconditioned conjugate gradients for T w = b with preconditioner P;
     stops as soon as the algebraic error estimate r.Pr drops below eps^2
@@ -13,41 +19,32 @@ def PCG(T, P, b, w0=None, kmax=100000, eps=1e-6, callback=None, history=None):
 
     Returns (w, iters).  If `history` is a list, r.Pr is appended after the
     initial residual and after every iteration."""
-    if w0 is not None:
-        w = w0
-    elif isinstance(b, KronVectorMPI):
-        w = KronVectorMPI(b.dofs_distr)
-    else:
-        w = np.zeros(b.shape)
-
-    iters = 0
+    w = _zero_like(b) if w0 is None else w0
+    record = (lambda value: None) if history is None else history.append
+    threshold = eps * eps
+    done = 0
     if b.dot(b) == 0:
-        return w, iters
+        return w, done
 
-    r = b - T @ w
-    p = P @ r
-    rho = r.dot(p)
-    if history is not None:
-        history.append(rho)
-    if rho < eps * eps:
-        return w, iters
-
-    for k in range(1, kmax):
-        iters += 1
-        Tp = T @ p
-        step = rho / p.dot(Tp)
-        w += step * p
-        r -= step * Tp
-        del Tp
+    residual = b - T @ w
+    direction = P @ residual
+    rho = residual.dot(direction)
+    record(rho)
+    while rho >= threshold and done < kmax - 1:
+        done += 1
+        image = T @ direction
+        step = rho / direction.dot(image)
+        w += step * direction
+        residual -= step * image
+        del image  # one slab less while P works
         if callback is not None:
-            callback(w, r, k)
-        z = P @ r
-        rho_prev, rho = rho, r.dot(z)
-        if history is not None:
-            history.append(rho)
-        if rho < eps * eps:
+            callback(w, residual, done)
+        z = P @ residual
+        rho, previous = residual.dot(z), rho
+        record(rho)
+        if rho < threshold:
             break
-        p *= rho / rho_prev
-        p += z
+        direction *= rho / previous
+        direction += z
         del z
-    return w, iters
+    return w, done
