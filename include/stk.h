@@ -85,6 +85,20 @@ int stk_pcg_solve(void *stream, int64_t n, stk_operator_fn T, void *T_ctx,
                   void *allreduce_ctx, const double *b, double *w, double eps,
                   int32_t kmax, double *work, double *history, int32_t *iters);
 
+/* ---- per-operation device-time counters (LinearOperatorMPI.num_applies /
+ *      time_applies, mpi_kron.py:23-36, for hosts without the Python classes) -----
+ * While enabled, every apply entry point brackets what it enqueues with two
+ * HIP events on its stream.  stk_timing_get waits for the recorded events and
+ * returns the number of calls and the summed device seconds of one class:
+ * "kron" (stk_kron_*_apply), "space" (stk_csr_spmm, stk_ell_spmm), "time"
+ * (stk_time_*_apply), "wavelet", "multigrid" (stk_mg_apply, stk_mg_smooth),
+ * "blas1" (stk_axpby(z), stk_dot).  Classes nest where entry points do (the
+ * BLAS-1 calls of stk_pcg_solve are counted as blas1).  Communication time is
+ * the caller's: the library does not communicate. */
+int stk_timing_enable(int32_t on);
+int stk_timing_reset(void);
+int stk_timing_get(const char *op_class, int64_t *calls, double *seconds);
+
 /* ---- Lanczos estimate of the extreme eigenvalues of P A (Lanczos,
  *      lanczos.py:87-159; Sturm-sequence bisection bisec / pol, :20-85) ---------
  * The reference's recurrence on device vectors of n doubles: `w` holds the start

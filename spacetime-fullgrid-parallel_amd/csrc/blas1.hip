@@ -88,6 +88,7 @@ __global__ __launch_bounds__(1024) void dot_final_kernel(int n_partial, const do
 extern "C" int stk_axpbyz(void *stream, int64_t n, double a, const double *x, double b, const double *y,
                           double *z)
 {
+    const stk_timed timed_(STK_OP_BLAS1, stream);
     if (n <= 0) return 0;
     STK_REQUIRE(x && z && (b == 0.0 || y), "stk_axpbyz: null pointer");
     STK_REQUIRE((((uintptr_t)x | (uintptr_t)z | (uintptr_t)(b == 0.0 ? z : y)) & 15) == 0,
@@ -107,6 +108,7 @@ extern "C" int64_t stk_dot_work_size(void) { return DOT_BLOCKS; }
 
 extern "C" int stk_dot(void *stream, int64_t n, const double *x, const double *y, double *work, double *out)
 {
+    const stk_timed timed_(STK_OP_BLAS1, stream);
     STK_REQUIRE(work && out, "stk_dot: null work/out");
     STK_REQUIRE(n == 0 || (x && y), "stk_dot: null input");
     STK_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "stk_dot: arrays must be 16-byte aligned");

@@ -463,6 +463,7 @@ extern "C" int stk_kron_sum_apply(void *stream, int32_t M, int32_t n_loc, int32_
                                   const int32_t *indices, const int32_t *row_ids, int32_t n_terms,
                                   const stk_kron_term *t, double beta, double *y)
 {
+    const stk_timed timed_(STK_OP_KRON, stream);
     STK_REQUIRE(M > 0 && n_loc > 0 && ld >= n_loc, "stk_kron_sum_apply: bad sizes M=%d n_loc=%d ld=%d", M,
                 n_loc, ld);
     STK_REQUIRE((ld & 1) == 0, "stk_kron_sum_apply: ld=%d must be even (16-byte time pairs)", ld);
@@ -491,6 +492,7 @@ extern "C" int stk_csr_spmm(void *stream, int32_t rows, int32_t n_loc, int32_t l
                             const double *cm, const double *x, double alpha, double beta, const double *z,
                             double *y)
 {
+    const stk_timed timed_(STK_OP_SPACE, stream);
     if (rows == 0) return 0;
     STK_REQUIRE(rows > 0 && n_loc > 0 && ld >= n_loc, "stk_csr_spmm: bad sizes");
     STK_REQUIRE(indptr && indices && vals_a && x && y, "stk_csr_spmm: null pointer");
@@ -528,6 +530,7 @@ __global__ __launch_bounds__(256) void time_dense_kernel(int64_t total, int32_t 
 extern "C" int stk_time_dense_apply(void *stream, int32_t M, int32_t n_in, int32_t ld_in, int32_t n_out,
                                     int32_t ld_out, const double *T, const double *x, double *y)
 {
+    const stk_timed timed_(STK_OP_TIME, stream);
     STK_REQUIRE(M > 0 && n_in > 0 && n_out > 0 && ld_in >= n_in && ld_out >= n_out,
                 "stk_time_dense_apply: bad sizes M=%d n_in=%d ld_in=%d n_out=%d ld_out=%d", M, n_in, ld_in, n_out,
                 ld_out);
@@ -543,6 +546,7 @@ extern "C" int stk_time_csr_apply(void *stream, int32_t M, int32_t n_loc, int32_
                                   const int32_t *t_cols, const double *t_vals, const double *x,
                                   const double *recv, int32_t add_identity, double *y)
 {
+    const stk_timed timed_(STK_OP_TIME, stream);
     STK_REQUIRE(M > 0 && n_loc > 0 && ld >= n_loc, "stk_time_csr_apply: bad sizes");
     STK_REQUIRE(t_indptr && t_cols && t_vals && x && y, "stk_time_csr_apply: null pointer");
     STK_REQUIRE(x != y, "stk_time_csr_apply: input aliases output");  // mpi_kron.py:296

@@ -508,6 +508,7 @@ int stk_kron_ell_set_tuning(const char *key, int32_t value)
 extern "C" int stk_kron_ell_ghost_apply(void *stream, const stk_ell_pattern *pat, int32_t n_loc, int32_t ld,
                                         int32_t n_terms, const stk_kron_ell_term *t, double *y)
 {
+    const stk_timed timed_(STK_OP_KRON, stream);
     STK_REQUIRE(pat && t && y, "stk_kron_ell_ghost_apply: null pointer");
     STK_REQUIRE(pat->M > 0 && pat->K >= 1 && pat->ell_idx, "stk_kron_ell_ghost_apply: bad pattern");
     STK_REQUIRE(n_loc > 0 && ld >= n_loc, "stk_kron_ell_ghost_apply: bad sizes n_loc=%d ld=%d", n_loc, ld);
@@ -528,6 +529,7 @@ extern "C" int stk_kron_ell_ghost_apply(void *stream, const stk_ell_pattern *pat
 extern "C" int stk_kron_ell_apply(void *stream, const stk_ell_pattern *pat, int32_t n_loc, int32_t ld,
                                   int32_t n_terms, const stk_kron_ell_term *t, double beta, double *y)
 {
+    const stk_timed timed_(STK_OP_KRON, stream);
     STK_REQUIRE(pat && t && y, "stk_kron_ell_apply: null pointer");
     STK_REQUIRE(pat->M > 0 && pat->K >= 1, "stk_kron_ell_apply: bad pattern M=%d K=%d", pat->M, pat->K);
     STK_REQUIRE(pat->ell_idx, "stk_kron_ell_apply: pattern has no ell_idx");

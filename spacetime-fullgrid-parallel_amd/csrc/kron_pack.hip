@@ -502,6 +502,7 @@ extern "C" int stk_kron_pack_apply(void *stream, const stk_pack_pattern *pat, in
                                    int32_t n_terms, const stk_kron_pack_term *t, const double *x,
                                    const double *ghosts, double beta, double *y)
 {
+    const stk_timed timed_(STK_OP_KRON, stream);
     STK_REQUIRE(pat && t && x && y, "stk_kron_pack_apply: null pointer");
     STK_REQUIRE(pat->M > 0 && pat->K >= 1 && pat->slots && pat->dict, "stk_kron_pack_apply: bad pattern");
     STK_REQUIRE(pat->rows_per_unit == 1 || pat->rows_per_unit == 2,

@@ -460,6 +460,7 @@ extern "C" int stk_mg_destroy(stk_mg *mg)
 extern "C" int stk_mg_apply(stk_mg *mg, void *stream, int32_t n_loc, int32_t ld, double ca, const double *cm,
                             const int32_t *kind, const double *f, double *u)
 {
+    const stk_timed timed_(STK_OP_MULTIGRID, stream);
     STK_REQUIRE(mg && f && u && f != u, "stk_mg_apply: bad pointers");
     STK_REQUIRE(n_loc > 0 && ld >= n_loc && ld <= mg->max_ld, "stk_mg_apply: ld=%d exceeds plan max_ld=%d", ld,
                 mg->max_ld);
@@ -477,6 +478,7 @@ extern "C" int stk_mg_apply(stk_mg *mg, void *stream, int32_t n_loc, int32_t ld,
 extern "C" int stk_mg_smooth(stk_mg *mg, void *stream, int32_t level, int32_t n_loc, int32_t ld, double ca,
                              const double *cm, int32_t its, int32_t backward, const double *f, double *u)
 {
+    const stk_timed timed_(STK_OP_MULTIGRID, stream);
     STK_REQUIRE(mg && f && u, "stk_mg_smooth: null pointer");
     STK_REQUIRE(level >= 1 && level < (int)mg->lv.size(), "stk_mg_smooth: level %d out of range", level);
     STK_REQUIRE(n_loc > 0 && ld >= n_loc, "stk_mg_smooth: bad sizes");

@@ -333,6 +333,7 @@ extern "C" int stk_ell_spmm(void *stream, const stk_ell_rows *ell, int32_t n_loc
                             double ca, const double *cm, const double *x, double alpha, double beta,
                             const double *z, double *y)
 {
+    const stk_timed timed_(STK_OP_SPACE, stream);
     STK_REQUIRE(ell && x && y && x != y, "stk_ell_spmm: bad pointers");
     STK_REQUIRE(beta == 0.0 || z, "stk_ell_spmm: beta != 0 needs z");
     return stk_rows_ell_launch(stk_stream(stream), MODE_SPMM, ell, 0, ell->n_pos, n_loc, ld, x_rows, ell->n_rows, ca,

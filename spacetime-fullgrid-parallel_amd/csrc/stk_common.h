@@ -30,6 +30,27 @@ void stk_set_error(const char *fmt, ...);
 
 static inline hipStream_t stk_stream(void *s) { return (hipStream_t)s; }
 
+// Per-operation device-time counters of the C ABI (stk_timing_*, common.hip; the
+// counterpart of LinearOperatorMPI.time_applies, reference mpi_kron.py:23-36): a
+// public entry point brackets what it enqueues with two HIP events while timing
+// is enabled.  Costs one branch otherwise.
+enum { STK_OP_KRON = 0, STK_OP_SPACE, STK_OP_TIME, STK_OP_WAVELET, STK_OP_MULTIGRID, STK_OP_BLAS1, STK_OP_CLASSES };
+extern bool g_stk_timing;
+void *stk_timing_begin(int op, hipStream_t st);
+void stk_timing_end(void *slot, hipStream_t st);
+struct stk_timed {
+    hipStream_t st;
+    void *slot;
+    stk_timed(int op, void *stream)
+        : st(stk_stream(stream)), slot(g_stk_timing ? stk_timing_begin(op, stk_stream(stream)) : nullptr)
+    {
+    }
+    ~stk_timed()
+    {
+        if (slot) stk_timing_end(slot, st);
+    }
+};
+
 // Compute units of the current device, queried once (a property query per
 // launch costs more host time than the launch itself).
 int stk_cu_count();

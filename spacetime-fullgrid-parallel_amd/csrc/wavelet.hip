@@ -241,6 +241,7 @@ int stk_wavelet_set_tuning(const char *key, int32_t value)
 extern "C" int stk_wavelet_apply(void *stream, int32_t M, int32_t J, int32_t ld, int32_t transposed,
                                  const double *x, double *y)
 {
+    const stk_timed timed_(STK_OP_WAVELET, stream);
     STK_REQUIRE(M > 0 && J >= 0 && J <= 11, "stk_wavelet_apply: bad M=%d J=%d", M, J);
     const int N = (1 << J) + 1;
     STK_REQUIRE(ld >= N, "stk_wavelet_apply: ld=%d < 2^J+1=%d", ld, N);

@@ -864,6 +864,54 @@ def test_c_lanczos_matches_python_lanczos(stk):
     assert rc == 7 and b'operator A failed' in lib.stk_last_error()
 
 
+def test_c_abi_timing_counters(stk):
+    """stk_timing_*: per-class call counts and device seconds of the apply entry
+    points (the C-side counterpart of LinearOperatorMPI.num_applies /
+    time_applies, reference mpi_kron.py:23-36), against what one S apply, one W
+    apply and one dot are known to enqueue, and against the HIP-event time of the
+    whole sequence."""
+    import ctypes
+    import heateq_mpi as hm
+    lib = stk.lib()
+    h = hm.HeatEquationMPI(J_space=4, J_time=4)
+    x = h.rhs.copy()
+    h.S @ x
+    h.W @ x  # plans and workspaces exist now
+
+    def read(name):
+        calls, seconds = ctypes.c_int64(), ctypes.c_double()
+        stk.check(lib.stk_timing_get(name.encode(), ctypes.byref(calls), ctypes.byref(seconds)))
+        return calls.value, seconds.value
+
+    try:
+        stk.check(lib.stk_timing_enable(1))
+        stk.check(lib.stk_timing_reset())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        h.S @ x
+        h.W @ x
+        x.dot(x)
+        e1.record()
+        torch.cuda.synchronize()
+        whole = e0.elapsed_time(e1) * 1e-3
+        kron, wav, mg, blas = read('kron'), read('wavelet'), read('multigrid'), read('blas1')
+        assert kron[0] == 3 and mg[0] == 2 and wav[0] == 1  # SchurMPI: 3 fused passes, 2 K applies
+        assert blas[0] >= 1
+        for calls, seconds in (kron, wav, mg, blas):
+            assert 0.0 < seconds < whole
+        assert mg[1] > kron[1] > 0.0  # two V-cycle applies outweigh three Kronecker passes
+        assert kron[1] + wav[1] + mg[1] <= whole * 1.001
+        stk.check(lib.stk_timing_reset())
+        assert read('kron') == (0, 0.0)
+        stk.check(lib.stk_timing_enable(0))
+        h.W @ x
+        assert read('wavelet') == (0, 0.0)  # disabled: nothing recorded
+        assert lib.stk_timing_get(b'nonsense', None, None) != 0
+        assert b'unknown class' in lib.stk_last_error()
+    finally:
+        lib.stk_timing_enable(0)
+
+
 def test_restricted_residual_variants_agree(stk):
     """d = R (A u - f) in two steps, or as (R A) u - R f with the precomputed
     product R A (stk_mg_level.ell_ra): same V-cycle up to rounding."""
