@@ -281,7 +281,8 @@ int stk_kron_plan_apply(stk_kron_plan *plan, void *stream, int32_t n_loc,
                         double *ghost_work, double beta, double *y);
 
 /* Diagnostic: while `buf` (device, at least 8 * grid * 4 words) is non-NULL,
- * the headline instantiation (2 terms, K = 7, no ghosts) runs a stamped build
+ * the headline instantiation of the one-row form (2 terms, K = 7, no ghosts;
+ * tuning key "pack_rows" = 1) runs a stamped build
  * that leaves, per wavefront, the shader-clock cycles spent in the four
  * segments of a row-group iteration.  NULL switches it off. */
 int stk_kron_pack_set_diag(unsigned long long *buf);

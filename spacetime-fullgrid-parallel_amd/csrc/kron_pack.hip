@@ -83,7 +83,7 @@ __device__ inline unsigned long long stamp()
     return t;
 }
 
-// DIAG = true is a separate diagnostic instantiation (tools/kron_phases.py): every
+// DIAG = true is a separate diagnostic instantiation (tools/kron_ab.py --phases): every
 // wave sums the shader-clock cycles it spends in the four segments of an
 // iteration -- publish + barrier, gathers + space factors, exchange + barrier,
 // time stencil + store -- into a.diag[wave][4].  Its outputs are still correct;
@@ -543,7 +543,7 @@ extern "C" int stk_interleave_ghosts(void *stream, int32_t M, const double *lo, 
     return 0;
 }
 
-/* Diagnostic (tools/kron_phases.py): while `buf` is set, launches of the headline
+/* Diagnostic (tools/kron_ab.py --phases): while `buf` is set, launches of the headline
  * instantiation (2 terms, K = 7, no ghosts) run the stamped build and leave
  * per-wave cycle sums of the four segments of an iteration in buf[wave][4]. */
 extern "C" int stk_kron_pack_set_diag(unsigned long long *buf)

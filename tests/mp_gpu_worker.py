@@ -28,7 +28,7 @@ from source.mpi_vector import KronVectorMPI  # noqa: E402
 def main():
     comm = MPI.COMM_WORLD
     rank, size = comm.Get_rank(), comm.Get_size()
-    J_time, J_space = 4, 3
+    J_time, J_space = int(os.environ.get('STK_TEST_J_TIME', '4')), 3
     problem = os.environ.get('STK_TEST_PROBLEM', 'square')
     h = hm.HeatEquationMPI(J_space=J_space, J_time=J_time, problem=problem)
     dd = h.dofs_distr

@@ -52,6 +52,15 @@ def test_distributed_solve_ranks_sharing_one_gpu(nproc, problem):
 
 
 @pytest.mark.gpu
+def test_distributed_solve_on_slabs_long_enough_for_row_pairs():
+    """Two ranks with 32 and 33 time steps each (J_time = 6): the Kronecker
+    operators then run the row-pair form of the packed kernel together with its
+    ghost lanes (shorter slabs keep one row per slot row)."""
+    out = _run('mp_gpu_worker.py', 2, {'STK_BACKEND': 'gloo', 'STK_TEST_J_TIME': '6'})
+    assert 'mp_gpu_worker ok' in out
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('nproc', [1, 2, 3])
 def test_every_operator_class_on_several_ranks(nproc):
     """Every operator class and the vector algebra against dense NumPy ground

@@ -1309,7 +1309,7 @@ def test_strip_wise_sweeps_are_exact(stk):
                     assert rc == 0, (problem, strip_mb, width,
                                      stk.lib().stk_last_error().decode())
         finally:
-            stk.check(stk.lib().stk_set_tuning(b'mg_strip_mb', 120))
+            stk.check(stk.lib().stk_set_tuning(b'mg_strip_mb', 250))
             stk.check(stk.lib().stk_set_tuning(b'mg_strip_width', 2))
         for Pv, Sv in res[1:]:
             assert np.array_equal(Pv, res[0][0]) and np.array_equal(Sv, res[0][1])
@@ -1346,7 +1346,7 @@ def test_coupling_bands_are_verified(stk):
         F = np.random.RandomState(3).rand(n, 6)
         got = (mg @ F)
     finally:
-        stk.check(stk.lib().stk_set_tuning(b'mg_strip_mb', 120))
+        stk.check(stk.lib().stk_set_tuning(b'mg_strip_mb', 250))
         stk.check(stk.lib().stk_set_tuning(b'mg_strip_width', 2))
     want = OracleMG(B, prolongation_matrices(mesh), 3, 2) @ F
     assert relerr(got, want) < 1e-12
@@ -1648,7 +1648,7 @@ def test_multigrid_plan_from_csr_through_ctypes_only(stk):
                     assert relerr(got[:, t], C @ F[:, t]) < 1e-12, (problem, t)
                 stk.check(lib.stk_mg_destroy(plan))
         finally:
-            stk.check(lib.stk_set_tuning(b'mg_strip_mb', 120))
+            stk.check(lib.stk_set_tuning(b'mg_strip_mb', 250))
             stk.check(lib.stk_set_tuning(b'mg_strip_width', 2))
     # a matrix without a diagonal entry is refused with a message
     bad, keep = host(sp.csr_matrix(np.array([[0.0, 1.0], [1.0, 2.0]])))
