@@ -304,10 +304,15 @@ int stk_csr_spmm(void *stream, int32_t rows, int32_t n_loc, int32_t ld,
                  const double *cm, const double *x, double alpha, double beta,
                  const double *z, double *y);
 
-/* The same on a sliced-ELL copy (fast path; slot count K one of 2, 5, 7, 9,
- * 12, 16, 20; padding slots: any valid column, value 0).  ELL row `pos` produces
- * output row row_ids[pos]; dia_a / dia_m hold the diagonal entry of that row
- * (Gauss-Seidel only). */
+/* The same on a sliced-ELL copy (fast path; slot count K one of 2, 4, 5, 6, 7,
+ * 9, 12, 16, 20; padding slots: any valid column, value 0).  ELL row `pos`
+ * produces output row row_ids[pos]; dia_a / dia_m hold the diagonal entry of
+ * that row (Gauss-Seidel only).  diag_free (Gauss-Seidel copies): the slots hold
+ * the OFF-diagonal entries only and a row is updated as
+ *     u_i = (f_i - sum_{j != i} a_ij u_j) / a_ii
+ * -- the form of PETSc's MatSOR, which the reference calls (multigrid.py:116-127);
+ * one gather less per row than u_i += (f_i - sum_j a_ij u_j) / a_ii with the
+ * diagonal among the slots (diag_free = 0), equal up to rounding. */
 typedef struct {
     int32_t n_pos;  /* ELL rows */
     int32_t n_rows; /* rows of the output slab */
@@ -316,6 +321,7 @@ typedef struct {
     const double *va, *vm;  /* n_pos*K values; vm may be NULL */
     const int32_t *row_ids; /* n_pos or NULL */
     const double *dia_a, *dia_m; /* n_pos each or NULL */
+    int32_t diag_free;
 } stk_ell_rows;
 
 /* y = alpha * A(t) x + beta * z; x has x_rows rows, y and z have ell->n_rows.

@@ -54,8 +54,11 @@ __global__ __launch_bounds__(GBS) void gs_group_kernel(int64_t total, const int3
         const double *ut = u + t;
         const double c = (vm != nullptr) ? cm[t] : 0.0;
         double ax = 0.0;
-        // batches of independent gathers (clamped past the row end), summed in
-        // CSR order like the sequential sweep
+        const int ed = diag[i];
+        // batches of independent gathers (clamped past the row end), the
+        // off-diagonal entries summed in CSR order like the sequential sweep:
+        // u_i = (f_i - sum_{j != i} a_ij u_j) / a_ii, as the diagonal-free ELL
+        // copies of the row engine (stk_ell_rows.diag_free)
         for (int eb = e0; eb < e1; eb += 8) {
             double uv[8], av[8];
 #pragma unroll
@@ -66,12 +69,11 @@ __global__ __launch_bounds__(GBS) void gs_group_kernel(int64_t total, const int3
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q)
-                if (eb + q < e1) ax = fma(av[q], uv[q], ax);
+                if (eb + q < e1 && eb + q != ed) ax = fma(av[q], uv[q], ax);
         }
-        const int ed = diag[i];
         const double d = (vm != nullptr) ? fma(c, vm[ed], ca * va[ed]) : ca * va[ed];
         const size_t o = (size_t)i * ld + t;
-        u[o] += (1.0 / d) * (f[o] - ax);
+        u[o] = (1.0 / d) * (f[o] - ax);
     }
 }
 

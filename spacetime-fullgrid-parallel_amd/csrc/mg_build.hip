@@ -281,16 +281,18 @@ struct Builder {
     }
 };
 
-static const int ROW_SLOTS[] = {2, 5, 7, 9, 12, 16, 20};
+static const int ROW_SLOTS[] = {2, 4, 5, 6, 7, 9, 12, 16, 20};
 
 // sliced-ELL copy of the rows `order` of a union pattern (source/linop.py
 // EllRowsMatrix): K = smallest slot count that holds the longest listed row,
 // unused slots: column pad_col, value 0.  ok = false if a row is too long.
+// diag = true (Gauss-Seidel copies): the diagonal entries go to dia_a / dia_m and
+// NOT into the slots (stk_ell_rows.diag_free).
 bool ell_rows(Builder &B, const Union &u, const std::vector<int32_t> &order, bool diag, int pad_col,
               const std::vector<double> *dia_a, const std::vector<double> *dia_m, stk_ell_rows *out)
 {
     int kmax = 1;
-    for (int i : order) kmax = std::max(kmax, u.ptr[i + 1] - u.ptr[i]);
+    for (int i : order) kmax = std::max(kmax, u.ptr[i + 1] - u.ptr[i] - (diag ? 1 : 0));
     int K = 0;
     for (int s : ROW_SLOTS)
         if (s >= kmax) {
@@ -309,14 +311,16 @@ bool ell_rows(Builder &B, const Union &u, const std::vector<int32_t> &order, boo
     for (size_t p = 0; p < np; ++p) {
         const int i = order[p];
         rows[p] = i;
-        for (int e = u.ptr[i], s = 0; e < u.ptr[i + 1]; ++e, ++s) {
-            idx[p * K + s] = u.idx[e];
-            va[p * K + s] = u.va[e];
-            if (has_m) vm[p * K + s] = u.vm[e];
+        for (int e = u.ptr[i], s = 0; e < u.ptr[i + 1]; ++e) {
             if (diag && u.idx[e] == i) {
                 da[p] = u.va[e];
                 if (has_m) dm[p] = u.vm[e];
+                continue;
             }
+            idx[p * K + s] = u.idx[e];
+            va[p * K + s] = u.va[e];
+            if (has_m) vm[p * K + s] = u.vm[e];
+            ++s;
         }
         if (dia_a) {
             da[p] = (*dia_a)[i];
@@ -332,6 +336,7 @@ bool ell_rows(Builder &B, const Union &u, const std::vector<int32_t> &order, boo
     out->row_ids = B.up(rows);
     out->dia_a = (diag || dia_a) ? B.up(da) : nullptr;
     out->dia_m = ((diag || dia_a) && has_m) ? B.up(dm) : nullptr;
+    out->diag_free = diag ? 1 : 0;
     return true;
 }
 

@@ -32,6 +32,7 @@ struct Job {
     double *y;
     double alpha, beta;
     int32_t use_m;     // entries are ca*va + cm[t]*vm (level matrices) or plain va (transfers)
+    int32_t diag_free; // GS: slots hold the off-diagonal entries only, u_i = (f_i - s) / a_ii
     int32_t lx, lz, ly;  // the same three vectors as row offsets into the LDS arena (LDS variant)
 };
 
@@ -81,7 +82,7 @@ __device__ inline void run_rows_job(const Job &j, const CoarseArgs &a, int p0, i
         double2 zv = make_double2(0.0, 0.0), own = make_double2(0.0, 0.0);
         if (j.kind == JOB_GS) {
             zv = *reinterpret_cast<const double2 *>(j.z + yo);
-            own = *reinterpret_cast<const double2 *>(j.x + yo);
+            if (!j.diag_free) own = *reinterpret_cast<const double2 *>(j.x + yo);
         } else if (j.beta != 0.0) {
             zv = *reinterpret_cast<const double2 *>(j.z + yo);
         }
@@ -176,7 +177,7 @@ __device__ inline void run_rows_job_lds(const Job &j, const CoarseArgs &a, typen
         V zv = E::make(0.0, 0.0), own = E::make(0.0, 0.0);
         if (j.kind == JOB_GS) {
             zv = sv[j.lz + row];
-            own = vx[row];
+            if (!j.diag_free) own = vx[row];
         } else if (j.beta != 0.0) {
             zv = sv[j.lz + row];
         }
@@ -259,7 +260,9 @@ __global__ __launch_bounds__(CBS) void mg_coarse_lds_kernel(const CoarseArgs a)
         } else {
             switch (j.K) {
                 case 2: run_rows_job_lds<2, HAS_M, PAIR>(j, a, sv, cm0, cm1, has1); break;
+                case 4: run_rows_job_lds<4, HAS_M, PAIR>(j, a, sv, cm0, cm1, has1); break;
                 case 5: run_rows_job_lds<5, HAS_M, PAIR>(j, a, sv, cm0, cm1, has1); break;
+                case 6: run_rows_job_lds<6, HAS_M, PAIR>(j, a, sv, cm0, cm1, has1); break;
                 case 7: run_rows_job_lds<7, HAS_M, PAIR>(j, a, sv, cm0, cm1, has1); break;
                 case 9: run_rows_job_lds<9, HAS_M, PAIR>(j, a, sv, cm0, cm1, has1); break;
                 case 12: run_rows_job_lds<12, HAS_M, PAIR>(j, a, sv, cm0, cm1, has1); break;
@@ -318,7 +321,9 @@ __global__ __launch_bounds__(CBS) void mg_coarse_kernel(const CoarseArgs a)
         } else {
             switch (j.K) {
                 case 2: run_rows_job<2, HAS_M>(j, a, p0, W); break;
+                case 4: run_rows_job<4, HAS_M>(j, a, p0, W); break;
                 case 5: run_rows_job<5, HAS_M>(j, a, p0, W); break;
+                case 6: run_rows_job<6, HAS_M>(j, a, p0, W); break;
                 case 7: run_rows_job<7, HAS_M>(j, a, p0, W); break;
                 case 9: run_rows_job<9, HAS_M>(j, a, p0, W); break;
                 case 12: run_rows_job<12, HAS_M>(j, a, p0, W); break;
@@ -368,6 +373,7 @@ static Job rows_job(int kind, const stk_ell_rows &e, int pos_begin, int pos_end,
     j.row_ids = e.row_ids;
     j.dia_a = e.dia_a;
     j.dia_m = e.dia_m;
+    j.diag_free = e.diag_free;
     j.x = x;
     j.z = z;
     j.y = y;
@@ -407,7 +413,7 @@ stk_coarse_plan *stk_coarse_plan_build(const stk_coarse_level *lv, int Lc, int s
         z.row_ids = nullptr;
         z.y = C.u;
         z.alpha = z.beta = 0.0;
-        z.use_m = 0;
+        z.use_m = z.diag_free = 0;
         z.lx = z.lz = z.ly = -1;
         if (j - 1 >= 1) J.push_back(z);  // level 0 is overwritten by the exact solve
     }
@@ -423,7 +429,7 @@ stk_coarse_plan *stk_coarse_plan_build(const stk_coarse_level *lv, int Lc, int s
         c.z = lv[0].f;
         c.y = lv[0].u;
         c.alpha = c.beta = 0.0;
-        c.use_m = 0;
+        c.use_m = c.diag_free = 0;
         c.lx = c.lz = c.ly = -1;
         J.push_back(c);
     }

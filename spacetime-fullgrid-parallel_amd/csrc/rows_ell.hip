@@ -13,9 +13,12 @@
 // through a buffer descriptor, ELL entries of the next row group prefetched
 // into registers and handed over through double-buffered LDS (one barrier per
 // group).  What a pass costs is its wave-level VMEM instructions: K gathers, the
-// right-hand side and the store per lane; in GS mode the row's own value is
-// taken from the diagonal gather (every such row has its diagonal entry among
-// the K slots) rather than loaded again.
+// right-hand side and the store per lane.  Gauss-Seidel copies are normally
+// DIAGONAL-FREE (stk_ell_rows.diag_free): the slots hold the off-diagonal entries
+// and u_i = (f_i - sum_{j != i} a_ij u_j) / a_ii needs no read of u_i at all -- one
+// gather and one row of L2-miss traffic less per row (the launches are bound by
+// exactly that traffic).  With the diagonal among the
+// slots (diag_free = 0) the row's own value is taken from that gather.
 #include <cstring>
 
 #include "stk_common.h"
@@ -238,14 +241,16 @@ int launch_k(hipStream_t st, const RowsArgs &a, int K, unsigned grid, size_t lds
 {
     switch (K) {
         case 2: return launch_npf<MODE, 2, HAS_M>(st, a, grid, lds);
+        case 4: return launch_npf<MODE, 4, HAS_M>(st, a, grid, lds);
         case 5: return launch_npf<MODE, 5, HAS_M>(st, a, grid, lds);
+        case 6: return launch_npf<MODE, 6, HAS_M>(st, a, grid, lds);
         case 7: return launch_npf<MODE, 7, HAS_M>(st, a, grid, lds);
         case 9: return launch_npf<MODE, 9, HAS_M>(st, a, grid, lds);
         case 12: return launch_npf<MODE, 12, HAS_M>(st, a, grid, lds);
         case 16: return launch_npf<MODE, 16, HAS_M>(st, a, grid, lds);
         case 20: return launch_npf<MODE, 20, HAS_M>(st, a, grid, lds);
     }
-    stk_set_error("rows_ell: K=%d is not one of 2, 5, 7, 9, 12, 16, 20", K);
+    stk_set_error("rows_ell: K=%d is not one of 2, 4, 5, 6, 7, 9, 12, 16, 20", K);
     return 2;
 }
 
@@ -306,7 +311,7 @@ int stk_rows_ell_launch(hipStream_t st, int mode, const stk_ell_rows *e, int32_t
     a.ngroups = (pos_end - pos_begin + a.R - 1) / a.R;
     a.chunk = (a.ngroups + 7) / 8;
     a.reverse = g_rows_alternate ? (int)(g_rows_launch_count++ & 1u) : 0;
-    a.zero_own = zero_own;
+    a.zero_own = (zero_own || e->diag_free) ? 1 : 0;  // diagonal-free rows: u_i = (f_i - sum_{j != i}) / a_ii
     a.wide = g_rows_force_wide || x_rows * ld * 8 >= ((int64_t)1 << 32) || y_rows * ld * 8 >= ((int64_t)1 << 32);
     a.x_bytes = a.wide ? 0u : (uint32_t)(x_rows * ld * 8);
     a.y_bytes = a.wide ? 0u : (uint32_t)(y_rows * ld * 8);

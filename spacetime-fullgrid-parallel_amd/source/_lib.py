@@ -54,7 +54,7 @@ class KronPackTerm(ctypes.Structure):
 class EllRows(ctypes.Structure):
     _fields_ = [('n_pos', c_i32), ('n_rows', c_i32), ('K', c_i32),
                 ('idx', c_p), ('va', c_p), ('vm', c_p), ('row_ids', c_p),
-                ('dia_a', c_p), ('dia_m', c_p)]
+                ('dia_a', c_p), ('dia_m', c_p), ('diag_free', c_i32)]
 
 
 class CsrHost(ctypes.Structure):

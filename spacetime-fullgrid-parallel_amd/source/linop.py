@@ -211,15 +211,37 @@ def permute_rows(indptr, indices, vals, order):
 class EllRowsMatrix:
     """One matrix (values va, optionally a second value array vm on the same
     pattern) in the sliced-ELL form of the row-gather engine (stk_ell_rows,
-    include/stk.h).  `order` lists the rows in processing order; `diag` adds
-    the diagonal arrays the Gauss-Seidel mode needs.  `ok` is False when a row
+    include/stk.h).  `order` lists the rows in processing order; `diag` makes
+    the Gauss-Seidel copy (diagonal entries in their own arrays, off-diagonal
+    entries in the slots: stk_ell_rows.diag_free).  `ok` is False when a row
     has more entries than the largest instantiated slot count."""
-    SLOTS = (2, 5, 7, 9, 12, 16, 20)
+    SLOTS = (2, 4, 5, 6, 7, 9, 12, 16, 20)
     _tls = threading.local()  # per-thread (key, base arrays, referents)
 
     def __init__(self, indptr, indices, va, vm=None, order=None, n_cols=None,
                  diag=False, pad_col=0, dia_values=None):
         n = len(indptr) - 1
+        if diag:
+            # Gauss-Seidel copy: the diagonal goes to dia_a / dia_m and NOT into
+            # the slots (stk_ell_rows.diag_free, include/stk.h).  The forward and
+            # the backward copy of a level strip the same arrays: done once.
+            assert dia_values is None
+            key = (id(indptr), id(indices), id(va), id(vm))
+            held = getattr(EllRowsMatrix._tls, 'stripped', None)
+            if held is None or held[0] != key:
+                rows_of = np.repeat(np.arange(n), np.diff(indptr))
+                on = indices == rows_of
+                assert np.array_equal(np.bincount(rows_of[on], minlength=n),
+                                      np.ones(n, dtype=np.int64)), 'matrix lacks a diagonal entry'
+                off = ~on
+                ptr = np.concatenate([[0], np.cumsum(np.bincount(
+                    rows_of[off], minlength=n))]).astype(np.int32)
+                held = (key, (ptr, indices[off], va[off],
+                              None if vm is None else vm[off],
+                              (va[on], None if vm is None else vm[on])),
+                        (indptr, indices, va, vm))
+                EllRowsMatrix._tls.stripped = held
+            indptr, indices, va, vm, dia_values = held[1]
         counts_all = np.diff(indptr)
         order = np.arange(n, dtype=np.int64) if order is None else np.asarray(
             order, dtype=np.int64)
@@ -265,19 +287,11 @@ class EllRowsMatrix:
             self.dia_a = _lib.to_dev(np.asarray(dia_values[0])[order])
             if dia_values[1] is not None:
                 self.dia_m = _lib.to_dev(np.asarray(dia_values[1])[order])
-        elif diag:
-            rows_of = np.repeat(np.arange(n), counts_all)
-            on = np.flatnonzero(indices == rows_of)
-            dpos = np.full(n, -1, dtype=np.int64)
-            dpos[rows_of[on]] = on
-            assert (dpos[order] >= 0).all(), 'matrix lacks a diagonal entry'
-            self.dia_a = _lib.to_dev(va[dpos[order]])
-            if vm is not None:
-                self.dia_m = _lib.to_dev(vm[dpos[order]])
         self.struct = _lib.EllRows(npos, n, K, _lib.ptr(self.idx),
                                    _lib.ptr(self.va), _lib.ptr(self.vm),
                                    _lib.ptr(self.row_ids),
-                                   _lib.ptr(self.dia_a), _lib.ptr(self.dia_m))
+                                   _lib.ptr(self.dia_a), _lib.ptr(self.dia_m),
+                                   int(diag))
 
 
 class EllMatrices:
