@@ -549,10 +549,12 @@ def test_coarse_subcycle_variants_agree(stk):
 # exists, so that the figure quoted in DESIGN.md section 5 has a source).
 # Measured (gpurun_out/parity_history_dev.json, round 2): iteration counts equal
 # everywhere; every r.Pr within 5e-11 of the oracle's at J_time = 3 / J_space = 6,
-# within 4.3e-10 at the sizes of configs 2-4.  The deviation starts at 1e-15 in the
+# within 4.7e-10 at the sizes of configs 2-4.  The deviation starts at 1e-15 in the
 # first iterations and roughly triples per iteration: CG turns last-bit
 # differences (order of additions in dot products and in the regrouped Schur
-# complement) into differences of alpha and beta.  1e-10 on the LAST entries,
+# complement, the Gauss-Seidel update written as (f_i - sum_{j != i}) / a_ii like
+# PETSc's MatSOR instead of u_i += (f_i - sum_j) / a_ii) into differences of alpha
+# and beta.  1e-10 on the LAST entries,
 # which are 1e-13 of the first, would need bit-identical arithmetic; what is
 # asserted is 1e-9 on every entry relative to itself and 1e-10 relative to the
 # initial residual.  The latter is set by the FIRST entry r0.P r0: 3e-13 at
