@@ -434,3 +434,62 @@ def test_coupling_bands_property(name, J):
             if coords is not None and n > 8:
                 # as thin as the mesh rows on these structured meshes
                 assert band.max() + 1 == len(np.unique(np.round(coords[:n, -1], 12)))
+
+
+def test_row_grouping_of_the_packed_kronecker_form():
+    """stk_pack_group_rows (host code of libstk, no device): rows that follow each
+    other are grouped greedily into units of up to rp rows whose union of columns
+    fits K_out slots.  Checked on random banded patterns against the definition:
+    every row in exactly one unit, in order; union columns ascending and complete;
+    every code where its row has the column, the zero code elsewhere; a unit ends
+    only because it is full, the next row would not fit, or the rows ran out."""
+    from source import _lib
+    lib = _lib.lib()
+    assert lib.stk_pack_unit_slots(7, 2) == 10 and lib.stk_pack_unit_slots(5, 2) == 8
+    assert lib.stk_pack_unit_slots(7, 1) == 7 and lib.stk_pack_unit_slots(16, 2) == 0
+    rng = np.random.RandomState(5)
+    for case in range(30):
+        M = int(rng.randint(1, 300))
+        K = int(rng.choice([3, 5, 7]))
+        rp = int(rng.randint(1, 5))
+        K_out = int(rng.randint(K, 2 * K + 2))
+        counts = rng.randint(0, K + 1, size=M).astype(np.int32)
+        cols = np.zeros((M, K), dtype=np.int32)
+        codes = np.zeros((M, K), dtype=np.int32)
+        zero = 99
+        rows = []
+        for p in range(M):
+            lo = max(0, p - 4)
+            c = np.sort(rng.choice(np.arange(lo, lo + 12), size=counts[p], replace=False))
+            cols[p, :counts[p]] = c
+            codes[p, :counts[p]] = rng.randint(0, 50, size=counts[p])
+            rows.append(dict(zip(c.tolist(), codes[p, :counts[p]].tolist())))
+        own = rng.permutation(M).astype(np.int32)
+        ucols = np.full((M, K_out), -7, dtype=np.int32)
+        ucodes = np.full((M, K_out, rp), -7, dtype=np.int32)
+        urows = np.full((M, rp), -7, dtype=np.int32)
+        n_units = ctypes.c_int32()
+        _lib.check(lib.stk_pack_group_rows(M, K, counts.ctypes.data, cols.ctypes.data, codes.ctypes.data,
+                                           own.ctypes.data, zero, rp, K_out, ctypes.byref(n_units),
+                                           ucols.ctypes.data, ucodes.ctypes.data, urows.ctypes.data))
+        pos = 0
+        for u in range(n_units.value):
+            members = [r for r in urows[u] if r >= 0]
+            n = len(members)
+            assert 1 <= n <= rp and list(urows[u, n:]) == [-1] * (rp - n)
+            assert members == own[pos:pos + n].tolist()  # every row once, in order
+            union = sorted(set().union(*[rows[pos + j].keys() for j in range(n)]))
+            assert len(union) <= K_out
+            assert ucols[u, :len(union)].tolist() == union
+            assert (ucols[u, len(union):] == own[pos]).all()  # unused slots: first row's own column
+            for e in range(K_out):
+                for j in range(rp):
+                    want = rows[pos + j].get(int(ucols[u, e]), zero) if (j < n and e < len(union)) else zero
+                    assert ucodes[u, e, j] == want, (case, u, e, j)
+            if n < rp and pos + n < M:  # greedy: the next row did not fit
+                assert len(set(union) | set(rows[pos + n].keys())) > K_out
+            pos += n
+        assert pos == M
+    # argument errors are reported, not executed
+    assert lib.stk_pack_group_rows(4, 7, None, None, None, None, 0, 2, 10, None, None, None, None) != 0
+    assert b'stk_pack_group_rows' in lib.stk_last_error()
