@@ -17,6 +17,7 @@ heateq_mpi.py:97-98, 147-153).  A family stores A and M hierarchies once and
 applies all members in one batched V-cycle with a per-time-slice coefficient.
 """
 import ctypes
+import threading
 
 import numpy as np
 import scipy.sparse as sp
@@ -144,8 +145,13 @@ class _DeviceHierarchy:
         self.shape = A[-1].shape
         self._keep = []  # device tensors / host arrays the plan points into
         self.levels = (_lib.MGLevel * (self.J + 1))()
-        for j in range(self.J + 1):
-            self._fill_level(j, hierarchy)
+        # the levels are independent host work (NumPy / SciPy release the GIL):
+        # finest first, side by side
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=3) as pool:
+            for done in [pool.submit(self._fill_level, j, hierarchy)
+                         for j in reversed(range(self.J + 1))]:
+                done.result()
         inv = np.stack([np.linalg.inv(np.asarray(m.todense()))
                         for m in coarse_mats(A[0], Mm[0] if Mm else None)])
         self.coarse_inv = _lib.to_dev(np.ascontiguousarray(inv))
@@ -185,6 +191,12 @@ class _DeviceHierarchy:
             band = coupling_bands(hierarchy.coords, indptr, indices)
             key = rank if band is None else band * np.int64(n) + rank
             vm = vals[1] if self.has_m else None
+            # transfer operators and the restricted-residual product R A: independent
+            # of the sweeps' copies, built beside them
+            moved = {}
+            transfers = threading.Thread(
+                target=self._transfer_ells, args=(j, hierarchy, mats, tile, moved))
+            transfers.start()
             ells = {'a': EllRowsMatrix(indptr, indices, vals[0], vm, tile)}
             for name, bw in (('fwd', False), ('bwd', True)):
                 ptr, rows = gauss_seidel_schedule(indptr, indices, bw)
@@ -214,29 +226,14 @@ class _DeviceHierarchy:
                         ptr.ctypes.data_as(ctypes.c_void_p))
                 if not bw:
                     fwd_groups = groups
-            P = sp.csr_matrix(hierarchy.P_mats[j - 1])
-            R = sp.csr_matrix(hierarchy.R_mats[j - 1])
-            nc = P.shape[1]
-            if hierarchy.coords is not None:
-                tile_c = tile_order_from_coords(hierarchy.coords[:nc])
-            else:
-                tile_c = np.arange(nc, dtype=np.int32)
-            for name, m, order in (('p', P, tile), ('r', R, tile_c)):
-                m.sort_indices()
-                dev[name + '_indptr'] = _lib.to_dev(m.indptr.astype(np.int32))
-                dev[name + '_indices'] = _lib.to_dev(
-                    m.indices.astype(np.int32))
-                dev[name + '_vals'] = _lib.to_dev(m.data.astype(np.float64))
-                ells[name] = EllRowsMatrix(m.indptr, m.indices, m.data, None,
-                                           order)
+            transfers.join()
+            if 'error' in moved:
+                raise moved['error']
+            dev.update(moved['dev'])
+            ells.update(moved['ells'])
             if all(e.ok for e in ells.values()):
-                # restricted residual in one step: d = (R A) u - R f
-                prods = [_drop_roundoff(sp.csr_matrix(R @ m)) for m in mats]
-                ra_ptr, ra_idx, ra_vals = union_pattern(prods)
-                ra = EllRowsMatrix(ra_ptr, ra_idx, ra_vals[0],
-                                   ra_vals[1] if self.has_m else None, tile_c)
-                if ra.ok:
-                    ells['ra'] = ra
+                if moved['ra'].ok:
+                    ells['ra'] = moved['ra']
                 for name, e in ells.items():
                     setattr(L, 'ell_' + name, ctypes.pointer(e.struct))
                 host['ells'] = ells
@@ -247,6 +244,32 @@ class _DeviceHierarchy:
         self._keep.append((dev, host))
         if j == self.J:
             self.groups_fwd = len(host['fwd_ptr']) - 1 if j > 0 else 0
+
+    def _transfer_ells(self, j, hierarchy, mats, tile, out):
+        """P, R of level j (CSR on the device + ELL copies) and the product R A
+        (restricted residual in one step: d = (R A) u - R f); results into `out`."""
+        try:
+            P = sp.csr_matrix(hierarchy.P_mats[j - 1])
+            R = sp.csr_matrix(hierarchy.R_mats[j - 1])
+            nc = P.shape[1]
+            if hierarchy.coords is not None:
+                tile_c = tile_order_from_coords(hierarchy.coords[:nc])
+            else:
+                tile_c = np.arange(nc, dtype=np.int32)
+            dev, ells = {}, {}
+            for name, m, order in (('p', P, tile), ('r', R, tile_c)):
+                m.sort_indices()
+                dev[name + '_indptr'] = _lib.to_dev(m.indptr.astype(np.int32))
+                dev[name + '_indices'] = _lib.to_dev(m.indices.astype(np.int32))
+                dev[name + '_vals'] = _lib.to_dev(m.data.astype(np.float64))
+                ells[name] = EllRowsMatrix(m.indptr, m.indices, m.data, None, order)
+            prods = [_drop_roundoff(sp.csr_matrix(R @ m)) for m in mats]
+            ra_ptr, ra_idx, ra_vals = union_pattern(prods)
+            out['ra'] = EllRowsMatrix(ra_ptr, ra_idx, ra_vals[0],
+                                      ra_vals[1] if self.has_m else None, tile_c)
+            out['dev'], out['ells'] = dev, ells
+        except Exception as exc:  # re-raised by the level's thread
+            out['error'] = exc
 
     def _zero_start_ells(self, L, host, indptr, indices, va, vm, diag,
                          groups):
