@@ -192,15 +192,27 @@ def space_matrices(mesh):
     K = np.matmul(g, np.swapaxes(g, 1, 2)) * vol[:, None, None]
     Mloc = (np.ones((nl, nl)) + np.eye(nl)) / (nl * (nl + 1.0))
     Mv = vol[:, None, None] * Mloc[None]
-    A = sp.coo_matrix((K.reshape(-1), (rows, cols)), shape=(nv, nv)).tocsr()
-    M = sp.coo_matrix((Mv.reshape(-1), (rows, cols)), shape=(nv, nv)).tocsr()
-    # the three-direction mesh (Kuhn mesh in 3-D) yields exact zeros on the
-    # diagonal edges only up to rounding; drop what is numerically zero, as
-    # eliminate_zeros would for NGSolve's exactly integrated entries
-    A.data[np.abs(A.data) < 1e-14 * np.abs(A.data).max()] = 0.0
     fd = free_dofs(mesh)
-    M, A = _restrict(M, fd), _restrict(A, fd)
-    M.stk_row_order = A.stk_row_order = tile_row_order(mesh)
+
+    def stiffness():
+        A = sp.coo_matrix((K.reshape(-1), (rows, cols)), shape=(nv, nv)).tocsr()
+        # the three-direction mesh (Kuhn mesh in 3-D) yields exact zeros on the
+        # diagonal edges only up to rounding; drop what is numerically zero, as
+        # eliminate_zeros would for NGSolve's exactly integrated entries
+        A.data[np.abs(A.data) < 1e-14 * np.abs(A.data).max()] = 0.0
+        return _restrict(A, fd)
+
+    def mass():
+        M = sp.coo_matrix((Mv.reshape(-1), (rows, cols)), shape=(nv, nv)).tocsr()
+        return _restrict(M, fd)
+
+    # two independent sparse assemblies and the processing order: side by side
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=3) as pool:
+        A, M, order = (pool.submit(stiffness), pool.submit(mass),
+                       pool.submit(tile_row_order, mesh))
+        A, M, order = A.result(), M.result(), order.result()
+    M.stk_row_order = A.stk_row_order = order
     return M, A
 
 
