@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel sums and averages of rocprofv3 --pmc counter CSVs (one directory
-per pass, as written by tools/pmc_passes.sh / pmc_kron.sh)."""
+per pass, as written by tools/pmc_passes.sh)."""
 import csv
 import glob
 import sys
