@@ -1114,9 +1114,12 @@ def test_kron_pack_row_pairs(stk):
     band = sp.diags([rng.choice([1.0, -2.0, 0.5], size=n - abs(o)) for o in (-17, -1, 0, 1, 17)],
                     (-17, -1, 0, 1, 17), format='csr')
     families.append(('band5', [band, sp.csr_matrix(band.T), sp.csr_matrix(band + band.T)]))
+    offs9 = (-18, -17, -16, -1, 0, 1, 16, 17, 18)  # 9-point stencil: pairs of 12 slots
+    nine = sp.diags([rng.choice([1.0, -2.0, 0.5, 3.0], size=n - abs(o)) for o in offs9], offs9, format='csr')
+    families.append(('nine', [nine, sp.csr_matrix(nine.T), sp.csr_matrix(nine + 2.0 * nine.T)]))
     seen_pairs = 0
     for name, mats_all in families:
-        for n_loc in (1, 2, 8, 9, 17, 33):
+        for n_loc in (1, 2, 8, 9, 17, 33, 65, 129):
             nt = int(rng.randint(1, 4))
             mats = mats_all[:nt]
             ell = EllMatrices(mats, [mats_all[0]])
@@ -1124,7 +1127,7 @@ def test_kron_pack_row_pairs(stk):
             assert one.ok and one.rows_per_unit == 1
             assert two.ok and two.rows_per_unit == 2, (name, two.ok)
             M = ell.M
-            assert two.n_units < 0.7 * M and two.K in (8, 10)
+            assert two.n_units < 0.7 * M and two.K in (8, 10, 12)
             seen_pairs += M - two.n_units
             ld = n_loc + (n_loc & 1)
             X = rng.rand(M, n_loc)
