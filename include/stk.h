@@ -47,6 +47,21 @@ int stk_device_info(int32_t *n_cu, int32_t *wave_size, int64_t *hbm_bytes);
  * or 256 / 512 / 1024 threads per workgroup).  Results never depend on them. */
 int stk_set_tuning(const char *key, int32_t value);
 
+/* ---- time slices of a slab (BlockDiagMPI._matvec with different operators per
+ *      slice, mpi_kron.py:126-131: every distinct operator gets the slices it owns
+ *      as one slab) --------------------------------------------------------------
+ * gather:  y[i*ld_y + k] = x[i*ld_x + cols[k]], k < n_cols; the padding columns
+ *          n_cols .. ld_y-1 of y are written as zero.
+ * scatter: y[i*ld_y + cols[k]] = x[i*ld_x + k], k < n_cols; other columns of y
+ *          are left alone.  cols: device int32; the caller guarantees that they
+ *          are valid, distinct columns of the wider slab. */
+int stk_slab_gather_columns(void *stream, int32_t M, int32_t n_cols,
+                            const int32_t *cols, const double *x, int32_t ld_x,
+                            double *y, int32_t ld_y);
+int stk_slab_scatter_columns(void *stream, int32_t M, int32_t n_cols,
+                             const int32_t *cols, const double *x, int32_t ld_x,
+                             double *y, int32_t ld_y);
+
 /* ---- BLAS-1 on flat arrays (KronVectorMPI arithmetic, mpi_vector.py:84-122,
  *      and dot, mpi_vector.py:205-210, local part) -------------------------- */
 /* y = a * x + b * y   (b == 0 ignores the old y; x == y allowed) */

@@ -83,7 +83,53 @@ __global__ __launch_bounds__(1024) void dot_final_kernel(int n_partial, const do
     if (threadIdx.x == 0) out[0] = r;
 }
 
+// Time slices of a slab: y[i][k] = x[i][cols[k]] (gather; columns k >= n_cols of y,
+// its padding, are written as zero) or y[i][cols[k]] = x[i][k] (scatter).
+__global__ __launch_bounds__(BS) void slab_columns_kernel(int64_t total, int32_t n_cols, int32_t width,
+                                                           const int32_t *__restrict__ cols,
+                                                           const double *__restrict__ x, int32_t ld_x, double *y,
+                                                           int32_t ld_y, int scatter)
+{
+    const int64_t stride = (int64_t)gridDim.x * BS;
+    for (int64_t idx = (int64_t)blockIdx.x * BS + threadIdx.x; idx < total; idx += stride) {
+        const int64_t i = idx / width;
+        const int k = (int)(idx - i * width);
+        if (scatter)
+            y[i * ld_y + cols[k]] = x[i * ld_x + k];
+        else
+            y[i * ld_y + k] = k < n_cols ? x[i * ld_x + cols[k]] : 0.0;
+    }
+}
+
 }  // namespace
+
+extern "C" int stk_slab_gather_columns(void *stream, int32_t M, int32_t n_cols, const int32_t *cols,
+                                       const double *x, int32_t ld_x, double *y, int32_t ld_y)
+{
+    const stk_timed timed_(STK_OP_BLAS1, stream);
+    STK_REQUIRE(M > 0 && n_cols > 0 && cols && x && y && x != y, "stk_slab_gather_columns: bad arguments");
+    STK_REQUIRE(ld_y >= n_cols && ld_x >= 1, "stk_slab_gather_columns: ld_y=%d is smaller than n_cols=%d", ld_y,
+                n_cols);
+    const int64_t total = (int64_t)M * ld_y;
+    hipLaunchKernelGGL(slab_columns_kernel, dim3(stk_flat_grid(total, BS)), dim3(BS), 0, stk_stream(stream), total,
+                       n_cols, ld_y, cols, x, ld_x, y, ld_y, 0);
+    STK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int stk_slab_scatter_columns(void *stream, int32_t M, int32_t n_cols, const int32_t *cols,
+                                        const double *x, int32_t ld_x, double *y, int32_t ld_y)
+{
+    const stk_timed timed_(STK_OP_BLAS1, stream);
+    STK_REQUIRE(M > 0 && n_cols > 0 && cols && x && y && x != y, "stk_slab_scatter_columns: bad arguments");
+    STK_REQUIRE(ld_x >= n_cols && ld_y >= 1, "stk_slab_scatter_columns: ld_x=%d is smaller than n_cols=%d", ld_x,
+                n_cols);
+    const int64_t total = (int64_t)M * n_cols;
+    hipLaunchKernelGGL(slab_columns_kernel, dim3(stk_flat_grid(total, BS)), dim3(BS), 0, stk_stream(stream), total,
+                       n_cols, n_cols, cols, x, ld_x, y, ld_y, 1);
+    STK_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int stk_axpbyz(void *stream, int64_t n, double a, const double *x, double b, const double *y,
                           double *z)

@@ -96,6 +96,8 @@ _PROTOTYPES = {
         c_p, c_i64, OPERATOR_FN, c_p, OPERATOR_FN, c_p, ALLREDUCE_FN, c_p, c_p,
         c_p, c_f64, c_i32, c_p, c_p, c_p
     ]),
+    'stk_slab_gather_columns': (ctypes.c_int, [c_p, c_i32, c_i32, c_p, c_p, c_i32, c_p, c_i32]),
+    'stk_slab_scatter_columns': (ctypes.c_int, [c_p, c_i32, c_i32, c_p, c_p, c_i32, c_p, c_i32]),
     'stk_timing_enable': (ctypes.c_int, [c_i32]),
     'stk_timing_reset': (ctypes.c_int, []),
     'stk_timing_get': (ctypes.c_int, [ctypes.c_char_p, c_p, c_p]),

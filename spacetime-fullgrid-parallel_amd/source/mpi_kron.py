@@ -206,6 +206,7 @@ class BlockDiagMPI(LinearOperatorMPI):
         super().__init__(dofs_distr)
         self._local = self.matrices_space[dofs_distr.t_begin:dofs_distr.t_end]
         self._batched = self._try_batch()
+        self._groups = None  # general case: (operator, slice count, slice indices on the device)
 
     def _try_batch(self):
         from .linop import CompositeLinOp
@@ -249,14 +250,23 @@ class BlockDiagMPI(LinearOperatorMPI):
             # general case: the time slices of every distinct operator object
             # together (one slice at a time if all operators differ)
             vec_out.buf.zero_()
-            groups = {}
-            for t_loc, linop in enumerate(self._local):
-                groups.setdefault(id(linop), (linop, []))[1].append(t_loc)
-            for linop, cols in groups.values():
-                idx = torch.tensor(cols, device=vec_in.buf.device)
-                xin = vec_in.buf.index_select(1, idx).contiguous()
-                res = linop.apply(xin, n_loc=len(cols))
-                vec_out.buf.index_copy_(1, idx, res[:, :len(cols)])
+            if self._groups is None:
+                groups = {}
+                for t_loc, linop in enumerate(self._local):
+                    groups.setdefault(id(linop), (linop, []))[1].append(t_loc)
+                self._groups = [(linop, len(cols), _lib.to_dev(np.asarray(cols, dtype=np.int32)))
+                                for linop, cols in groups.values()]
+            lib, M, ld = _lib.lib(), vec_in.M, vec_in.ld
+            for linop, n_cols, cols in self._groups:
+                width = n_cols + (n_cols & 1)
+                xin = torch.empty((M, width), dtype=torch.float64, device=vec_in.buf.device)
+                _lib.check(lib.stk_slab_gather_columns(
+                    _lib.stream(), M, n_cols, _lib.ptr(cols), _lib.ptr(vec_in.buf), ld,
+                    _lib.ptr(xin), width))
+                res = linop.apply(xin, n_loc=n_cols)
+                _lib.check(lib.stk_slab_scatter_columns(
+                    _lib.stream(), M, n_cols, _lib.ptr(cols), _lib.ptr(res), res.shape[1],
+                    _lib.ptr(vec_out.buf), ld))
         vec_out.communicated_bdr = False
         return vec_out
 
