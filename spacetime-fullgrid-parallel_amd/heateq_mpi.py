@@ -251,9 +251,13 @@ class HeatEquationMPI:
 
         # -- RHS -- (heateq_mpi.py:188-191)
         self.rhs = KronVectorMPI(dd)
-        self.rhs.X_loc[:] = torch.from_numpy(
-            np.kron(self.u0_t[self.rhs.t_begin:self.rhs.t_end],
-                    self.u0_x).reshape(-1, self.M)).to(self.rhs.buf.device)
+        dev = self.rhs.buf.device
+        # u0_t kron u0_x, formed on the device: one product per entry, the same
+        # doubles as np.kron on the host
+        self.rhs.X_loc[:] = torch.outer(
+            torch.from_numpy(np.ascontiguousarray(
+                self.u0_t[self.rhs.t_begin:self.rhs.t_end])).to(dev),
+            torch.from_numpy(np.ascontiguousarray(self.u0_x)).to(dev))
 
         self.setup_time = MPI.Wtime() - start_time
         self.mem_after_mpi = mem()
