@@ -218,6 +218,31 @@ def sp_union(a, m):
     return u
 
 
+def profiler_preloaded():
+    """True under rocprofv3 / rocprof: their preloaded tool library initialises
+    the GPU before the program starts (it does with --pmc)."""
+    pre = os.environ.get('LD_PRELOAD', '')
+    return ('rocprof' in pre or 'roctracer' in pre
+            or any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ))
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: N ranks as child processes
+    of torch.distributed.run on 127.0.0.1, a free port; returns their exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -235,6 +260,14 @@ def main():
                     help='seconds of untimed applies before the warm-up steps')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        # started as plain `python bench.py --gpus N` (the reference's protocol is
+        # `mpirun -np N`, README.md:26-31): start the N ranks ourselves, one
+        # process per GPU, as children under torch.distributed.run -- before this
+        # process has touched the GPU, and never by exec.  Rank 0's JSON line
+        # arrives on the inherited stdout.
+        sys.exit(spawn_ranks(args.gpus))
+
     from source.assembly import space_matrices, time_matrices
     from source.problem import problem_helper
 
@@ -248,6 +281,11 @@ def main():
     # CPU baseline first: nothing has touched the GPU yet, so its process pool
     # can fork (rank 0 of a one-GPU run only)
     cpu = None
+    if profiler_preloaded() and not args.no_cpu_baseline:
+        # a profiler's preloaded library has initialised the GPU before main():
+        # forking the baseline's process pool from here is not allowed
+        args.no_cpu_baseline = True
+        print('bench.py: profiler preload detected, CPU baseline skipped', file=sys.stderr)
     if (int(os.environ.get('RANK', '0')) == 0 and args.gpus == 1
             and int(os.environ.get('WORLD_SIZE', '1')) == 1 and not args.no_cpu_baseline):
         nb = 16 * N * M + 12 * (M_x.nnz + A_x.nnz) + 8 * (M + 1)

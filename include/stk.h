@@ -62,6 +62,52 @@ int stk_slab_scatter_columns(void *stream, int32_t M, int32_t n_cols,
                              const int32_t *cols, const double *x, int32_t ld_x,
                              double *y, int32_t ld_y);
 
+/* ---- slab storage for hosts that own no device allocator (KronVectorMPI.__init__
+ *      / reset, mpi_vector.py:62-71; scatter / gather, :124-138) ------------------
+ * stk_slab_alloc: a zeroed slab of M rows with leading dimension *ld =
+ * stk_slab_ld(n_loc) (n_loc rounded up to even: time pairs are 16-byte aligned).
+ * upload / download move the reference's time-major host block X_loc[t][i],
+ * (n_loc, M) C order, to / from the space-major slab (a transpose on the device
+ * through a staging buffer; padding columns are written as zero).  These two
+ * calls block until the transfer is complete. */
+int stk_slab_ld(int32_t n_loc);
+int stk_slab_alloc(int32_t M, int32_t n_loc, int32_t *ld, double **slab);
+int stk_slab_free(double *slab);
+int stk_slab_upload(void *stream, int32_t M, int32_t n_loc, int32_t ld,
+                    const double *x_host, double *slab);
+int stk_slab_download(void *stream, int32_t M, int32_t n_loc, int32_t ld,
+                      const double *slab, double *x_host);
+/* dst[c * ld_dst + r] = src[r * ld_src + c] for r < rows, c < cols (device to
+ * device, tiled through LDS); the columns rows .. zero_to-1 of dst are written
+ * as zero (0: none).  Time-major block <-> slab, and the block transposes of
+ * KronVectorMPI.permute (mpi_vector.py:212-240). */
+int stk_transpose(void *stream, int32_t rows, int32_t cols, const double *src,
+                  int64_t ld_src, double *dst, int64_t ld_dst, int32_t zero_to);
+/* The two time rows a slab sends to its neighbour ranks in communicate_bdr
+ * (mpi_vector.py:148-167): first[j * stride_first] = x[j][0], last[j *
+ * stride_last] = x[j][n_loc-1], both from one pass over the slab's lines.
+ * Stride 1: contiguous send buffers; stride 2: every other double of an
+ * interleaved ghost buffer gh[j] = (lo, hi) (stk_kron_pack_apply), e.g. the
+ * neighbour's own buffer mapped into this process.  Either pointer may be NULL. */
+int stk_halo_pack(void *stream, int32_t M, int32_t n_loc, int32_t ld,
+                  const double *x, double *first, int32_t stride_first,
+                  double *last, int32_t stride_last);
+/* out[k * ld_out + j] = x[j][t_idx[k]], k < n_rows: the time rows communicate_dofs
+ * sends (mpi_vector.py:189-203), all from one pass over the slab.  t_idx: device
+ * int32, valid local time indices. */
+int stk_slab_extract_time_rows(void *stream, int32_t M, int32_t n_rows,
+                               const int32_t *t_idx, const double *x, int32_t ld,
+                               double *out, int64_t ld_out);
+/* dst[r * ld_dst + c] = src[r * ld_src + c], r < rows, c < cols: a block of rows
+ * moved to another leading dimension (the pieces of the all-to-all transposes of
+ * KronVectorMPI.permute and of the distributed wavelet transform). */
+int stk_copy_block(void *stream, int64_t rows, int32_t cols, const double *src,
+                   int64_t ld_src, double *dst, int64_t ld_dst);
+/* y[i * ld + t] = u_t[t] * u_x[i] (padding zero): the right-hand side
+ * u0_t kron u0_x of heateq_mpi.py:189-191 formed on the device. */
+int stk_outer(void *stream, int32_t M, int32_t n_loc, int32_t ld,
+              const double *u_t, const double *u_x, double *y);
+
 /* ---- BLAS-1 on flat arrays (KronVectorMPI arithmetic, mpi_vector.py:84-122,
  *      and dot, mpi_vector.py:205-210, local part) -------------------------- */
 /* y = a * x + b * y   (b == 0 ignores the old y; x == y allowed) */

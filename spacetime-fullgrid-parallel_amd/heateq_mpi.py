@@ -140,7 +140,18 @@ class HeatEquationMPI:
     through MPI-3 windows, which has no meaning across HBMs).
 
     schur='fused' (default) builds S as SchurMPI; schur='reference' builds the
-    five-term SumMPI exactly as reference heateq_mpi.py:166-181."""
+    five-term SumMPI exactly as reference heateq_mpi.py:166-181.
+
+    family='batched' (default) applies the preconditioner's multigrids for
+    2^j M_x + alpha A_x, all j, as one batched V-cycle over a shared pair of
+    hierarchies; family='reference' builds one MultiGrid per j from the assembled
+    matrix, as reference heateq_mpi.py:147-153 does.
+
+    arithmetic='reference' = schur='reference' + family='reference' + Gauss-Seidel
+    rows with their diagonal (u_i += (f_i - row_i u) / a_ii, multigrid.py:89-97):
+    every regrouping this build adds is switched off, what remains against the
+    CPU path is the order of additions inside dot products and fused multiply-adds
+    (DESIGN.md section 5)."""
     def __init__(self,
                  J_space=2,
                  J_time=None,
@@ -151,9 +162,15 @@ class HeatEquationMPI:
                  alpha=0.3,
                  vcycles=2,
                  schur='fused',
+                 family='batched',
+                 arithmetic='fast',
                  comm=None):
         start_time = MPI.Wtime()
         comm = MPI.COMM_WORLD if comm is None else comm
+        assert arithmetic in ('fast', 'reference')
+        if arithmetic == 'reference':
+            schur = family = 'reference'
+        self.arithmetic = arithmetic
         if J_time is None:
             J_time = J_space
         self.J_time = J_time
@@ -192,20 +209,38 @@ class HeatEquationMPI:
         # ---- Preconditioners in space ---- (heateq_mpi.py:141-162)
         hierarchy = MeshHierarchy(mesh_space)
         self.hierarchy = hierarchy
-        if precond == 'multigrid':
+        from source import multigrid as _mg
+        gs_form = _mg.GS_DIAG_FREE
+        if arithmetic == 'reference':
+            _mg.GS_DIAG_FREE = False
+        if precond == 'multigrid' and family == 'reference':
+            # one hierarchy per wavelet level from the assembled matrix
+            # (reference heateq_mpi.py:147-153)
+            self.u0_x = space_load(mesh_space, data['u0'])
+            self.Kinv_x = MultiGrid(self.A_x, hierarchy, smoothsteps=smoothsteps,
+                                    vcycles=vcycles)
+            self.C_family = None
+            self.C_j = [
+                MultiGrid(2**j * self.M_x + alpha * self.A_x, hierarchy,
+                          smoothsteps=smoothsteps, vcycles=vcycles)
+                for j in range(self.J_time + 1)
+            ]
+        elif precond == 'multigrid':
             # the two hierarchies (A_x alone; 2^j M_x + alpha A_x, all j in one
             # family) are independent host work (SciPy / NumPy release the GIL)
             from concurrent.futures import ThreadPoolExecutor
+            # worker threads start on device 0: pin them to this rank's GPU
+            on_dev = _lib.in_device_context
             with ThreadPoolExecutor(max_workers=4) as pool:
                 if schur != 'reference':  # the Kronecker plan S streams: independent of both
                     n_steps = self.dofs_distr.t_end - self.dofs_distr.t_begin
-                    pool.submit(lambda: EllMatrices.shared(
-                        [self.M_x, self.A_x]).packed_for(n_steps))
+                    pool.submit(on_dev(lambda: EllMatrices.shared(
+                        [self.M_x, self.A_x]).packed_for(n_steps)))
                 u0_x = pool.submit(space_load, mesh_space, data['u0'])
-                kinv = pool.submit(MultiGrid, self.A_x, hierarchy,
+                kinv = pool.submit(on_dev(MultiGrid), self.A_x, hierarchy,
                                    smoothsteps=smoothsteps, vcycles=vcycles)
                 family = pool.submit(
-                    MultiGridFamily, self.A_x, self.M_x, hierarchy, ca=alpha,
+                    on_dev(MultiGridFamily), self.A_x, self.M_x, hierarchy, ca=alpha,
                     cms=[2**j for j in range(self.J_time + 1)],
                     smoothsteps=smoothsteps, vcycles=vcycles)
                 self.Kinv_x, self.C_family = kinv.result(), family.result()
@@ -219,6 +254,7 @@ class HeatEquationMPI:
                 InvLinOp(2**j * self.M_x + alpha * self.A_x)
                 for j in range(self.J_time + 1)
             ]
+        _mg.GS_DIAG_FREE = gs_form
         self.CAC_j = [
             CompositeLinOp([self.C_j[j], self.A_x, self.C_j[j]])
             for j in range(self.J_time + 1)
@@ -251,13 +287,13 @@ class HeatEquationMPI:
 
         # -- RHS -- (heateq_mpi.py:188-191)
         self.rhs = KronVectorMPI(dd)
-        dev = self.rhs.buf.device
-        # u0_t kron u0_x, formed on the device: one product per entry, the same
-        # doubles as np.kron on the host
-        self.rhs.X_loc[:] = torch.outer(
-            torch.from_numpy(np.ascontiguousarray(
-                self.u0_t[self.rhs.t_begin:self.rhs.t_end])).to(dev),
-            torch.from_numpy(np.ascontiguousarray(self.u0_x)).to(dev))
+        # u0_t kron u0_x, formed on the device (stk_outer): one product per entry,
+        # the same doubles as np.kron on the host
+        u_t = _lib.to_dev(self.u0_t[self.rhs.t_begin:self.rhs.t_end])
+        u_x = _lib.to_dev(self.u0_x)
+        _lib.check(_lib.lib().stk_outer(
+            _lib.stream(), self.M, self.rhs.n_loc, self.rhs.ld, _lib.ptr(u_t),
+            _lib.ptr(u_x), _lib.ptr(self.rhs.buf)))
 
         self.setup_time = MPI.Wtime() - start_time
         self.mem_after_mpi = mem()

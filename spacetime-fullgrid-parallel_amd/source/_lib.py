@@ -98,6 +98,16 @@ _PROTOTYPES = {
     ]),
     'stk_slab_gather_columns': (ctypes.c_int, [c_p, c_i32, c_i32, c_p, c_p, c_i32, c_p, c_i32]),
     'stk_slab_scatter_columns': (ctypes.c_int, [c_p, c_i32, c_i32, c_p, c_p, c_i32, c_p, c_i32]),
+    'stk_slab_ld': (ctypes.c_int, [c_i32]),
+    'stk_slab_alloc': (ctypes.c_int, [c_i32, c_i32, c_p, c_p]),
+    'stk_slab_free': (ctypes.c_int, [c_p]),
+    'stk_slab_upload': (ctypes.c_int, [c_p, c_i32, c_i32, c_i32, c_p, c_p]),
+    'stk_slab_download': (ctypes.c_int, [c_p, c_i32, c_i32, c_i32, c_p, c_p]),
+    'stk_transpose': (ctypes.c_int, [c_p, c_i32, c_i32, c_p, c_i64, c_p, c_i64, c_i32]),
+    'stk_halo_pack': (ctypes.c_int, [c_p, c_i32, c_i32, c_i32, c_p, c_p, c_i32, c_p, c_i32]),
+    'stk_slab_extract_time_rows': (ctypes.c_int, [c_p, c_i32, c_i32, c_p, c_p, c_i32, c_p, c_i64]),
+    'stk_copy_block': (ctypes.c_int, [c_p, c_i64, c_i32, c_p, c_i64, c_p, c_i64]),
+    'stk_outer': (ctypes.c_int, [c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p]),
     'stk_timing_enable': (ctypes.c_int, [c_i32]),
     'stk_timing_reset': (ctypes.c_int, []),
     'stk_timing_get': (ctypes.c_int, [ctypes.c_char_p, c_p, c_p]),
@@ -212,20 +222,56 @@ def stream():
 
 
 def ptr(t):
-    """Device pointer of a tensor (None -> NULL).  Refuses host tensors."""
+    """Device pointer of a tensor (None -> NULL).  Refuses host tensors and
+    tensors of another GPU than this process's (a kernel of this rank's stream
+    over another rank's memory is a peer access at best, a fault at worst)."""
     if t is None:
         return None
     if not t.is_cuda:
         raise StkError('libstk kernels need device tensors; got a %s tensor '
                        '(no GPU visible? there is no CPU fallback)' % t.device)
+    if _process_device is not None and t.device.index != _process_device:
+        raise StkError('tensor lives on cuda:%d but this process computes on '
+                       'cuda:%d' % (t.device.index, _process_device))
     return t.data_ptr()
 
 
-def compute_device():
-    """Device the slab of this process lives on."""
+# The GPU of this process, fixed ONCE (comm.init_from_env, or the first use):
+# torch.cuda.current_device() is thread-local and a new thread starts on device
+# 0, so plans built in worker threads (heateq_mpi.py, multigrid.py) would
+# otherwise be uploaded to cuda:0 on every rank.
+_process_device = None
+
+
+def set_process_device(index):
+    """Pins the device of this process (one process per GPU)."""
+    global _process_device
+    _process_device = int(index)
     if torch.cuda.is_available():
-        return torch.device('cuda', torch.cuda.current_device())
-    return torch.device('cpu')
+        torch.cuda.set_device(_process_device)
+
+
+def compute_device():
+    """Device the slab of this process lives on -- the same answer in every
+    thread."""
+    global _process_device
+    if _process_device is None:
+        if not torch.cuda.is_available():
+            return torch.device('cpu')
+        _process_device = torch.cuda.current_device()
+    return torch.device('cuda', _process_device)
+
+
+def in_device_context(fn):
+    """Wraps a worker-thread body so that the thread's current device (what
+    hipMalloc and torch.cuda.current_stream() see) is the process's."""
+    def run(*args, **kw):
+        dev = compute_device()
+        if dev.type != 'cuda':
+            return fn(*args, **kw)
+        with torch.cuda.device(dev):
+            return fn(*args, **kw)
+    return run
 
 
 def to_dev(array, dtype=None):
@@ -234,6 +280,19 @@ def to_dev(array, dtype=None):
     if dtype is not None:
         t = t.to(dtype)
     return t.to(compute_device())
+
+
+def transpose(src, rows, cols, ld_src, dst, ld_dst, zero_to=0, src_off=0, dst_off=0):
+    """dst[c, r] = src[r, c] on the device (stk_transpose); offsets in doubles."""
+    check(lib().stk_transpose(stream(), rows, cols, ptr(src) + 8 * src_off, ld_src,
+                              ptr(dst) + 8 * dst_off, ld_dst, zero_to))
+
+
+def copy_block(src, rows, cols, ld_src, dst, ld_dst, src_off=0, dst_off=0):
+    """dst[r, c] = src[r, c] between two leading dimensions (stk_copy_block)."""
+    if rows and cols:
+        check(lib().stk_copy_block(stream(), rows, cols, ptr(src) + 8 * src_off, ld_src,
+                                   ptr(dst) + 8 * dst_off, ld_dst))
 
 
 class DeviceCSR:

@@ -120,7 +120,8 @@ class Comm:
 
     def _device(self):
         if dist.get_backend(self.group) == 'nccl':
-            return torch.device('cuda', torch.cuda.current_device())
+            from . import _lib
+            return _lib.compute_device()
         return torch.device('cpu')
 
 
@@ -141,7 +142,8 @@ def init_from_env():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if torch.cuda.is_available():
         # several ranks may share one GPU in tests (STK_BACKEND=gloo)
-        torch.cuda.set_device(
+        from . import _lib
+        _lib.set_process_device(
             int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count())
     force = os.environ.get('STK_FORCE_COLLECTIVES') == '1' and 'RANK' in os.environ
     if (world > 1 or force) and not dist.is_initialized():
@@ -151,7 +153,8 @@ def init_from_env():
             'STK_BACKEND', 'nccl' if torch.cuda.is_available() else 'gloo')
         kw = {}
         if backend == 'nccl':
-            kw['device_id'] = torch.device('cuda', torch.cuda.current_device())
+            from . import _lib
+            kw['device_id'] = _lib.compute_device()
         dist.init_process_group(backend, **kw)
     return Comm()
 

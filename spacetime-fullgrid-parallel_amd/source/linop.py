@@ -111,25 +111,45 @@ class SpaceMatrix(SpaceOp):
         return out
 
 
-class InvLinOp(SpaceMatrix):
+class InvLinOp(SpaceOp):
     """Direct inverse as a space operator (reference linop.py:18-26, used by
     precond='direct', heateq_mpi.py:154-157).  The factorisation is SuperLU on
-    the host at setup, as in the reference; the device then applies the
-    explicit inverse with the same row-gather kernels as any other matrix.
-    Meant for the small systems the reference's tests use it on: the dense
-    inverse needs M^2 doubles."""
+    the host at setup, as in the reference.  Up to MAX_ROWS rows the device
+    applies the explicit inverse with the same row-gather kernels as any other
+    matrix (the sizes the reference's tests use it on: the dense inverse needs
+    M^2 doubles).  Above that the apply is the reference's own: the slab goes to
+    the host (stk_slab_download), SuperLU solves for all time columns at once,
+    and the result comes back (stk_slab_upload) -- slow, PCIe both ways, but
+    size-agnostic like linop.py:24-26."""
     MAX_ROWS = 8192
 
     def __init__(self, mat):
         mat = sp.csc_matrix(mat)
         n = mat.shape[0]
-        if n > self.MAX_ROWS:
-            raise NotImplementedError(
-                'InvLinOp: a dense inverse of %d rows does not fit; use the '
-                'multigrid preconditioner' % n)
-        lu = sp.linalg.splu(mat, options={"SymmetricMode": True},
-                            permc_spec="MMD_AT_PLUS_A")
-        super().__init__(sp.csr_matrix(lu.solve(np.eye(n))))
+        self.shape = mat.shape
+        self.dtype = np.float64
+        self.lu = sp.linalg.splu(mat, options={"SymmetricMode": True},
+                                 permc_spec="MMD_AT_PLUS_A")
+        self._dense = None
+        if n <= self.MAX_ROWS:
+            self._dense = SpaceMatrix(sp.csr_matrix(self.lu.solve(np.eye(n))))
+            self.mat = self._dense.mat
+
+    def apply(self, x, out=None, n_loc=None, **kw):
+        if self._dense is not None:
+            return self._dense.apply(x, out=out, n_loc=n_loc, **kw)
+        M, ld = x.shape
+        n_loc = ld if n_loc is None else n_loc
+        if out is None:
+            out = torch.empty_like(x)
+        lib = _lib.lib()
+        host = np.empty((n_loc, M))
+        _lib.check(lib.stk_slab_download(_lib.stream(), M, n_loc, ld, _lib.ptr(x),
+                                         host.ctypes.data))
+        sol = np.ascontiguousarray(self.lu.solve(np.ascontiguousarray(host.T)).T)
+        _lib.check(lib.stk_slab_upload(_lib.stream(), M, n_loc, ld,
+                                       sol.ctypes.data, _lib.ptr(out)))
+        return out
 
 
 class CompositeLinOp(SpaceOp):

@@ -49,6 +49,43 @@ class DofDistributionMPI:
             self.dof2proc[t_begin:t_end] = p
 
 
+def _fill_slab(buf, n_loc, src):
+    """buf[i, t] = src[t, i] for a time-major (n_loc, M) block `src` (padding
+    columns zero).  On the device: libstk's tiled transpose (stk_transpose); host
+    tensors (the CPU tests of the communication layer) take the torch view."""
+    M, ld = buf.shape
+    if buf.is_cuda:
+        src = src.to(buf.device).contiguous()
+        _lib.transpose(src, n_loc, M, M, buf, ld, zero_to=ld)
+    else:
+        buf[:, :n_loc].copy_(src.t())
+
+
+def _time_major(buf, n_loc):
+    """Contiguous (n_loc, M) block X_loc[t][i] of a slab."""
+    M, ld = buf.shape
+    if not buf.is_cuda:
+        return buf[:, :n_loc].t().contiguous()
+    out = torch.empty((n_loc, M), dtype=torch.float64, device=buf.device)
+    _lib.transpose(buf, M, n_loc, ld, out, M)
+    return out
+
+
+def _time_rows(buf, t_idx):
+    """(len(t_idx), M) contiguous copies of the time rows t_idx of a slab: ONE
+    pass over the slab's lines (stk_halo_pack / stk_slab_extract_time_rows)
+    instead of a strided copy per row."""
+    M, ld = buf.shape
+    if not buf.is_cuda:
+        return torch.stack([buf[:, t] for t in t_idx]).contiguous()
+    out = torch.empty((len(t_idx), M), dtype=torch.float64, device=buf.device)
+    idx = _lib.to_dev(np.asarray(t_idx, dtype=np.int32))
+    _lib.check(_lib.lib().stk_slab_extract_time_rows(
+        _lib.stream(), M, len(t_idx), _lib.ptr(idx), _lib.ptr(buf), ld,
+        _lib.ptr(out), M))
+    return out
+
+
 _dot_ws = {}
 
 
@@ -98,7 +135,7 @@ class KronVectorMPI:
     def reset(self, initial_data=None):
         self.communicated_bdr = False
         # ghost time rows (the reference's X_loc_bdr[0] and X_loc_bdr[-1])
-        self.X_lo = self.X_hi = self._ghost = self._ghost_il = None
+        self.X_lo = self.X_hi = self._ghost = self._ghost_il = self._halo_send = None
         self._notify_pending()
         dev = _lib.compute_device()
         if initial_data is None:
@@ -113,14 +150,14 @@ class KronVectorMPI:
             src = initial_data if torch.is_tensor(
                 initial_data) else torch.from_numpy(
                     np.ascontiguousarray(initial_data, dtype=np.float64))
-            self._buf[:, :self.n_loc].copy_(src.to(dev).t())
+            _fill_slab(self._buf, self.n_loc, src)
 
     def copy(self):
         cpy = KronVectorMPI.__new__(KronVectorMPI)
         cpy.__dict__.update(self.__dict__)
         cpy._pending = None
         cpy.communicated_bdr = False
-        cpy.X_lo = cpy.X_hi = cpy._ghost = cpy._ghost_il = None
+        cpy.X_lo = cpy.X_hi = cpy._ghost = cpy._ghost_il = cpy._halo_send = None
         cpy._buf = self.buf.clone()
         return cpy
 
@@ -129,7 +166,7 @@ class KronVectorMPI:
         out.__dict__.update(self.__dict__)
         out._pending = None
         out.communicated_bdr = False
-        out.X_lo = out.X_hi = out._ghost = out._ghost_il = None
+        out.X_lo = out.X_hi = out._ghost = out._ghost_il = out._halo_send = None
         out._buf = torch.empty_like(self.buf)
         return out
 
@@ -248,12 +285,12 @@ class KronVectorMPI:
             else:
                 slab = slab.to(comm._device())
                 comm.wait_all(comm.exchange([], [(slab, 0)]))
-        self._buf[:, :self.n_loc].copy_(slab.to(dev).t())
+        _fill_slab(self._buf, self.n_loc, slab)
 
     def gather(self, X_glob):
         """Slabs -> root's flat global array (reference mpi_vector.py:134-138)."""
         comm, dd = self.dofs_distr.comm, self.dofs_distr
-        mine = self.X_loc.contiguous()
+        mine = _time_major(self.buf, self.n_loc)
         if comm.size == 1:
             X_glob[...] = mine.cpu().numpy().reshape(X_glob.shape)
             return
@@ -292,13 +329,30 @@ class KronVectorMPI:
             self._ghost = torch.zeros((2, self.M),
                                       dtype=torch.float64,
                                       device=self.buf.device)
+        if size > 1:
+            # the first and the last time step, both from one pass over the slab
+            # (stk_halo_pack) into a reused (2, M) send buffer
+            if getattr(self, '_halo_send', None) is None:
+                self._halo_send = torch.empty((2, self.M), dtype=torch.float64,
+                                              device=self.buf.device)
+            first = self._halo_send[0] if rank > 0 else None
+            last = self._halo_send[1] if rank + 1 < size else None
+            if self.buf.is_cuda:
+                _lib.check(_lib.lib().stk_halo_pack(
+                    _lib.stream(), self.M, self.n_loc, self.ld, _lib.ptr(self.buf),
+                    _lib.ptr(first), 1, _lib.ptr(last), 1))
+            else:
+                if first is not None:
+                    first.copy_(self.buf[:, 0])
+                if last is not None:
+                    last.copy_(self.buf[:, self.n_loc - 1])
         if rank > 0:
             self.X_lo = self._ghost[0]
-            sends.append((self.buf[:, 0].contiguous(), rank - 1))
+            sends.append((first, rank - 1))
             recvs.append((self.X_lo, rank - 1))
         if rank + 1 < size:
             self.X_hi = self._ghost[1]
-            sends.append((self.buf[:, self.n_loc - 1].contiguous(), rank + 1))
+            sends.append((last, rank + 1))
             recvs.append((self.X_hi, rank + 1))
         reqs = comm.exchange(sends, recvs)
 
@@ -348,8 +402,9 @@ class KronVectorMPI:
                                device=self.buf.device)
         send_set = sorted(
             set((int(s), int(dd.dof2proc[int(r)])) for s, r in comm_dofs))
-        sends = [(self.buf[:, s - self.t_begin].contiguous(), p)
-                 for s, p in send_set]
+        rows = sorted(set(s - self.t_begin for s, _ in send_set))
+        packed = _time_rows(self.buf, rows) if rows else None
+        sends = [(packed[rows.index(s - self.t_begin)], p) for s, p in send_set]
         recvs = [(recv_buf[slot[r]], int(dd.dof2proc[r])) for r in need]
         reqs = dd.comm.exchange(sends, recvs)
         return recv_buf, slot, reqs
@@ -368,28 +423,50 @@ class KronVectorMPI:
         pd = vec_perm.dofs_distr
         x_begin, x_end = vec_perm.t_begin, vec_perm.t_end
         # own block needs no transfer
+        ld, ldp = self.ld, vec_perm.ld
+
+        def own_block(xb, xe, tb):
+            # vec_perm.buf[tb + t, x - xb] = self.buf[x, t]  (stk_transpose)
+            if self.buf.is_cuda:
+                _lib.transpose(self.buf, xe - xb, self.n_loc, ld, vec_perm._buf,
+                               ldp, src_off=xb * ld, dst_off=tb * ldp)
+            else:
+                vec_perm._buf[tb:tb + self.n_loc, :xe - xb].copy_(
+                    self.buf[xb:xe, :self.n_loc].t())
+
         if comm.size == 1:
-            # vec_perm.buf[tglob, x - x_begin] = self.buf[x, t]
-            vec_perm._buf[:, :vec_perm.n_loc].copy_(
-                self.buf[x_begin:x_end, :self.n_loc].t())
+            own_block(x_begin, x_end, 0)
             return vec_perm, MPI.Wtime() - start_time
         sends, recvs, staged = [], [], []
         for p in range(comm.size):
             xb, xe = pd.dof_distribution[p]
             tb, te = self.dofs_distr.dof_distribution[p]
             if p == comm.rank:
-                vec_perm._buf[tb:te, :vec_perm.n_loc].copy_(
-                    self.buf[xb:xe, :self.n_loc].t())
+                own_block(xb, xe, tb)
                 continue
-            sends.append((self.buf[xb:xe, :self.n_loc].contiguous(), p))
-            rbuf = torch.empty((x_end - x_begin, te - tb),
+            # the block travels already transposed: (n_loc, xe - xb), time-major
+            sbuf = torch.empty((self.n_loc, xe - xb), dtype=torch.float64,
+                               device=self.buf.device)
+            if xe > xb:
+                if self.buf.is_cuda:
+                    _lib.transpose(self.buf, xe - xb, self.n_loc, ld, sbuf,
+                                   xe - xb, src_off=xb * ld)
+                else:
+                    sbuf.copy_(self.buf[xb:xe, :self.n_loc].t())
+            sends.append((sbuf, p))
+            rbuf = torch.empty((te - tb, x_end - x_begin),
                                dtype=torch.float64,
                                device=self.buf.device)
             recvs.append((rbuf, p))
             staged.append((tb, te, rbuf))
         comm.wait_all(comm.exchange(sends, recvs))
+        nx = x_end - x_begin
         for tb, te, rbuf in staged:
-            vec_perm._buf[tb:te, :vec_perm.n_loc].copy_(rbuf.t())
+            if rbuf.is_cuda:
+                _lib.copy_block(rbuf, te - tb, nx, nx, vec_perm._buf, ldp,
+                                dst_off=tb * ldp)
+            else:
+                vec_perm._buf[tb:te, :nx].copy_(rbuf)
         return vec_perm, MPI.Wtime() - start_time
 
 
@@ -402,7 +479,7 @@ class _ScaledVector(KronVectorMPI):
         self.__dict__.update(src.__dict__)
         self._pending = None
         self.communicated_bdr = False
-        self.X_lo = self.X_hi = self._ghost = None
+        self.X_lo = self.X_hi = self._ghost = self._halo_send = None
         self._alpha, self._src, self._lazy = alpha, src, True
         self.__dict__.pop('_buf', None)
         if src._pending is None:

@@ -126,6 +126,14 @@ def coupling_bands(coords, indptr, indices):
     return band
 
 
+# Gauss-Seidel rows on the device: True = diagonal-free copies,
+# u_i = (f_i - sum_{j != i} a_ij u_j) / a_ii (PETSc MatSOR's form; one gather less
+# per row); False = the whole row in the slots and the reference's pure-Python
+# update u_i += (f_i - row_i u) / a_ii (reference multigrid.py:89-97) -- part of
+# the "reference arithmetic" mode (heateq_mpi.HeatEquationMPI(arithmetic='reference')).
+GS_DIAG_FREE = True
+
+
 class _DeviceHierarchy:
     """Everything one libstk multigrid plan needs, resident on the device."""
     def __init__(self, mat_a, mat_m, hierarchy, smoothsteps, vcycles,
@@ -149,7 +157,7 @@ class _DeviceHierarchy:
         # finest first, side by side
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=3) as pool:
-            for done in [pool.submit(self._fill_level, j, hierarchy)
+            for done in [pool.submit(_lib.in_device_context(self._fill_level), j, hierarchy)
                          for j in reversed(range(self.J + 1))]:
                 done.result()
         inv = np.stack([np.linalg.inv(np.asarray(m.todense()))
@@ -195,7 +203,8 @@ class _DeviceHierarchy:
             # of the sweeps' copies, built beside them
             moved = {}
             transfers = threading.Thread(
-                target=self._transfer_ells, args=(j, hierarchy, mats, tile, moved))
+                target=_lib.in_device_context(self._transfer_ells),
+                args=(j, hierarchy, mats, tile, moved))
             transfers.start()
             ells = {'a': EllRowsMatrix(indptr, indices, vals[0], vm, tile)}
             for name, bw in (('fwd', False), ('bwd', True)):
@@ -211,8 +220,13 @@ class _DeviceHierarchy:
                 groups = [r_[np.argsort(key[r_], kind='stable')] for r_ in groups]
                 listed = (np.concatenate(groups) if n else
                           np.zeros(0, dtype=np.int64))
-                ells[name] = EllRowsMatrix(indptr, indices, vals[0], vm,
-                                           listed, diag=True)
+                if GS_DIAG_FREE:
+                    ells[name] = EllRowsMatrix(indptr, indices, vals[0], vm,
+                                               listed, diag=True)
+                else:
+                    ells[name] = EllRowsMatrix(
+                        indptr, indices, vals[0], vm, listed,
+                        dia_values=(vals[0][diag], None if vm is None else vm[diag]))
                 if band is not None:
                     # band of every ELL position (ascending inside a group):
                     # lets the plan run the sweeps strip by strip (mg.hip)

@@ -185,20 +185,33 @@ class _TransposedWavelet:
                            device=vec_in.buf.device)
         t0 = MPI.Wtime()
         sends, recvs, parts = [], [], []
+        n_in, ld_in = vec_in.n_loc, vec_in.ld
+
+        def block(src, rows, cols, ld_src, dst, ld_dst, src_off=0, dst_off=0):
+            # a block of rows moved to another leading dimension: libstk's
+            # stk_copy_block on the device (host tensors: CPU tests of the layer)
+            if src.is_cuda:
+                _lib.copy_block(src, rows, cols, ld_src, dst, ld_dst, src_off, dst_off)
+            elif rows and cols:
+                dst.view(-1)[dst_off:].as_strided((rows, cols), (ld_dst, 1)).copy_(
+                    src.view(-1)[src_off:].as_strided((rows, cols), (ld_src, 1)))
+
         for p in range(comm.size):
             pb, pe = self.space.dof_distribution[p]
             tb, te = dd.dof_distribution[p]
             if p == rank:
-                full[:, tb:te] = vec_in.buf[xb:xe, :vec_in.n_loc]
+                block(vec_in.buf, xe - xb, n_in, ld_in, full, ldN, xb * ld_in, tb)
                 continue
-            sends.append((vec_in.buf[pb:pe, :vec_in.n_loc].contiguous(), p))
+            sbuf = torch.empty((pe - pb, n_in), dtype=torch.float64, device=full.device)
+            block(vec_in.buf, pe - pb, n_in, ld_in, sbuf, n_in, pb * ld_in)
+            sends.append((sbuf, p))
             r = torch.empty((xe - xb, te - tb), dtype=torch.float64,
                             device=full.device)
             recvs.append((r, p))
             parts.append((tb, te, r))
         comm.wait_all(comm.exchange(sends, recvs))
         for tb, te, r in parts:
-            full[:, tb:te] = r
+            block(r, xe - xb, te - tb, te - tb, full, ldN, 0, tb)
         t_comm = MPI.Wtime() - t0
         out = torch.empty_like(full)
         if xe > xb:
@@ -212,18 +225,22 @@ class _TransposedWavelet:
             pb, pe = self.space.dof_distribution[p]
             tb, te = dd.dof_distribution[p]
             if p == rank:
-                vec_out.buf[xb:xe, :vec_out.n_loc] = out[:, tb:te]
+                block(out, xe - xb, te - tb, ldN, vec_out.buf, vec_out.ld, tb,
+                      xb * vec_out.ld)
                 continue
-            sends.append((out[:, tb:te].contiguous(), p))
+            sbuf = torch.empty((xe - xb, te - tb), dtype=torch.float64, device=full.device)
+            block(out, xe - xb, te - tb, ldN, sbuf, te - tb, tb)
+            sends.append((sbuf, p))
             r = torch.empty((pe - pb, te_me - tb_me), dtype=torch.float64,
                             device=full.device)
             recvs.append((r, p))
             parts.append((pb, pe, r))
         comm.wait_all(comm.exchange(sends, recvs))
+        n_out = vec_out.n_loc
         for pb, pe, r in parts:
-            vec_out.buf[pb:pe, :vec_out.n_loc] = r
+            block(r, pe - pb, n_out, n_out, vec_out.buf, vec_out.ld, 0, pb * vec_out.ld)
         if vec_out.ld > vec_out.n_loc:
-            vec_out.buf[:, vec_out.n_loc:] = 0.0
+            vec_out.buf[:, vec_out.n_loc:].zero_()
         return t_comm + MPI.Wtime() - t0
 
 

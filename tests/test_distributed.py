@@ -123,3 +123,44 @@ def test_bench_runs_as_the_driver_launches_it(nproc, backend):
     assert rec['pcg']['roofline']['bytes_per_iteration'] > 0
     if nproc > 1:
         assert 'ghost' in rec['roofline']['kernel']
+
+
+def test_bench_builds_its_own_launch_line(monkeypatch):
+    """`python bench.py --gpus N` without a launcher starts N ranks under
+    torch.distributed.run on 127.0.0.1 as CHILD processes (CPU check of the
+    command; the GPU test below runs it)."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen['cmd'], seen['env'] = cmd, env
+        return 0
+
+    monkeypatch.setattr(subprocess, 'call', fake_call)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '3'])
+    assert bench.spawn_ranks(4) == 0
+    cmd = seen['cmd']
+    assert cmd[:3] == [sys.executable, '-m', 'torch.distributed.run']
+    assert cmd[cmd.index('--nproc-per-node') + 1] == '4'
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert cmd[-5:] == [os.path.abspath(bench.__file__), '--gpus', '4', '--steps', '3']
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+
+
+@pytest.mark.gpu
+def test_bench_started_without_a_launcher_spawns_its_ranks():
+    """The driver's command shape, `python bench.py --gpus N ...`, for N = 2: the
+    bench starts its two ranks itself (here sharing the box's GPU over gloo) and
+    rank 0's JSON line comes back on stdout."""
+    import json
+    env = dict(os.environ, STK_BACKEND='gloo', OMP_NUM_THREADS='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(os.path.dirname(HERE), 'bench.py'), '--gpus', '2',
+           '--steps', '2', '--warmup', '1', '--J_time', '4', '--J_space', '5',
+           '--solve-iters', '2', '--no-cpu-baseline', '--preheat', '0']
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    rec = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('{')][-1])
+    assert rec['n_gpus'] == 2 and rec['value'] > 0 and 'ghost' in rec['roofline']['kernel']

@@ -1661,3 +1661,111 @@ def test_multigrid_plan_from_csr_through_ctypes_only(stk):
     assert lib.stk_mg_create_from_csr(1, ctypes.byref(bad), None, None, None, 2, 1,
                                       1, 1.0, 0, None, 2, ctypes.byref(plan)) != 0
     assert b'diagonal' in lib.stk_last_error()
+
+
+def test_slab_storage_through_ctypes_only(stk):
+    """vector alloc / upload / download for a host that owns no
+    device allocator (KronVectorMPI.__init__, scatter, gather:
+    mpi_vector.py:62-71, 124-138), called through ctypes with host buffers and
+    raw device pointers only -- no torch tensor involved -- and checked through a
+    libstk kernel that consumes the slab (stk_axpby on the flat array)."""
+    import ctypes
+    lib = stk.lib()
+    rng = np.random.RandomState(5)
+    for M, n_loc in [(1, 1), (37, 9), (1000, 33), (4099, 64), (513, 65)]:
+        ld, slab = ctypes.c_int32(), ctypes.c_void_p()
+        stk.check(lib.stk_slab_alloc(M, n_loc, ctypes.byref(ld), ctypes.byref(slab)))
+        assert ld.value == lib.stk_slab_ld(n_loc) == n_loc + (n_loc & 1)
+        X = rng.rand(n_loc, M)
+        stk.check(lib.stk_slab_upload(None, M, n_loc, ld.value, X.ctypes.data, slab))
+        # y = 2 x + 0 y in place on the flat array: padding stays zero
+        stk.check(lib.stk_axpby(None, M * ld.value, 2.0, slab, 0.0, slab))
+        Y = np.full((n_loc, M), np.nan)
+        stk.check(lib.stk_slab_download(None, M, n_loc, ld.value, slab, Y.ctypes.data))
+        assert np.array_equal(Y, 2.0 * X)
+        stk.check(lib.stk_slab_free(slab))
+    assert lib.stk_slab_alloc(0, 3, ctypes.byref(ld), ctypes.byref(slab)) != 0
+
+
+def test_byte_moving_kernels(stk):
+    """stk_transpose (with zero padding), stk_halo_pack at strides 1 and 2,
+    stk_slab_extract_time_rows, stk_copy_block and stk_outer against NumPy:
+    pure data movement, bit-exact."""
+    import torch
+    lib = stk.lib()
+    rng = np.random.RandomState(6)
+    dev = stk.compute_device()
+    for M, n_loc in [(5, 1), (130, 9), (1027, 33), (300, 65)]:
+        ld = n_loc + (n_loc & 1)
+        X = rng.rand(n_loc, M)
+        src = torch.from_numpy(X).to(dev)
+        slab = torch.full((M, ld), float('nan'), dtype=torch.float64, device=dev)
+        stk.transpose(src, n_loc, M, M, slab, ld, zero_to=ld)
+        want = np.zeros((M, ld))
+        want[:, :n_loc] = X.T
+        assert np.array_equal(slab.cpu().numpy(), want)
+        back = torch.empty((n_loc, M), dtype=torch.float64, device=dev)
+        stk.transpose(slab, M, n_loc, ld, back, M)
+        assert np.array_equal(back.cpu().numpy(), X)
+        # halo rows: contiguous, and interleaved into a ghost buffer
+        send = torch.zeros((2, M), dtype=torch.float64, device=dev)
+        stk.check(lib.stk_halo_pack(stk.stream(), M, n_loc, ld, stk.ptr(slab),
+                                    stk.ptr(send[0]), 1, stk.ptr(send[1]), 1))
+        assert np.array_equal(send.cpu().numpy(), X[[0, n_loc - 1]])
+        gh = torch.zeros((M, 2), dtype=torch.float64, device=dev)
+        # as a neighbour pair would: my LAST row is the upper rank's lo entry,
+        # my FIRST row the lower rank's hi entry
+        stk.check(lib.stk_halo_pack(stk.stream(), M, n_loc, ld, stk.ptr(slab),
+                                    stk.ptr(gh) + 8, 2, stk.ptr(gh), 2))
+        assert np.array_equal(gh.cpu().numpy(), np.stack([X[n_loc - 1], X[0]], axis=1))
+        only = torch.zeros(M, dtype=torch.float64, device=dev)
+        stk.check(lib.stk_halo_pack(stk.stream(), M, n_loc, ld, stk.ptr(slab), None, 1,
+                                    stk.ptr(only), 1))
+        assert np.array_equal(only.cpu().numpy(), X[n_loc - 1])
+        rows = sorted(set(int(t) for t in rng.randint(0, n_loc, size=3)))
+        idx = stk.to_dev(np.asarray(rows, dtype=np.int32))
+        out = torch.empty((len(rows), M), dtype=torch.float64, device=dev)
+        stk.check(lib.stk_slab_extract_time_rows(stk.stream(), M, len(rows), stk.ptr(idx),
+                                                 stk.ptr(slab), ld, stk.ptr(out), M))
+        assert np.array_equal(out.cpu().numpy(), X[rows])
+        # a block of rows to another leading dimension
+        r0, r1, nc = M // 3, M, max(1, n_loc - 1)
+        blk = torch.zeros((r1 - r0, nc + 3), dtype=torch.float64, device=dev)
+        stk.copy_block(slab, r1 - r0, nc, ld, blk, nc + 3, src_off=r0 * ld)
+        assert np.array_equal(blk.cpu().numpy()[:, :nc], want[r0:r1, :nc])
+        assert not blk.cpu().numpy()[:, nc:].any()
+        u_t, u_x = rng.rand(n_loc), rng.rand(M)
+        y = torch.full((M, ld), float('nan'), dtype=torch.float64, device=dev)
+        stk.check(lib.stk_outer(stk.stream(), M, n_loc, ld, stk.ptr(stk.to_dev(u_t)),
+                                stk.ptr(stk.to_dev(u_x)), stk.ptr(y)))
+        wy = np.zeros((M, ld))
+        wy[:, :n_loc] = np.kron(u_t, u_x).reshape(n_loc, M).T
+        assert np.array_equal(y.cpu().numpy(), wy)
+    assert lib.stk_halo_pack(stk.stream(), 4, 2, 2, stk.ptr(slab), None, 1, None, 1) != 0
+
+
+def test_direct_inverse_above_the_dense_limit(stk):
+    """InvLinOp on a system too large for a dense inverse (reference linop.py:18-26
+    is size-agnostic SuperLU): the host-SuperLU apply through stk_slab_download /
+    stk_slab_upload, against SciPy's solve."""
+    from scipy.sparse.linalg import splu
+    from source.assembly import space_matrices
+    from source.linop import InvLinOp
+    from source.problem import problem_helper
+    mesh, _, _, _, _ = problem_helper('square', J_space=6, J_time=1)
+    M_x, A_x = space_matrices(mesh)
+    mat = sp.csr_matrix(4.0 * M_x + 0.3 * A_x)
+    assert mat.shape[0] > InvLinOp.MAX_ROWS
+    op = InvLinOp(mat)
+    assert op._dense is None
+    rng = np.random.RandomState(11)
+    n_loc = 5
+    X = rng.rand(n_loc, mat.shape[0])
+    dd = _dd(n_loc, mat.shape[0])
+    x = _vec(dd, X)
+    y = op.apply(x.buf, n_loc=n_loc)
+    got = y[:, :n_loc].t().cpu().numpy()
+    want = splu(sp.csc_matrix(mat), options={"SymmetricMode": True},
+                permc_spec="MMD_AT_PLUS_A").solve(X.T.copy()).T
+    assert np.array_equal(got, want)
+    assert not y[:, n_loc:].cpu().numpy().any()

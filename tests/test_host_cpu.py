@@ -51,6 +51,34 @@ def test_no_cpu_fallback():
             x.dot(x)
 
 
+def test_worker_threads_and_pointers_use_the_process_device(monkeypatch):
+    """torch.cuda.current_device() is thread-local (a new thread starts on
+    device 0): plans built in worker threads must land on the GPU pinned for the
+    process, and a tensor of another GPU must be refused."""
+    import threading
+    from source import _lib
+    monkeypatch.setattr(_lib, '_process_device', 5)
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: True)
+    seen = []
+    worker = threading.Thread(target=lambda: seen.append(_lib.compute_device()))
+    worker.start()
+    worker.join()
+    assert seen == [torch.device('cuda', 5)] and _lib.compute_device() == seen[0]
+
+    class FakeTensor:
+        is_cuda = True
+
+        def __init__(self, index):
+            self.device = torch.device('cuda', index)
+
+        def data_ptr(self):
+            return 4096
+
+    assert _lib.ptr(FakeTensor(5)) == 4096
+    with pytest.raises(_lib.StkError):
+        _lib.ptr(FakeTensor(0))
+
+
 # ---- a1: partition -------------------------------------------------------------
 class _FakeComm:
     def __init__(self, rank, size):

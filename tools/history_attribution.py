@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Which rounding owns the gap between the GPU solve's r.Pr history and the CPU
+oracle's?  Solves the BASELINE configurations with each of this build's
+regroupings switched off in turn and compares every history with the oracle
+fixture (tests/golden/o1_pcg_*.npz):
+
+  default            fused Schur complement, batched multigrid family, diagonal-free
+                     Gauss-Seidel rows
+  schur=reference    the five-term sum of reference heateq_mpi.py:166-181
+  gs=full rows       u_i += (f_i - row_i u) / a_ii (multigrid.py:89-97)
+  family=reference   one hierarchy per wavelet level from the assembled
+                     2^j M + alpha A (heateq_mpi.py:147-153)
+  arithmetic=reference   all three
+
+    python tools/history_attribution.py --configs square:5:8,square:6:9,lshape:5:8
+Writes gpurun_out/history_attribution.json (copy it to profiles/).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, 'spacetime-fullgrid-parallel_amd'))
+import heateq_mpi as hm  # noqa: E402
+from source import multigrid as mg  # noqa: E402
+from source.linalg import PCG  # noqa: E402
+
+VARIANTS = [
+    ('default', {}, True),
+    ('schur=reference', {'schur': 'reference'}, True),
+    ('gs=full rows', {}, False),
+    ('family=reference', {'family': 'reference'}, True),
+    ('family=reference + gs=full rows', {'family': 'reference'}, False),
+    ('arithmetic=reference', {'arithmetic': 'reference'}, True),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--configs', default='square:3:6,square:5:8,square:6:9,lshape:5:8')
+    ap.add_argument('--variants', default='')
+    ap.add_argument('--out', default=os.path.join(REPO, 'gpurun_out', 'history_attribution.json'))
+    args = ap.parse_args()
+    import torch
+    want = set(filter(None, args.variants.split(',')))
+    out = {}
+    for spec in args.configs.split(','):
+        problem, jt, js = spec.split(':')
+        jt, js = int(jt), int(js)
+        g = np.load(os.path.join(REPO, 'tests', 'golden', 'o1_pcg_%s_J%d_J%d.npz' % (problem, jt, js)))
+        ref = np.asarray(g['hist'])
+        rec = out.setdefault(spec, {})
+        for name, kw, diag_free in VARIANTS:
+            if want and name not in want:
+                continue
+            mg.GS_DIAG_FREE = diag_free
+            t0 = time.time()
+            h = hm.HeatEquationMPI(J_space=js, J_time=jt, problem=problem, **kw)
+            mg.GS_DIAG_FREE = True
+            setup = time.time() - t0
+            hist = []
+            torch.cuda.synchronize()
+            t0 = time.time()
+            _, it = PCG(h.WT_S_W, h.P, h.rhs, history=hist)
+            torch.cuda.synchronize()
+            solve = time.time() - t0
+            hist = np.asarray(hist)
+            n = min(len(hist), len(ref))
+            rel = np.abs(hist[:n] / ref[:n] - 1.0)
+            rec[name] = {'iterations': it, 'oracle_iterations': int(g['iters']),
+                         'first_entry_rel_dev': float(rel[0]), 'max_rel_dev': float(rel.max()),
+                         'rel_dev_per_entry': [float(v) for v in rel],
+                         'max_dev_relative_to_initial': float(np.abs(hist[:n] - ref[:n]).max() / ref[0]),
+                         'setup_s': setup, 'solve_s': solve}
+            print('%-14s %-34s iters %2d/%2d  first %.1e  max %.1e  (setup %.1f s, solve %.2f s)' % (
+                spec, name, it, int(g['iters']), rel[0], rel.max(), setup, solve), flush=True)
+            del h
+            torch.cuda.empty_cache()
+            os.makedirs(os.path.dirname(args.out), exist_ok=True)
+            json.dump(out, open(args.out, 'w'), indent=1)
+    print('wrote', args.out)
+
+
+if __name__ == '__main__':
+    main()
