@@ -108,6 +108,41 @@ int stk_copy_block(void *stream, int64_t rows, int32_t cols, const double *src,
 int stk_outer(void *stream, int32_t M, int32_t n_loc, int32_t ld,
               const double *u_t, const double *u_x, double *y);
 
+/* ---- communication of the time-slab decomposition for hosts without
+ *      torch.distributed: the reference's mpi4py call sites on
+ *      RCCL over xGMI, one process per GPU --------------------------------------
+ * RCCL is loaded at run time (librccl.so.1); nothing else in the library needs it.
+ * Rank 0 obtains a unique id and the HOST distributes its STK_COMM_ID_BYTES bytes
+ * to the other ranks (by whatever launched them: MPI, a file, a socket); every
+ * rank then calls stk_comm_create on the device it computes on.  All calls are
+ * enqueued on `stream`; buffers are device pointers of float64.
+ *   stk_comm_allreduce_sum  KronVectorMPI.dot's allreduce (mpi_vector.py:209), in place
+ *   stk_comm_halo_exchange  communicate_bdr (mpi_vector.py:140-187): send_first goes to
+ *                           rank-1 (its X_loc_bdr[-1]), send_last to rank+1 (its
+ *                           X_loc_bdr[0]); recv_lo / recv_hi receive the neighbours' rows
+ *                           (M doubles each); pointers of a side without a neighbour are
+ *                           ignored.  Feed it from stk_halo_pack.
+ *   stk_comm_exchange       a batch of sends and receives as ONE group (communicate_dofs,
+ *                           mpi_vector.py:189-203; the tiles of permute, :224-239);
+ *                           messages between a pair of ranks match in posting order. */
+#define STK_COMM_ID_BYTES 128
+typedef struct stk_comm stk_comm;
+typedef struct {
+    void *buf;     /* device, float64 */
+    int64_t count; /* doubles */
+    int32_t peer;  /* rank */
+} stk_comm_msg;
+int stk_comm_unique_id(void *id_host);
+int stk_comm_create(int32_t rank, int32_t size, const void *id_host, stk_comm **out);
+int stk_comm_destroy(stk_comm *comm);
+int stk_comm_allreduce_sum(stk_comm *comm, void *stream, double *values, int32_t n);
+int stk_comm_halo_exchange(stk_comm *comm, void *stream, int32_t M,
+                           const double *send_first, const double *send_last,
+                           double *recv_lo, double *recv_hi);
+int stk_comm_exchange(stk_comm *comm, void *stream, int32_t n_send,
+                      const stk_comm_msg *sends_host, int32_t n_recv,
+                      const stk_comm_msg *recvs_host);
+
 /* ---- BLAS-1 on flat arrays (KronVectorMPI arithmetic, mpi_vector.py:84-122,
  *      and dot, mpi_vector.py:205-210, local part) -------------------------- */
 /* y = a * x + b * y   (b == 0 ignores the old y; x == y allowed) */
@@ -271,7 +306,16 @@ typedef struct {
     const uint32_t *slots;  /* n_units*K */
     const int32_t *row_ids; /* n_units*rows_per_unit; NULL (index order) only when rows_per_unit = 1 */
     const double *dict;     /* n_mats*n_codes*rows_per_unit */
+    const double *vals;     /* NULL, or explicit values (no dictionary; rows_per_unit = 2 only):
+                               n_units*K*rows_per_unit*n_mats, the slot words are then bare columns */
 } stk_pack_pattern;
+/* Explicit values: matrices whose entries do not repeat (an unstructured mesh;
+ * the reference takes any CSR, mpi_kron.py:135-150) have no dictionary, but their
+ * rows still share COLUMNS.  vals[((u*K + s)*2 + j)*n_mats + m] is the entry of
+ * matrix m in row j of slot row u at the column of slot s (zero where that row
+ * has none): 36 bytes per slot for two matrices instead of 20 in the one-row
+ * plain form (stk_kron_ell_apply), 10 gathers for two rows instead of 14, the
+ * same sums in the same order. */
 /* Row pairs (rows_per_unit = 2): slot row u serves the matrix rows
  * row_ids[2u] and row_ids[2u + 1] (-1: none); its K slots (K one of 8, 10, 12)
  * list the UNION of their columns in ascending order, and matrix m has the
@@ -295,6 +339,16 @@ typedef struct {
  * urows [units][rp] (-1 = none).  stk_pack_unit_slots: K_out of the instantiated
  * kernels for rows of K slots (0: none). */
 int32_t stk_pack_unit_slots(int32_t K, int32_t rp);
+/* Host helper: a processing order in which rows that can share a slot row follow
+ * each other, for patterns whose given order lacks that (unstructured meshes).
+ * Behind every not yet placed row of the given order goes ONE not yet placed
+ * neighbour (a column of the row) whose union of columns with it fits K_out
+ * slots -- the nearest in the given order, at most `window` positions away.
+ * counts / cols / own as in stk_pack_group_rows; perm[q] = position in the given
+ * order of the row at position q of the new order. */
+int stk_pack_match_order(int32_t M, int32_t K, const int32_t *counts,
+                         const int32_t *cols, const int32_t *own, int32_t K_out,
+                         int32_t window, int32_t *perm);
 int stk_pack_group_rows(int32_t M, int32_t K, const int32_t *counts,
                         const int32_t *cols, const int32_t *codes,
                         const int32_t *own, int32_t zero_code, int32_t rp,
@@ -305,6 +359,17 @@ int stk_kron_pack_apply(void *stream, const stk_pack_pattern *pattern_host,
                         int32_t n_loc, int32_t ld, int32_t n_terms,
                         const stk_kron_pack_term *terms_host, const double *x,
                         const double *ghosts, double beta, double *y);
+
+/* What the ghost time rows add to y after stk_kron_pack_apply ran with ghosts =
+ * NULL while the halo exchange was in flight (the reference overlaps the exchange
+ * with the rows that do not need it, mpi_kron.py:193-200, mpi_vector.py:177-179):
+ *   y[i][0] += sum_k sub_k[0] (X_k x_lo)[i],  y[i][n_loc-1] += sum_k super_k[n_loc-1] (X_k x_hi)[i].
+ * x_lo / x_hi: the received rows as they arrive (contiguous, length M; NULL on a
+ * side without a neighbour).  One lane per slot row on the packed stream. */
+int stk_kron_pack_ghost_apply(void *stream, const stk_pack_pattern *pattern_host,
+                              int32_t n_loc, int32_t ld, int32_t n_terms,
+                              const stk_kron_pack_term *terms_host,
+                              const double *x_lo, const double *x_hi, double *y);
 
 /* ---- plan construction from CSR (no Python needed) ---------------------------
  * Everything the three forms above stream is derived here, on the host side of
@@ -486,6 +551,13 @@ int stk_mg_create(int32_t n_levels, const stk_mg_level *levels_host,
                   int32_t smoothsteps, int32_t vcycles, int32_t n_kinds,
                   const double *coarse_inv, int32_t max_ld, stk_mg **out);
 int stk_mg_destroy(stk_mg *mg);
+/* Per-plan choices that regroup the reference's arithmetic (results change in
+ * the last bits only; the solve's r.Pr history is sensitive to them, DESIGN.md
+ * section 5).  "fuse_restrict": 1 = the restricted residual as (R A) u - R f from
+ * the precomputed product R A (no fine-level residual is written), 0 = the
+ * reference's R (A u - f) (multigrid.py:174-175), -1 = follow the process-wide
+ * tuning key "mg_fuse_restrict" (default 1). */
+int stk_mg_set_option(stk_mg *plan, const char *key, int32_t value);
 /* u = MG(f): `vcycles` V-cycles from u = 0.  cm/kind: per-time-slice mass
  * coefficient and coarse-inverse index (device, n_loc) or NULL. */
 int stk_mg_apply(stk_mg *mg, void *stream, int32_t n_loc, int32_t ld,

@@ -43,6 +43,15 @@
 //    were measured slower than pairs, 0.322 and 0.576 ms against 0.301 ms, for
 //    their registers and LDS, and are not instantiated:
 //    profiles/r02_rows_per_unit.log.)
+//  * EXPLICIT VALUES (DICT = false, row pairs only): matrices whose entries do not
+//    repeat -- an unstructured mesh, reference mpi_kron.py:135-150 takes any CSR --
+//    have no dictionary.  Pairs need shared COLUMNS, not repeated values: the slot
+//    word is then the column alone and the values of both rows of every slot travel
+//    beside it, vals[unit][slot][row][matrix] (zero where a row has no entry in the
+//    column), prefetched into registers and handed over through LDS like the slot
+//    words.  36 bytes per slot instead of 20 in the one-row plain form
+//    (kron_ell.hip), but 10 gathers for two rows instead of 14; accumulation order
+//    and results are those of the plain form, bit for bit.
 #include <cstring>
 
 #include "stk_common.h"
@@ -66,6 +75,10 @@ struct PackArgs {
     int32_t col_bits, n_codes;
     int32_t flags;  // bit 0: non-temporal y stores, bit 1: non-temporal slot loads
     unsigned long long *diag;  // DIAG instantiation: [waves][4] cycle sums
+    // explicit values (no dictionary): [n_units][K][RP][n_mats], term k reads matrix mat[k]
+    const double *vals;
+    int32_t n_mats;
+    int32_t mat[NT];
 };
 
 typedef double stk_v2d __attribute__((ext_vector_type(2)));
@@ -88,9 +101,10 @@ __device__ inline unsigned long long stamp()
 // iteration -- publish + barrier, gathers + space factors, exchange + barrier,
 // time stencil + store -- into a.diag[wave][4].  Its outputs are still correct;
 // its run time is not quoted anywhere.
-template <int NT, int K, int NPF, bool GHOST, int BS, bool DIAG, int RP>
+template <int NT, int K, int NPF, bool GHOST, int BS, bool DIAG, int RP, bool DICT = true>
 __global__ __launch_bounds__(BS, (K >= 12 || RP > 1) ? 4 : 6) void kron_pack_kernel(const PackArgs<NT> a)
 {
+    constexpr int NPV = DICT ? 1 : 2;  // explicit values prefetched per thread (R is sized for it)
     constexpr int KS = (K + 3) & ~3;  // LDS stride of a row's slots (16-byte vectors)
     extern __shared__ double sm[];
     const int W = a.W, R = a.R, SW = a.n_loc + 3;
@@ -99,9 +113,9 @@ __global__ __launch_bounds__(BS, (K >= 12 || RP > 1) ? 4 : 6) void kron_pack_ker
     int32_t *s_row = reinterpret_cast<int32_t *>(s_slot + R * KS);  // [R][RP]
     const int LT = (a.n_loc + 2) & ~1;
     double *s_tri = reinterpret_cast<double *>(s_row + ((R * RP + 3) & ~3));  // [NT][3][LT], 16-byte aligned rows
-    double *s_dict = s_tri + NT * 3 * LT;                                     // [n_codes][RP][NT]
+    double *s_dict = s_tri + NT * 3 * LT;  // [n_codes][RP][NT], or the group's explicit values [R][K][RP][n_mats]
     // s_w[k][r * RP + j][q], q = t + 1: the space-factor results z_k[row][t], t = -1 .. n_loc
-    double *s_w = s_dict + a.n_codes * RP * NT;
+    double *s_w = s_dict + (DICT ? a.n_codes * RP * NT : R * K * RP * a.n_mats);
 
     const int tid = threadIdx.x;
     const int r = tid / W;
@@ -120,9 +134,11 @@ __global__ __launch_bounds__(BS, (K >= 12 || RP > 1) ? 4 : 6) void kron_pack_ker
     const int wdq = ghost_lane ? a.n_loc + 1 : 1;
     const bool wr1 = ghost_lane || has1;
 
-    for (int i = tid; i < a.n_codes * RP * NT; i += BS) {
-        const int c = i / NT, k = i - c * NT;  // c = code * RP + row of the pair
-        s_dict[i] = a.dict[k][c];
+    if constexpr (DICT) {
+        for (int i = tid; i < a.n_codes * RP * NT; i += BS) {
+            const int c = i / NT, k = i - c * NT;  // c = code * RP + row of the pair
+            s_dict[i] = a.dict[k][c];
+        }
     }
     if (a.any_tri) {
         for (int i = tid; i < NT * 3 * LT; i += BS) {
@@ -145,9 +161,13 @@ __global__ __launch_bounds__(BS, (K >= 12 || RP > 1) ? 4 : 6) void kron_pack_ker
     int g = xcd * a.chunk + (int)(blockIdx.x >> 3);
 
     uint32_t pslot[NPF];
+    double pval[NPV];
     int32_t prow = 0;
 #pragma unroll
     for (int q = 0; q < NPF; ++q) pslot[q] = 0;
+#pragma unroll
+    for (int q = 0; q < NPV; ++q) pval[q] = 0.0;
+    const int vper = K * RP * a.n_mats;  // explicit values of one slot row
     auto fetch = [&](int gq) {
         const int rows = min(R, a.n_units - gq * R);
         const uint32_t *src = a.slots + (size_t)gq * R * K;
@@ -155,6 +175,14 @@ __global__ __launch_bounds__(BS, (K >= 12 || RP > 1) ? 4 : 6) void kron_pack_ker
         for (int q = 0; q < NPF; ++q) {
             const int i = tid + q * BS;
             if (i < rows * K) pslot[q] = (a.flags & 2) ? __builtin_nontemporal_load(src + i) : src[i];
+        }
+        if constexpr (!DICT) {
+            const double *vsrc = a.vals + (size_t)gq * R * vper;
+#pragma unroll
+            for (int q = 0; q < NPV; ++q) {
+                const int i = tid + q * BS;
+                if (i < rows * vper) pval[q] = (a.flags & 2) ? __builtin_nontemporal_load(vsrc + i) : vsrc[i];
+            }
         }
         if (tid < rows * RP) prow = a.row_ids ? a.row_ids[(size_t)gq * R * RP + tid] : gq * R + tid;
     };
@@ -170,6 +198,13 @@ __global__ __launch_bounds__(BS, (K >= 12 || RP > 1) ? 4 : 6) void kron_pack_ker
             const int i = tid + q * BS;
             // element i of the group's flat [rows][K] chunk -> LDS [row][KS]
             if (i < rows * K) s_slot[i + (i / K) * (KS - K)] = pslot[q];
+        }
+        if constexpr (!DICT) {
+#pragma unroll
+            for (int q = 0; q < NPV; ++q) {
+                const int i = tid + q * BS;
+                if (i < rows * vper) s_dict[i] = pval[q];
+            }
         }
         if (tid < rows * RP) s_row[tid] = prow;
         __syncthreads();
@@ -235,11 +270,15 @@ __global__ __launch_bounds__(BS, (K >= 12 || RP > 1) ? 4 : 6) void kron_pack_ker
             }
 #pragma unroll
             for (int u = 0; u < K; ++u) {
-                const double *dv = s_dict + (sl[u] >> a.col_bits) * (RP * NT);
+                const double *dv = DICT ? s_dict + (sl[u] >> a.col_bits) * (RP * NT)
+                                        : s_dict + ((r * K + u) * RP) * a.n_mats;
 #pragma unroll
-                for (int j = 0; j < RP; ++j, dv += NT) {
+                for (int j = 0; j < RP; ++j, dv += (DICT ? NT : a.n_mats)) {
                     double v[NT];
-                    if constexpr (NT == 2) {  // one 16-byte read (s_dict is 16-byte aligned)
+                    if constexpr (!DICT) {
+#pragma unroll
+                        for (int k = 0; k < NT; ++k) v[k] = dv[a.mat[k]];
+                    } else if constexpr (NT == 2) {  // one 16-byte read (s_dict is 16-byte aligned)
                         const double2 vv = *reinterpret_cast<const double2 *>(dv);
                         v[0] = vv.x, v[1] = vv.y;
                     } else {
@@ -361,6 +400,138 @@ __global__ __launch_bounds__(BS, (K >= 12 || RP > 1) ? 4 : 6) void kron_pack_ker
     }
 }
 
+// What the two ghost time steps add to y when the main pass ran WITHOUT them
+// (GHOST = false) while the halo exchange was still in flight -- the reference
+// overlaps the exchange with the rows that do not need it the same way,
+// mpi_kron.py:193-200:
+//     y[i][0]         += sum_k sub_k[0]         * (X_k x_lo)[i]
+//     y[i][n_loc - 1] += sum_k super_k[n_loc-1] * (X_k x_hi)[i]
+// One lane per slot row on the same packed stream (4 bytes per slot; x_lo and
+// x_hi are the two received rows as they arrive, contiguous -- no interleave
+// step), read-modify-write of the two boundary entries of every row of y.
+template <int NT, int K, int RP>
+__global__ __launch_bounds__(256) void kron_pack_ghost_kernel(const PackArgs<NT> a, const double *__restrict__ lo,
+                                                              const double *__restrict__ hi)
+{
+    extern __shared__ double sm[];
+    double *s_dict = sm;  // [n_codes][RP][NT]
+    if (a.vals == nullptr) {
+        for (int i = threadIdx.x; i < a.n_codes * RP * NT; i += 256) {
+            const int c = i / NT, k = i - c * NT;
+            s_dict[i] = a.dict[k][c];
+        }
+    }
+    __syncthreads();
+    double c_lo[NT], c_hi[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        c_lo[k] = (lo && a.tri[k]) ? a.tri[k][0] : 0.0;                                // sub-diagonal of local row 0
+        c_hi[k] = (hi && a.tri[k]) ? a.tri[k][2 * a.n_loc + a.n_loc - 1] : 0.0;        // super-diagonal of the last row
+    }
+    const uint32_t col_mask = (1u << a.col_bits) - 1u;
+    const int stride = gridDim.x * 256;
+    for (int u = blockIdx.x * 256 + threadIdx.x; u < a.n_units; u += stride) {
+        uint32_t sl[K];
+#pragma unroll
+        for (int q = 0; q < K; ++q) sl[q] = a.slots[(size_t)u * K + q];
+        double zl[RP][NT], zh[RP][NT];
+#pragma unroll
+        for (int j = 0; j < RP; ++j)
+#pragma unroll
+            for (int k = 0; k < NT; ++k) zl[j][k] = zh[j][k] = 0.0;
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            const uint32_t col = sl[q] & col_mask;
+            const double xl = lo ? lo[col] : 0.0, xh = hi ? hi[col] : 0.0;
+            const double *dv = a.vals ? a.vals + ((size_t)u * K + q) * RP * a.n_mats
+                                      : s_dict + (sl[q] >> a.col_bits) * (RP * NT);
+#pragma unroll
+            for (int j = 0; j < RP; ++j)
+#pragma unroll
+                for (int k = 0; k < NT; ++k) {
+                    const double v = a.vals ? dv[j * a.n_mats + a.mat[k]] : dv[j * NT + k];
+                    zl[j][k] = fma(v, xl, zl[j][k]);
+                    zh[j][k] = fma(v, xh, zh[j][k]);
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < RP; ++j) {
+            const int row = a.row_ids ? a.row_ids[(size_t)u * RP + j] : u;
+            if (row < 0) continue;
+            double add_lo = 0.0, add_hi = 0.0;
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                add_lo = fma(c_lo[k], zl[j][k], add_lo);
+                add_hi = fma(c_hi[k], zh[j][k], add_hi);
+            }
+            double *yr = a.y + (size_t)row * a.ld;
+            if (a.n_loc == 1) {
+                yr[0] += add_lo + add_hi;
+            } else {
+                if (lo) yr[0] += add_lo;
+                if (hi) yr[a.n_loc - 1] += add_hi;
+            }
+        }
+    }
+}
+
+template <int NT, int RP>
+int launch_ghost_only(hipStream_t st, const PackArgs<NT> &a, int K, const double *lo, const double *hi)
+{
+    const size_t lds = sizeof(double) * (a.vals ? 0 : (size_t)a.n_codes * RP * NT) + 16;
+    const unsigned grid = stk_flat_grid(a.n_units, 256);
+#define STK_GHOST_CASE(KK)                                                                                   \
+    case KK:                                                                                                 \
+        hipLaunchKernelGGL((kron_pack_ghost_kernel<NT, KK, RP>), dim3(grid), dim3(256), lds, st, a, lo, hi); \
+        break;
+    if constexpr (RP == 1) {
+        switch (K) {
+            STK_GHOST_CASE(5)
+            STK_GHOST_CASE(7)
+            STK_GHOST_CASE(9)
+            STK_GHOST_CASE(12)
+            STK_GHOST_CASE(16)
+            default: stk_set_error("stk_kron_pack_ghost_apply: K=%d is not one of 5, 7, 9, 12, 16", K); return 2;
+        }
+    } else {
+        switch (K) {
+            STK_GHOST_CASE(8)
+            STK_GHOST_CASE(10)
+            STK_GHOST_CASE(12)
+            default: stk_set_error("stk_kron_pack_ghost_apply: K=%d is not one of 8, 10, 12 (row pairs)", K); return 2;
+        }
+    }
+#undef STK_GHOST_CASE
+    STK_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int NT>
+int dispatch_ghost_only(hipStream_t st, const stk_pack_pattern *pat, int32_t n_loc, int32_t ld,
+                        const stk_kron_pack_term *t, const double *lo, const double *hi, double *y)
+{
+    PackArgs<NT> a;
+    std::memset(&a, 0, sizeof(a));
+    a.slots = pat->slots;
+    a.row_ids = pat->row_ids;
+    a.y = y;
+    a.M = pat->M;
+    a.n_units = pat->n_units;
+    a.n_loc = n_loc;
+    a.ld = ld;
+    a.col_bits = pat->col_bits;
+    a.n_codes = pat->n_codes;
+    a.vals = pat->vals;
+    a.n_mats = pat->n_mats;
+    for (int k = 0; k < NT; ++k) {
+        a.dict[k] = pat->vals ? nullptr : pat->dict + (size_t)t[k].mat * pat->n_codes * pat->rows_per_unit;
+        a.tri[k] = t[k].tri;
+        a.mat[k] = t[k].mat;
+    }
+    return pat->rows_per_unit == 2 ? launch_ghost_only<NT, 2>(st, a, pat->K, lo, hi)
+                                   : launch_ghost_only<NT, 1>(st, a, pat->K, lo, hi);
+}
+
 __global__ __launch_bounds__(256) void interleave_ghosts_kernel(int32_t M, const double *__restrict__ lo,
                                                                 const double *__restrict__ hi,
                                                                 double2 *__restrict__ gh)
@@ -379,6 +550,21 @@ template <int NT, int K, bool GHOST, int BS, int RP>
 int launch_npf(hipStream_t st, const PackArgs<NT> &a, unsigned grid, size_t lds)
 {
     const int npf = (a.R * K + BS - 1) / BS;
+    if constexpr (RP == 2) {
+        if (a.vals != nullptr) {  // explicit values: pairs only (the one-row plain form is kron_ell.hip)
+            if (npf <= 1)
+                hipLaunchKernelGGL((kron_pack_kernel<NT, K, 1, GHOST, BS, false, RP, false>), dim3(grid), dim3(BS), lds,
+                                   st, a);
+            else if (npf <= 2)
+                hipLaunchKernelGGL((kron_pack_kernel<NT, K, 2, GHOST, BS, false, RP, false>), dim3(grid), dim3(BS), lds,
+                                   st, a);
+            else
+                hipLaunchKernelGGL((kron_pack_kernel<NT, K, 4, GHOST, BS, false, RP, false>), dim3(grid), dim3(BS), lds,
+                                   st, a);
+            STK_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if constexpr (NT == 2 && K == 7 && !GHOST && BS == 512 && RP == 1) {
         if (a.diag != nullptr && npf <= 1) {
             hipLaunchKernelGGL((kron_pack_kernel<NT, K, 1, GHOST, BS, true, RP>), dim3(grid), dim3(BS), lds, st, a);
@@ -403,10 +589,13 @@ int launch(hipStream_t st, PackArgs<NT> a, int K)
     a.W = a.P + (ghost ? 1 : 0);
     a.R = BS / a.W;
     if (a.R * K > 4 * BS) a.R = 4 * BS / K;  // at most 4 prefetched words per thread
+    if (a.vals && a.R * K * RP * a.n_mats > 2 * BS) a.R = 2 * BS / (K * RP * a.n_mats);  // ... and 2 values
+    STK_REQUIRE(a.R >= 1, "stk_kron_pack_apply: a slot row of %d x %d x %d values is too wide", K, RP, a.n_mats);
     const int KS = (K + 3) & ~3;
     auto lds_of = [&](int R) {
-        return sizeof(double) * ((a.any_tri ? (size_t)NT * R * RP * (a.n_loc + 3) : 0) +
-                                 (size_t)a.n_codes * RP * NT + (size_t)NT * 3 * (a.n_loc + 2)) +
+        const size_t values = a.vals ? (size_t)R * K * RP * a.n_mats : (size_t)a.n_codes * RP * NT;
+        return sizeof(double) * ((a.any_tri ? (size_t)NT * R * RP * (a.n_loc + 3) : 0) + values +
+                                 (size_t)NT * 3 * (a.n_loc + 2)) +
                sizeof(uint32_t) * ((size_t)R * KS + (size_t)R * RP + 4) + 32;
     };
     while (a.R > 1 && lds_of(a.R) > 64 * 1024) --a.R;  // short slabs: many units per group
@@ -467,9 +656,12 @@ int dispatch(hipStream_t st, const stk_pack_pattern *pat, int32_t n_loc, int32_t
     a.col_bits = pat->col_bits;
     a.n_codes = pat->n_codes;
     a.any_tri = 0;
+    a.vals = pat->vals;
+    a.n_mats = pat->n_mats;
     for (int k = 0; k < NT; ++k) {
-        a.dict[k] = pat->dict + (size_t)t[k].mat * pat->n_codes * pat->rows_per_unit;
+        a.dict[k] = pat->vals ? nullptr : pat->dict + (size_t)t[k].mat * pat->n_codes * pat->rows_per_unit;
         a.tri[k] = t[k].tri;
+        a.mat[k] = t[k].mat;
         if (t[k].tri) a.any_tri = 1;
     }
     a.P = (n_loc + 1) / 2;
@@ -504,7 +696,8 @@ extern "C" int stk_kron_pack_apply(void *stream, const stk_pack_pattern *pat, in
 {
     const stk_timed timed_(STK_OP_KRON, stream);
     STK_REQUIRE(pat && t && x && y, "stk_kron_pack_apply: null pointer");
-    STK_REQUIRE(pat->M > 0 && pat->K >= 1 && pat->slots && pat->dict, "stk_kron_pack_apply: bad pattern");
+    STK_REQUIRE(pat->M > 0 && pat->K >= 1 && pat->slots && (pat->dict || pat->vals), "stk_kron_pack_apply: bad pattern");
+    STK_REQUIRE(!pat->vals || pat->rows_per_unit == 2, "stk_kron_pack_apply: explicit values need row pairs");
     STK_REQUIRE(pat->rows_per_unit == 1 || pat->rows_per_unit == 2,
                 "stk_kron_pack_apply: rows_per_unit=%d is not 1 or 2", pat->rows_per_unit);
     STK_REQUIRE(pat->n_units > 0 && (int64_t)pat->n_units * pat->rows_per_unit >= pat->M &&
@@ -513,7 +706,7 @@ extern "C" int stk_kron_pack_apply(void *stream, const stk_pack_pattern *pat, in
                 pat->n_units, pat->rows_per_unit, pat->M);
     STK_REQUIRE(pat->col_bits >= 1 && pat->col_bits <= 31 && ((int64_t)1 << pat->col_bits) >= pat->M,
                 "stk_kron_pack_apply: col_bits=%d cannot address %d columns", pat->col_bits, pat->M);
-    STK_REQUIRE(pat->n_codes >= 1 && (int64_t)pat->n_codes <= ((int64_t)1 << (32 - pat->col_bits)),
+    STK_REQUIRE(pat->vals || (pat->n_codes >= 1 && (int64_t)pat->n_codes <= ((int64_t)1 << (32 - pat->col_bits))),
                 "stk_kron_pack_apply: %d codes do not fit %d bits", pat->n_codes, 32 - pat->col_bits);
     STK_REQUIRE(n_loc > 0 && ld >= n_loc && (ld & 1) == 0,
                 "stk_kron_pack_apply: bad sizes n_loc=%d ld=%d (ld must be even)", n_loc, ld);
@@ -550,4 +743,30 @@ extern "C" int stk_kron_pack_set_diag(unsigned long long *buf)
 {
     g_pack_diag = buf;
     return 0;
+}
+
+extern "C" int stk_kron_pack_ghost_apply(void *stream, const stk_pack_pattern *pat, int32_t n_loc, int32_t ld,
+                                         int32_t n_terms, const stk_kron_pack_term *t, const double *x_lo,
+                                         const double *x_hi, double *y)
+{
+    const stk_timed timed_(STK_OP_KRON, stream);
+    STK_REQUIRE(pat && t && y, "stk_kron_pack_ghost_apply: null pointer");
+    if (!x_lo && !x_hi) return 0;
+    STK_REQUIRE(pat->M > 0 && pat->K >= 1 && pat->slots && (pat->dict || pat->vals) && pat->n_units > 0,
+                "stk_kron_pack_ghost_apply: bad pattern");
+    STK_REQUIRE(pat->rows_per_unit == 1 || (pat->rows_per_unit == 2 && pat->row_ids),
+                "stk_kron_pack_ghost_apply: rows_per_unit=%d", pat->rows_per_unit);
+    STK_REQUIRE(n_loc > 0 && ld >= n_loc, "stk_kron_pack_ghost_apply: bad sizes n_loc=%d ld=%d", n_loc, ld);
+    STK_REQUIRE(n_terms >= 1 && n_terms <= 3, "stk_kron_pack_ghost_apply: n_terms=%d not in 1..3", n_terms);
+    STK_REQUIRE(pat->vals || sizeof(double) * (size_t)pat->n_codes * pat->rows_per_unit * n_terms <= 60 * 1024,
+                "stk_kron_pack_ghost_apply: dictionary too large");
+    for (int k = 0; k < n_terms; ++k)
+        STK_REQUIRE(t[k].mat >= 0 && t[k].mat < pat->n_mats, "stk_kron_pack_ghost_apply: term %d names matrix %d of %d",
+                    k, t[k].mat, pat->n_mats);
+    hipStream_t st = stk_stream(stream);
+    switch (n_terms) {
+        case 1: return dispatch_ghost_only<1>(st, pat, n_loc, ld, t, x_lo, x_hi, y);
+        case 2: return dispatch_ghost_only<2>(st, pat, n_loc, ld, t, x_lo, x_hi, y);
+        default: return dispatch_ghost_only<3>(st, pat, n_loc, ld, t, x_lo, x_hi, y);
+    }
 }

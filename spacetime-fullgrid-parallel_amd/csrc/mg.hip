@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <vector>
 
@@ -128,6 +129,9 @@ struct stk_mg {
     int Lc = -1;
     // device arrays the plan owns (plans built by stk_mg_create_from_csr)
     std::vector<void *> adopted;
+    // -1: follow the process-wide tuning key "mg_fuse_restrict"; 0 / 1: this plan's
+    // own choice (stk_mg_set_option; 0 is part of the reference-arithmetic mode)
+    int fuse_restrict = -1;
 };
 
 // The ELL row engine needs 16-byte time pairs (even ld) and slabs below 64 GiB.
@@ -289,7 +293,8 @@ static int mgm(stk_mg *mg, hipStream_t st, int j, int n_loc, int ld, double ca, 
     double *r_j = mg->r[j], *d_c = mg->f[j - 1], *u_c = mg->u[j - 1];
     const EllLevel &E = mg->ell[j];
     const bool even = ell_slab_ok(L.n, ld);
-    if (g_mg_fuse_restrict && E.has_ra && E.has_r && even) {
+    const bool fuse_restrict = mg->fuse_restrict >= 0 ? mg->fuse_restrict != 0 : g_mg_fuse_restrict != 0;
+    if (fuse_restrict && E.has_ra && E.has_r && even) {
         // d_c = R (A_j u_j - f_j) = (R A_j) u_j - R f_j: the fine residual is never written
         rc = stk_rows_ell_launch(st, 0, &E.r, 0, E.r.n_pos, n_loc, ld, L.n, C.n, 1.0, nullptr, f_j, 1.0, 0.0, nullptr,
                                  d_c);
@@ -457,6 +462,17 @@ extern "C" int stk_mg_destroy(stk_mg *mg)
     stk_coarse_plan_free(mg->coarse);
     delete mg;
     return 0;
+}
+
+extern "C" int stk_mg_set_option(stk_mg *mg, const char *key, int32_t value)
+{
+    STK_REQUIRE(mg && key, "stk_mg_set_option: null pointer");
+    if (std::strcmp(key, "fuse_restrict") == 0) {
+        mg->fuse_restrict = value < 0 ? -1 : (value != 0);
+        return 0;
+    }
+    stk_set_error("stk_mg_set_option: unknown key '%s' (fuse_restrict)", key);
+    return 2;
 }
 
 extern "C" int stk_mg_apply(stk_mg *mg, void *stream, int32_t n_loc, int32_t ld, double ca, const double *cm,

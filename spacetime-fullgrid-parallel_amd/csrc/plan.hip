@@ -50,6 +50,58 @@ extern "C" int32_t stk_pack_unit_slots(int32_t K, int32_t rp)
 // for M units): ucols [units][K_out] (ascending union, unused slots = the first
 // row's own column), ucodes [units][K_out][rp] (zero_code where a row has no
 // entry in the column), urows [units][rp] (-1: no row).
+// Row pairs need rows that follow each other in the processing order to share
+// columns.  A mesh-tile order of a structured mesh has that by itself (x-neighbours
+// are consecutive); the order of an unstructured mesh does not.  This walks the
+// given order and moves, behind every row that has not been placed yet, ONE of its
+// not yet placed neighbours (a column of the row) whose union of columns with it
+// fits K_out slots -- the nearest one in the given order, at most `window`
+// positions away, so that the locality of the order survives.  perm[q] = position
+// (in the given order) of the row that goes to position q of the new order.
+extern "C" int stk_pack_match_order(int32_t M, int32_t K, const int32_t *counts, const int32_t *cols,
+                                    const int32_t *own, int32_t K_out, int32_t window, int32_t *perm)
+{
+    STK_REQUIRE(M > 0 && K >= 1 && counts && cols && own && perm && K_out >= K && window >= 1,
+                "stk_pack_match_order: bad arguments");
+    std::vector<int32_t> pos_of((size_t)M, -1);
+    for (int32_t p = 0; p < M; ++p) {
+        STK_REQUIRE(own[p] >= 0 && own[p] < M && pos_of[own[p]] < 0, "stk_pack_match_order: own is not a permutation");
+        pos_of[own[p]] = p;
+    }
+    std::vector<char> placed((size_t)M, 0);
+    int32_t q = 0;
+    for (int32_t p = 0; p < M; ++p) {
+        if (placed[p]) continue;
+        placed[p] = 1;
+        perm[q++] = p;
+        const int32_t *ca = cols + (size_t)p * K;
+        const int na = counts[p];
+        int32_t best = -1, best_dist = window + 1;
+        for (int e = 0; e < na; ++e) {
+            const int32_t c = ca[e];
+            if (c < 0 || c >= M) continue;
+            const int32_t pc = pos_of[c];
+            if (pc == p || placed[pc]) continue;
+            const int32_t dist = pc > p ? pc - p : p - pc;
+            if (dist >= best_dist) continue;
+            // size of the union of the two sorted column lists
+            const int32_t *cb = cols + (size_t)pc * K;
+            const int nb = counts[pc];
+            int ia = 0, ib = 0, m = 0;
+            while (ia < na || ib < nb) {
+                const int32_t va = ia < na ? ca[ia] : INT32_MAX, vb = ib < nb ? cb[ib] : INT32_MAX;
+                ia += va <= vb, ib += vb <= va, ++m;
+            }
+            if (m <= K_out) best = pc, best_dist = dist;
+        }
+        if (best >= 0) {
+            placed[best] = 1;
+            perm[q++] = best;
+        }
+    }
+    return 0;
+}
+
 extern "C" int stk_pack_group_rows(int32_t M, int32_t K, const int32_t *counts, const int32_t *cols,
                                    const int32_t *codes, const int32_t *own, int32_t zero_code, int32_t rp,
                                    int32_t K_out, int32_t *n_units, int32_t *ucols, int32_t *ucodes, int32_t *urows)

@@ -102,11 +102,19 @@ class SchurMPI(LinearOperatorMPI):
             # packed matrix stream, ghost time steps fused into the one pass
             # (csrc/kron_pack.hip); the halo has to be there first
             ghosts = None
-            if self.dofs_distr.size > 1:
-                self.time_communication = vec_in.communicate_bdr()
+            first = [(self.tA, 0), (self.tL, 1)]
+            if self.dofs_distr.size > 1 and not vec_in.communicated_bdr:
+                # the pass over the slab without the ghost steps while the halo is
+                # in flight (reference mpi_kron.py:193-200), their share afterwards
+                self.time_communication = vec_in.communicate_bdr(
+                    callback=lambda: packed.apply(first, x, None, n_loc, ld, 0.0, u))
+                packed.apply_ghost(first, vec_in.X_lo, vec_in.X_hi, n_loc, ld, u)
                 ghosts = vec_in.ghost_interleaved()
-            packed.apply([(self.tA, 0), (self.tL, 1)], x, ghosts, n_loc, ld,
-                         0.0, u)
+            else:
+                if self.dofs_distr.size > 1:
+                    self.time_communication = vec_in.communicate_bdr()
+                    ghosts = vec_in.ghost_interleaved()
+                packed.apply(first, x, ghosts, n_loc, ld, 0.0, u)
             v1 = self.Kinv_x.apply(u, n_loc=n_loc)
             packed.apply([(self.tLT, 0), (self.tM, 1)], x, ghosts, n_loc, ld,
                          0.0, u)
@@ -148,10 +156,11 @@ class HeatEquationMPI:
     matrix, as reference heateq_mpi.py:147-153 does.
 
     arithmetic='reference' = schur='reference' + family='reference' + Gauss-Seidel
-    rows with their diagonal (u_i += (f_i - row_i u) / a_ii, multigrid.py:89-97):
-    every regrouping this build adds is switched off, what remains against the
-    CPU path is the order of additions inside dot products and fused multiply-adds
-    (DESIGN.md section 5)."""
+    rows with their diagonal (u_i += (f_i - row_i u) / a_ii, multigrid.py:89-97) +
+    the restricted residual as R (A u - f) (multigrid.py:174-175) instead of
+    (R A) u - R f: every regrouping this build adds is switched off, what remains
+    against the CPU path is the order of additions inside dot products and fused
+    multiply-adds."""
     def __init__(self,
                  J_space=2,
                  J_time=None,
@@ -217,12 +226,14 @@ class HeatEquationMPI:
             # one hierarchy per wavelet level from the assembled matrix
             # (reference heateq_mpi.py:147-153)
             self.u0_x = space_load(mesh_space, data['u0'])
+            fuse = False if arithmetic == 'reference' else None
             self.Kinv_x = MultiGrid(self.A_x, hierarchy, smoothsteps=smoothsteps,
-                                    vcycles=vcycles)
+                                    vcycles=vcycles, fuse_restrict=fuse)
             self.C_family = None
             self.C_j = [
                 MultiGrid(2**j * self.M_x + alpha * self.A_x, hierarchy,
-                          smoothsteps=smoothsteps, vcycles=vcycles)
+                          smoothsteps=smoothsteps, vcycles=vcycles,
+                          fuse_restrict=fuse)
                 for j in range(self.J_time + 1)
             ]
         elif precond == 'multigrid':

@@ -44,11 +44,15 @@ class PackPattern(ctypes.Structure):
     _fields_ = [('M', c_i32), ('K', c_i32), ('col_bits', c_i32),
                 ('n_codes', c_i32), ('n_mats', c_i32),
                 ('rows_per_unit', c_i32), ('n_units', c_i32), ('slots', c_p),
-                ('row_ids', c_p), ('dict', c_p)]
+                ('row_ids', c_p), ('dict', c_p), ('vals', c_p)]
 
 
 class KronPackTerm(ctypes.Structure):
     _fields_ = [('tri', c_p), ('mat', c_i32)]
+
+
+class CommMsg(ctypes.Structure):
+    _fields_ = [('buf', c_p), ('count', c_i64), ('peer', c_i32)]
 
 
 class EllRows(ctypes.Structure):
@@ -108,6 +112,13 @@ _PROTOTYPES = {
     'stk_slab_extract_time_rows': (ctypes.c_int, [c_p, c_i32, c_i32, c_p, c_p, c_i32, c_p, c_i64]),
     'stk_copy_block': (ctypes.c_int, [c_p, c_i64, c_i32, c_p, c_i64, c_p, c_i64]),
     'stk_outer': (ctypes.c_int, [c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p]),
+    'stk_comm_unique_id': (ctypes.c_int, [c_p]),
+    'stk_comm_create': (ctypes.c_int, [c_i32, c_i32, c_p, ctypes.POINTER(c_p)]),
+    'stk_comm_destroy': (ctypes.c_int, [c_p]),
+    'stk_comm_allreduce_sum': (ctypes.c_int, [c_p, c_p, c_p, c_i32]),
+    'stk_comm_halo_exchange': (ctypes.c_int, [c_p, c_p, c_i32, c_p, c_p, c_p, c_p]),
+    'stk_comm_exchange': (ctypes.c_int, [c_p, c_p, c_i32, ctypes.POINTER(CommMsg), c_i32,
+                                         ctypes.POINTER(CommMsg)]),
     'stk_timing_enable': (ctypes.c_int, [c_i32]),
     'stk_timing_reset': (ctypes.c_int, []),
     'stk_timing_get': (ctypes.c_int, [ctypes.c_char_p, c_p, c_p]),
@@ -129,12 +140,17 @@ _PROTOTYPES = {
         ctypes.POINTER(KronEllTerm), c_p
     ]),
     'stk_pack_unit_slots': (c_i32, [c_i32, c_i32]),
+    'stk_pack_match_order': (ctypes.c_int, [c_i32, c_i32, c_p, c_p, c_p, c_i32, c_i32, c_p]),
     'stk_pack_group_rows': (ctypes.c_int, [
         c_i32, c_i32, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p
     ]),
     'stk_kron_pack_apply': (ctypes.c_int, [
         c_p, ctypes.POINTER(PackPattern), c_i32, c_i32, c_i32,
         ctypes.POINTER(KronPackTerm), c_p, c_p, c_f64, c_p
+    ]),
+    'stk_kron_pack_ghost_apply': (ctypes.c_int, [
+        c_p, ctypes.POINTER(PackPattern), c_i32, c_i32, c_i32,
+        ctypes.POINTER(KronPackTerm), c_p, c_p, c_p
     ]),
     'stk_interleave_ghosts': (ctypes.c_int, [c_p, c_i32, c_p, c_p, c_p]),
     'stk_kron_plan_create': (ctypes.c_int, [
@@ -175,6 +191,7 @@ _PROTOTYPES = {
         c_i32, ctypes.POINTER(c_p)
     ]),
     'stk_mg_destroy': (ctypes.c_int, [c_p]),
+    'stk_mg_set_option': (ctypes.c_int, [c_p, ctypes.c_char_p, c_i32]),
     'stk_mg_apply': (ctypes.c_int,
                      [c_p, c_p, c_i32, c_i32, c_f64, c_p, c_p, c_p, c_p]),
     'stk_mg_smooth': (ctypes.c_int, [

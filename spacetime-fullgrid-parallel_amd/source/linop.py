@@ -487,6 +487,8 @@ class PackedEllMatrices:
     def __init__(self, M, K, ell_idx, ell_vals, row_ids, has_overflow,
                  counts=None, own=None, rows_per_unit=1):
         self.ok = False
+        self.explicit = False
+        self.rows_per_unit = rows_per_unit
         if has_overflow or M < 1:
             return
         K_out = K
@@ -495,17 +497,63 @@ class PackedEllMatrices:
             if K_out == 0 or counts is None:
                 return
         col_bits = max(1, int(M - 1).bit_length())
+        built = self._with_dictionary(M, K, K_out, col_bits, ell_idx, ell_vals,
+                                      counts, own, rows_per_unit)
+        if built is None and rows_per_unit == 2 and self.EXPLICIT_PAIRS:
+            # values that do not repeat (an unstructured mesh): no dictionary, but
+            # neighbouring rows still share COLUMNS -- pairs with explicit values
+            built = self._with_explicit_values(M, K, K_out, ell_idx, ell_vals,
+                                               counts, own)
+        if built is None:
+            return
+        cols, codes, table, unit_rows, vals = built
+        self.ok = True
+        self.explicit = vals is not None
+        self.rows_per_unit = rows_per_unit
+        self.n_units, self.K = cols.shape
+        self.M, self.col_bits = M, col_bits
+        self.n_mats = len(ell_vals)
+        self.row_ids = row_ids if unit_rows is None else _lib.to_dev(unit_rows)
+        self.dict = self.vals = None
+        if vals is not None:
+            self.n_codes = 1
+            self.slots = _lib.to_dev(cols.astype(np.uint32).view(np.int32).reshape(cols.shape))
+            self.vals = _lib.to_dev(vals)
+        else:
+            self.n_codes = len(table)
+            slots = (codes.reshape(-1).astype(np.uint32) << np.uint32(col_bits)
+                     ) | cols.reshape(-1).astype(np.uint32)
+            self.slots = _lib.to_dev(slots.view(np.int32).reshape(cols.shape))
+            # dict[m][code][row of the unit]
+            self.dict = _lib.to_dev(np.ascontiguousarray(
+                table.reshape(len(table), rows_per_unit, self.n_mats).transpose(
+                    2, 0, 1)).view(np.float64))
+        self.pattern = _lib.PackPattern(M, self.K, col_bits, self.n_codes,
+                                        self.n_mats, rows_per_unit,
+                                        self.n_units, _lib.ptr(self.slots),
+                                        _lib.ptr(self.row_ids),
+                                        _lib.ptr(self.dict), _lib.ptr(self.vals))
+
+    # Row pairs with explicit values for matrices without a dictionary (False:
+    # such matrices keep the one-row plain form, stk_kron_ell_apply).
+    EXPLICIT_PAIRS = True
+    MATCH_WINDOW = 8192  # positions of the processing order a row's partner may come from
+
+    def _with_dictionary(self, M, K, K_out, col_bits, ell_idx, ell_vals, counts,
+                         own, rows_per_unit):
+        """(columns, codes, dictionary, unit rows, None) of the packed form, or
+        None when the values do not fit a dictionary."""
         # distinct value tuples, by bit pattern (+0.0 and -0.0 stay distinct):
         # one 1-D unique per matrix, then one over the combined codes
         codes, table = np.zeros(M * K, dtype=np.int64), None
         for e in ell_vals:
             found = _few_unique(e.reshape(-1).view(np.int64), self.MAX_CODES)
             if found is None:
-                return
+                return None
             u, inv = found
             uc, codes = _small_unique(codes * len(u) + inv, self.MAX_CODES * len(u))
             if len(uc) > self.MAX_CODES:
-                return
+                return None
             col = u[uc % len(u)][:, None]
             table = col if table is None else np.hstack(
                 [table[uc // len(u)], col])
@@ -517,28 +565,48 @@ class PackedEllMatrices:
                                        codes.reshape(M, K), uniq,
                                        np.asarray(counts), np.asarray(own))
             if grouped is None:
-                return
+                return None
             cols, codes, uniq, unit_rows = grouped
         if len(uniq) > (1 << (32 - col_bits)):
-            return
-        self.ok = True
-        self.rows_per_unit = rows_per_unit
-        self.n_units, self.K = cols.shape
-        self.M, self.col_bits, self.n_codes = M, col_bits, len(uniq)
-        self.n_mats = len(ell_vals)
-        slots = (codes.reshape(-1).astype(np.uint32) << np.uint32(col_bits)
-                 ) | cols.reshape(-1).astype(np.uint32)
-        self.slots = _lib.to_dev(slots.view(np.int32).reshape(cols.shape))
-        # dict[m][code][row of the unit]
-        self.dict = _lib.to_dev(np.ascontiguousarray(
-            uniq.reshape(len(uniq), rows_per_unit, self.n_mats).transpose(
-                2, 0, 1)).view(np.float64))
-        self.row_ids = row_ids if unit_rows is None else _lib.to_dev(unit_rows)
-        self.pattern = _lib.PackPattern(M, self.K, col_bits, self.n_codes,
-                                        self.n_mats, rows_per_unit,
-                                        self.n_units, _lib.ptr(self.slots),
-                                        _lib.ptr(self.row_ids),
-                                        _lib.ptr(self.dict))
+            return None
+        return cols, codes, uniq, unit_rows, None
+
+    def _with_explicit_values(self, M, K, K_out, ell_idx, ell_vals, counts, own):
+        """(columns, None, None, unit rows, values) of the pair form without a
+        dictionary: every entry is its own "code" (its position in the ELL arrays),
+        the pairing is the one of the dictionary form (stk_pack_group_rows), and the
+        values of both rows of every slot are stored next to the columns:
+        vals[unit][slot][row][matrix], zero where a row has no entry in a column."""
+        c32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        rp = 2
+        entry = np.arange(1, M * K + 1, dtype=np.int32).reshape(M, K)  # 0 = "no entry"
+        counts, cols, own = c32(counts), c32(ell_idx.reshape(M, K)), c32(own)
+        # the processing order of an unstructured mesh does not put neighbours next
+        # to each other: move one matching neighbour behind every row first
+        # (locality window: a few mesh tiles)
+        perm = np.empty(M, dtype=np.int32)
+        _lib.check(_lib.lib().stk_pack_match_order(
+            M, K, counts.ctypes.data, cols.ctypes.data, own.ctypes.data, K_out,
+            self.MATCH_WINDOW, perm.ctypes.data))
+        counts, cols, own, entry = c32(counts[perm]), c32(cols[perm]), c32(own[perm]), c32(entry[perm])
+        ucols = np.empty((M, K_out), dtype=np.int32)
+        ucodes = np.empty((M, K_out, rp), dtype=np.int32)
+        urows = np.empty((M, rp), dtype=np.int32)
+        n_units = ctypes.c_int32()
+        _lib.check(_lib.lib().stk_pack_group_rows(
+            M, K, counts.ctypes.data, cols.ctypes.data, entry.ctypes.data,
+            own.ctypes.data, 0, rp, K_out, ctypes.byref(n_units),
+            ucols.ctypes.data, ucodes.ctypes.data, urows.ctypes.data))
+        U = n_units.value
+        if U > 0.95 * M:  # hardly any rows share a unit
+            return None
+        ucodes = ucodes[:U]
+        vals = np.empty((U, K_out, rp, len(ell_vals)))
+        for m, e in enumerate(ell_vals):
+            flat = np.concatenate([[0.0], e.reshape(-1)])
+            vals[..., m] = flat[ucodes]
+        return (ucols[:U].astype(np.int64), None, None,
+                np.ascontiguousarray(urows[:U]), np.ascontiguousarray(vals))
 
     def _group_rows(self, M, K, K_out, rp, cols, codes, uniq, counts, own):
         """Units of up to `rp` rows that follow each other in the processing
@@ -583,12 +651,26 @@ class PackedEllMatrices:
         return (ucols.astype(np.int64), ucode.reshape(U, K_out), unit_dict,
                 np.ascontiguousarray(urows))
 
-    def apply(self, specs, x, ghosts, n_loc, ld, beta, out):
-        """y = beta*y + sum over specs (tri, matrix index) applied to x;
-        `ghosts`: (M, 2) interleaved ghost time steps or None."""
+    def _terms(self, specs):
         terms = (_lib.KronPackTerm * len(specs))()
         for t, (tri, k) in zip(terms, specs):
             t.tri, t.mat = _lib.ptr(tri), k
+        return terms
+
+    def apply_ghost(self, specs, x_lo, x_hi, n_loc, ld, out):
+        """Adds what the ghost time rows contribute after `apply` ran without
+        them (ghosts=None) while the halo was in flight: x_lo / x_hi are the
+        received rows, contiguous, or None (stk_kron_pack_ghost_apply)."""
+        if x_lo is None and x_hi is None:
+            return
+        _lib.check(_lib.lib().stk_kron_pack_ghost_apply(
+            _lib.stream(), ctypes.byref(self.pattern), n_loc, ld, len(specs),
+            self._terms(specs), _lib.ptr(x_lo), _lib.ptr(x_hi), _lib.ptr(out)))
+
+    def apply(self, specs, x, ghosts, n_loc, ld, beta, out):
+        """y = beta*y + sum over specs (tri, matrix index) applied to x;
+        `ghosts`: (M, 2) interleaved ghost time steps or None."""
+        terms = self._terms(specs)
         _lib.check(_lib.lib().stk_kron_pack_apply(
             _lib.stream(), ctypes.byref(self.pattern), n_loc, ld, len(specs),
             terms, _lib.ptr(x), _lib.ptr(ghosts), beta, _lib.ptr(out)))

@@ -388,7 +388,14 @@ class _FusedKronSum:
     with plain CSR space factors: shared pattern, one launch.  use_ell selects
     the persistent sliced-ELL kernel (default) or the plain CSR one."""
     use_ell = True
-    use_pack = True  # packed matrix stream + fused ghost steps when the plan fits
+    use_pack = True  # packed matrix stream when the plan fits
+    # Several ranks, packed form: True = the pass over the slab runs WITHOUT the
+    # ghost steps while the halo exchange is in flight and a one-lane-per-row
+    # kernel adds their contribution afterwards (the reference overlaps the
+    # exchange with the interior rows, mpi_kron.py:193-200); False = wait for the
+    # halo, then one pass with the ghost steps as an extra lane per row.  A halo
+    # that is already there (cached) always takes the one-pass form.
+    overlap = True
 
     @classmethod
     def max_terms(cls):
@@ -429,11 +436,20 @@ class _FusedKronSum:
             # one pass: matrix stream packed, ghost time steps handled by an extra
             # lane per row (csrc/kron_pack.hip); the halo has to be there first
             ghosts = None
-            if self.dofs_distr.size > 1 and (self.needs_lo or self.needs_hi):
+            specs = [(self.tri[k], k) for k in range(self.n_terms)]
+            halo = self.dofs_distr.size > 1 and (self.needs_lo or self.needs_hi)
+            if halo and type(self).overlap and not vec_in.communicated_bdr:
+                time_comm = vec_in.communicate_bdr(callback=lambda: packed.apply(
+                    specs, vec_in.buf, None, vec_in.n_loc, vec_in.ld, beta,
+                    vec_out.buf))
+                packed.apply_ghost(specs, vec_in.X_lo if self.needs_lo else None,
+                                   vec_in.X_hi if self.needs_hi else None,
+                                   vec_in.n_loc, vec_in.ld, vec_out.buf)
+                return time_comm
+            if halo:
                 time_comm = vec_in.communicate_bdr()
                 ghosts = vec_in.ghost_interleaved()
-            packed.apply([(self.tri[k], k) for k in range(self.n_terms)],
-                         vec_in.buf, ghosts, vec_in.n_loc, vec_in.ld, beta,
+            packed.apply(specs, vec_in.buf, ghosts, vec_in.n_loc, vec_in.ld, beta,
                          vec_out.buf)
             return time_comm
         if self.use_ell:
@@ -480,9 +496,10 @@ class _FusedKronSum:
         if type(self).use_pack and self.ell.packed_for(n_loc).ok:
             ghost = self.dofs_distr.size > 1 and (self.needs_lo or self.needs_hi)
             pk = self.ell.packed_for(n_loc)
-            return 'kron_pack_kernel<%d, %d, %s, %s>' % (
+            return 'kron_pack_kernel<%d, %d, %s, %s%s>' % (
                 self.n_terms, pk.K, 'ghost lanes' if ghost else 'no ghosts',
-                'row pairs' if pk.rows_per_unit == 2 else 'single rows')
+                'row pairs' if pk.rows_per_unit == 2 else 'single rows',
+                ', explicit values' if pk.explicit else '')
         return 'kron_ell_kernel<%d, shared input, %d>' % (self.n_terms, self.ell.K)
 
     def algorithmic_bytes(self, n_loc, M):

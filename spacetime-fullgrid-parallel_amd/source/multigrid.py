@@ -166,6 +166,7 @@ class _DeviceHierarchy:
         self.n_kinds = inv.shape[0]
         self.plan = None
         self.plan_ld = 0
+        self.options = {}  # stk_mg_set_option keys of this hierarchy's plans
 
     def _fill_level(self, j, hierarchy):
         L = self.levels[j]
@@ -327,7 +328,14 @@ class _DeviceHierarchy:
             self.n_kinds, _lib.ptr(self.coarse_inv), ld,
             ctypes.byref(handle)))
         self.plan, self.plan_ld = handle, ld
+        for key, value in self.options.items():
+            _lib.check(_lib.lib().stk_mg_set_option(handle, key.encode(), int(value)))
         return self.plan
+
+    def set_option(self, key, value):
+        self.options[key] = int(value)
+        if self.plan is not None:
+            _lib.check(_lib.lib().stk_mg_set_option(self.plan, key.encode(), int(value)))
 
     def apply(self, x, out, n_loc, ca, cm, kind):
         ld = x.shape[1]
@@ -355,7 +363,8 @@ class MultiGrid(SpaceOp):
     family = None
     member = None
 
-    def __init__(self, mat, hierarchy, smoothsteps=2, vcycles=1):
+    def __init__(self, mat, hierarchy, smoothsteps=2, vcycles=1,
+                 fuse_restrict=None):
         self.num_applies = 0
         self.time_applies = 0
         self.hierarchy = hierarchy
@@ -363,6 +372,10 @@ class MultiGrid(SpaceOp):
         self.vcycles = vcycles
         self._dev = _DeviceHierarchy(mat, None, hierarchy, smoothsteps,
                                      vcycles, lambda a0, m0: [a0])
+        if fuse_restrict is not None:
+            # False: the restricted residual as the reference forms it,
+            # R (A u - f) (multigrid.py:174-175); see stk_mg_set_option
+            self._dev.set_option('fuse_restrict', bool(fuse_restrict))
         self.mats = self._dev.mats_a
         self.shape = self.mats[-1].shape
         self.dtype = np.float64

@@ -34,6 +34,28 @@ def lshape(J_space, J_time=None):
     return mesh_space, bc, _time_mesh(J_space, J_time), data, "lshape"
 
 
+def jitter(mesh, rel=0.2, seed=0):
+    """Moves every interior vertex by up to `rel` times the shortest edge (seeded):
+    the triangulation keeps its topology and hierarchy, but no two elements are
+    congruent any more, so no two entries of M_x or A_x repeat -- an "unstructured
+    mesh, irregular CSR" in the sense of BASELINE.json config 4 for the kernels
+    that otherwise live on repeated values (dictionary form of the Kronecker
+    apply)."""
+    pts, tris = mesh.points, mesh.tris
+    e = np.concatenate([pts[tris[:, a]] - pts[tris[:, b]] for a, b in ((0, 1), (1, 2), (2, 0))])
+    h = np.sqrt((e * e).sum(axis=1)).min()
+    rng = np.random.RandomState(seed)
+    move = rel * h * (2.0 * rng.rand(*pts.shape) - 1.0)
+    move[mesh.boundary] = 0.0
+    mesh.points = pts + move
+    return mesh
+
+
+def lshape_jitter(J_space, J_time=None):
+    mesh_space, bc, mesh_time, data, _ = lshape(J_space, J_time)
+    return jitter(mesh_space), bc, mesh_time, data, "lshape_jitter"
+
+
 def _u0_3d(x, y, z):
     return np.sin(np.pi * x) * np.sin(np.pi * y) * np.sin(np.pi * z)
 
@@ -49,6 +71,8 @@ def problem_helper(problem, J_space, J_time=None):
         return square(J_space, J_time)
     elif problem == 'lshape':
         return lshape(J_space, J_time)
+    elif problem == 'lshape_jitter':
+        return lshape_jitter(J_space, J_time)
     elif problem == 'cube':
         return cube(J_space, J_time)
     else:

@@ -81,6 +81,27 @@ def test_rccl_backend_executes_on_one_rank():
 
 
 @pytest.mark.gpu
+def test_c_abi_communication(tmp_path):
+    """stk_comm_* (the neighbour exchange and the scalar all-reduce for
+    a host without torch.distributed; RCCL loaded by libstk itself) through
+    ctypes: one rank on the test box's GPU (self-addressed messages really travel
+    through RCCL), one rank per GPU where two are visible."""
+    import torch
+    ranks = [1] + ([2] if torch.cuda.device_count() >= 2 else [])
+    for n in ranks:
+        id_file = str(tmp_path / ('rccl_id_%d' % n))
+        procs = []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(n), LOCAL_RANK=str(r),
+                       STK_COMM_ID_FILE=id_file)
+            procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, 'mp_ccomm_worker.py')],
+                                          env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        for r, pr in enumerate(procs):
+            out, _ = pr.communicate(timeout=300)
+            assert pr.returncode == 0 and 'mp_ccomm_worker ok' in out, out[-3000:]
+
+
+@pytest.mark.gpu
 def test_distributed_solve_over_rccl_on_two_gpus():
     """The same worker with one rank per GPU and backend nccl (= RCCL over xGMI):
     ghost-row send/recv, wavelet partner exchange and the scalar all-reduce on

@@ -41,6 +41,27 @@ def _dd(N, M):
     return DofDistributionMPI(Comm(distributed=False), N, M)
 
 
+def _hist_dev(tag, hist, ref, tol):
+    """Largest relative deviation of a residual history from the reference's,
+    entry by entry; asserted against `tol` and written to
+    gpurun_out/parity_history_dev.json (the source of the bounds quoted in
+    DESIGN.md section 5: every bound in this file is the north star's 1e-10 or,
+    where the measured deviation is larger, about twice the measured one)."""
+    import json
+    import os
+    hist, ref = np.asarray(hist, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    assert hist.shape == ref.shape, (tag, hist.shape, ref.shape)
+    dev = float(np.max(np.abs(hist / ref - 1.0))) if len(ref) else 0.0
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    if os.path.isdir(out):
+        path = os.path.join(out, 'parity_history_dev.json')
+        rec = json.load(open(path)) if os.path.exists(path) else {}
+        rec[tag] = {'max_rel_dev': dev, 'entries': int(len(ref)), 'asserted_bound': tol}
+        json.dump(rec, open(path, 'w'), indent=1, sort_keys=True)
+    assert dev < tol, (tag, dev, tol)
+    return dev
+
+
 # ---------------------------------------------------------------------------
 def test_blas1_and_dot(stk):
     rng = np.random.RandomState(0)
@@ -254,8 +275,8 @@ def test_heat_operators_and_solve_match_reference_golden(stk, g3, schur):
     rr = []
     w, iters = PCG(WT_S_W, P, rhs, callback=lambda w, r, k: rr.append(r.dot(r)))
     assert iters == int(g3['pcg_iters_multigrid'])
-    assert np.allclose(rr, g3['pcg_rr_multigrid'], rtol=1e-8, atol=1e-24)
-    assert relerr(_np(w), g3['pcg_w_multigrid']) < 1e-8
+    _hist_dev('golden_%d_%d_%s_rr' % (N, M, schur), rr, g3['pcg_rr_multigrid'], 1e-10)
+    assert relerr(_np(w), g3['pcg_w_multigrid']) < 1e-10
     w2, it2 = PCG(S, IdentityMPI(dd), rhs, kmax=60)
     assert it2 == int(g3['pcg_unprec_iters_multigrid'])
     assert relerr(_np(w2), g3['pcg_unprec_w_multigrid']) < 1e-6
@@ -293,8 +314,8 @@ def test_driver_end_to_end_against_oracle(stk, problem, J_space):
     hist = []
     w, it = PCG(h.WT_S_W, h.P, h.rhs, history=hist)
     assert it == it_o
-    assert np.allclose(hist, hist_o, rtol=1e-8, atol=1e-26)
-    assert relerr(_np(w), wo) < 1e-8
+    _hist_dev('driver_%s_J%d' % (problem, J_space), hist, hist_o, 1e-10)
+    assert relerr(_np(w), wo) < 1e-10
 
 
 def test_full_size_properties(stk):
@@ -427,8 +448,8 @@ def test_direct_preconditioner_matches_reference_golden(stk, g3):
     w, iters = PCG(WT_S_W, P, _vec(dd, g3['rhs']),
                    callback=lambda w, r, k: rr.append(r.dot(r)))
     assert iters == int(g3['pcg_iters_direct'])
-    assert np.allclose(rr, g3['pcg_rr_direct'], rtol=1e-6, atol=1e-24)
-    assert relerr(_np(w), g3['pcg_w_direct']) < 1e-7
+    _hist_dev('golden_%d_%d_direct_rr' % (N, M), rr, g3['pcg_rr_direct'], 1e-9)
+    assert relerr(_np(w), g3['pcg_w_direct']) < 1e-9
 
 
 def test_mat_kron_identity_and_original_wavelet_mode(stk):
@@ -563,7 +584,8 @@ def test_coarse_subcycle_variants_agree(stk):
 # stores R M P and R A P once and combines them per time slice (exactly the
 # assembled entries on the finest level, one rounding apart on the coarse ones),
 # and the conditioning of the level problems turns that ulp into 1e-11.
-HIST_RTOL = 1e-9
+HIST_RTOL = 1e-9              # fast default: twice the largest deviation measured (4.6e-10)
+HIST_RTOL_REFERENCE = 1e-10   # arithmetic='reference': the north star's bound, per entry
 HIST_RTOL_VS_INITIAL = 1e-10
 
 
@@ -595,22 +617,32 @@ def _bench_vector(N, M):
     return X
 
 
+@pytest.mark.parametrize('arithmetic', ['fast', 'reference'])
 @pytest.mark.parametrize('problem,J_space,J_time', [('square', 6, 3),
                                                     ('square', 8, 5),
                                                     ('square', 9, 6),
                                                     ('lshape', 8, 5)])
-def test_baseline_configs_solve_matches_oracle_trajectory(stk, problem, J_space, J_time):
+def test_baseline_configs_solve_matches_oracle_trajectory(stk, problem, J_space, J_time, arithmetic):
     """BASELINE.json configs 1-4 at full size, the whole solve as the
     reference's integration test compares it (heateq_mpi_test.py:138-189):
     iteration count EQUAL to the CPU oracle's, every r.Pr of the history within
-    HIST_RTOL, the solution on the fixture's sample, plus S, P and W applied
+    the bound, the solution on the fixture's sample, plus S, P and W applied
     to the bench's vector on the same sample.  The oracle trajectories are
     fixtures (tests/golden/make_oracle_vectors.py; config 3 takes 11 minutes on
-    6 host threads)."""
+    6 host threads).
+
+    arithmetic='reference' (every regrouping of the build switched off:
+    five-term S, one hierarchy per wavelet level from the assembled matrix,
+    Gauss-Seidel rows with their diagonal, restricted residual as R (A u - f))
+    is held to the north star's 1e-10 on EVERY entry; measured 7e-12 .. 2.1e-11
+    (profiles/r03_history_attribution.json).  The fast default is held to 1e-9 per
+    entry = twice what it measures (4.6e-10), and to 1e-10 relative to the
+    initial residual; DESIGN.md section 5 attributes the difference."""
     import heateq_mpi as hm
     from source.linalg import PCG
     g = load_golden('o1_pcg_%s_J%d_J%d' % (problem, J_time, J_space))
-    h = hm.HeatEquationMPI(J_space=J_space, J_time=J_time, problem=problem)
+    h = hm.HeatEquationMPI(J_space=J_space, J_time=J_time, problem=problem,
+                           arithmetic=arithmetic)
     st, sx = (int(v) for v in g['sample_strides'])
     x = _vec(h.dofs_distr, _bench_vector(h.N, h.M))
     assert relerr(_np(h.W @ x)[::st, ::sx], g['WX_sample']) < 1e-13
@@ -620,11 +652,12 @@ def test_baseline_configs_solve_matches_oracle_trajectory(stk, problem, J_space,
     hist = []
     w, it = PCG(h.WT_S_W, h.P, h.rhs, history=hist)
     assert it == int(g['iters']), (it, int(g['iters']))
-    dev = _record_history_dev('%s_J%d_J%d' % (problem, J_time, J_space), hist, g['hist'])
-    assert dev < HIST_RTOL, dev
+    tag = '%s_J%d_J%d' % (problem, J_time, J_space) + ('' if arithmetic == 'fast' else '_reference_arithmetic')
+    dev = _record_history_dev(tag, hist, g['hist'])
+    assert dev < (HIST_RTOL if arithmetic == 'fast' else HIST_RTOL_REFERENCE), dev
     wn = _np(w)
     assert abs(np.linalg.norm(wn) - g['w_norm']) < 1e-10 * g['w_norm']
-    assert relerr(wn[::st, ::sx], g['w_sample']) < 1e-9
+    assert relerr(wn[::st, ::sx], g['w_sample']) < (1e-9 if arithmetic == 'fast' else 1e-10)
 
 
 @pytest.mark.parametrize('problem,J_space,J_time', [('square', 9, 6),
@@ -744,8 +777,8 @@ def test_serial_driver_against_oracle(stk, precond):
     w, iters = PCG(h.WT_S_W, h.P, h.WT @ h.f, history=hist)
     wo, iters_o, hist_o = pcg(o.WT_S_W, o.P, o.WT(o.f()))
     assert iters == iters_o
-    assert np.allclose(hist, hist_o, rtol=1e-7, atol=1e-26)
-    assert relerr(w, wo) < 1e-7
+    _hist_dev('serial_driver_%s' % precond, hist, hist_o, 1e-9 if precond == 'direct' else 1e-10)
+    assert relerr(w, wo) < 1e-9
     # the parallel driver builds the same Schur complement from five terms
     hp = hm.HeatEquationMPI(J_space=J_space, J_time=J_time, precond=precond)
     xv = _vec(hp.dofs_distr, x.reshape(h.N, h.M))
@@ -798,8 +831,10 @@ def test_c_pcg_solve_matches_python_pcg(stk):
                                 stk.ptr(w.buf), 1e-6, kmax, stk.ptr(work),
                                 history, ctypes.byref(iters)))
     assert iters.value == it_py
-    assert np.allclose(list(history)[:it_py + 1], hist_py, rtol=1e-9, atol=1e-28)
-    assert relerr(_np(w), _np(w_py)) < 1e-9
+    # the same kernels driven from C instead of Python: the recurrences only differ
+    # in where the scalars are combined
+    _hist_dev('c_pcg_vs_python_pcg', list(history)[:it_py + 1], hist_py, 1e-11)
+    assert relerr(_np(w), _np(w_py)) < 1e-11
 
 
 def test_c_lanczos_matches_python_lanczos(stk):
@@ -1165,12 +1200,118 @@ def test_kron_pack_row_pairs(stk):
             assert relerr(y2[:, :n_loc].cpu().numpy(), want) < 1e-13, (name, n_loc, nt)
             if ld > n_loc:
                 assert float(y2[:, n_loc:].abs().max()) == 0.0
+            # the overlapped form of several ranks (reference mpi_kron.py:193-200): the
+            # pass WITHOUT the ghost steps, then their share from the received rows as
+            # they arrive (stk_kron_pack_ghost_apply) -- the same sums, regrouped
+            if gh is not None:
+                dev_lo = None if lo is None else torch.from_numpy(lo).cuda()
+                dev_hi = None if hi is None else torch.from_numpy(hi).cuda()
+                for form in (one, two):
+                    y3 = slab(y0)
+                    form.apply(specs, x, None, n_loc, ld, beta, y3)
+                    form.apply_ghost(specs, dev_lo, dev_hi, n_loc, ld, y3)
+                    assert relerr(y3[:, :n_loc].cpu().numpy(), want) < 1e-13, (name, n_loc, nt)
+                    assert float((y3 - y2).abs().max()) <= 1e-13 * float(y2.abs().max())
+                    if ld > n_loc:
+                        assert float(y3[:, n_loc:].abs().max()) == 0.0
     assert seen_pairs > 0
     # rows that share nothing stay alone: the planner keeps the one-row form
     circ = lambda k: sp.csr_matrix((np.ones(64), (np.arange(64), (np.arange(64) + k) % 64)), shape=(64, 64))
     scattered = sp.csr_matrix(circ(0) + circ(13) + circ(-13) + circ(29) + circ(-29))
     e = EllMatrices([scattered])
     assert e.packed.ok and e.packed.rows_per_unit == 1
+
+
+def test_kron_pack_explicit_value_pairs(stk):
+    """Row pairs WITHOUT a dictionary (stk_pack_pattern.vals): matrices whose
+    values do not repeat -- P1 on a jittered L-shape (BASELINE config 4's
+    "unstructured spatial mesh, irregular CSR"; the reference takes any CSR,
+    mpi_kron.py:135-150) and banded matrices with random entries.  The planner
+    must take the explicit form, rows must really be paired, and the result must
+    be bit for bit that of the one-row plain form (stk_kron_ell_apply: same
+    accumulation order, absent columns add exact zeros) and agree with dense
+    NumPy; ghost lanes, the overlapped ghost share, 1-3 terms, beta, slab lengths
+    through the lane / group / prefetch instances."""
+    from source.assembly import space_matrices
+    from source.linop import EllMatrices
+    from source.problem import problem_helper
+    rng = np.random.RandomState(321)
+    families = []
+    for J in (2, 4):
+        M_x, A_x = space_matrices(problem_helper('lshape_jitter', J_space=J, J_time=2)[0])
+        families.append(('lshape_jitter%d' % J, [M_x, A_x, sp.csr_matrix(M_x + 0.3 * A_x)]))
+    n = 23 * 17
+    offs = (-17, -1, 0, 1, 17)
+    band = sp.diags([rng.rand(n - abs(o)) + 0.1 for o in offs], offs, format='csr')
+    families.append(('band5_random', [band, sp.csr_matrix(band.T), sp.csr_matrix(band + 2.0 * band.T)]))
+    for name, mats_all in families:
+        for n_loc in (1, 2, 8, 9, 17, 33, 65, 129):
+            nt = int(rng.randint(1, 4))
+            mats = mats_all[:nt]
+            ell = EllMatrices(mats, [mats_all[0]])
+            two = ell.packed_variant(2)
+            assert two.ok and two.explicit and two.rows_per_unit == 2, (name, two.ok)
+            assert not ell.packed_variant(1).ok  # no dictionary for these values
+            M = ell.M
+            assert two.n_units < 0.7 * M and two.K in (8, 10, 12)
+            ld = n_loc + (n_loc & 1)
+            X = rng.rand(M, n_loc)
+            lo = rng.rand(M) if rng.randint(2) else None
+            hi = rng.rand(M) if rng.randint(2) else None
+            beta = float(rng.choice([0.0, 0.5]))
+            y0 = rng.rand(M, n_loc)
+            want, specs, plain = beta * y0, [], []
+
+            def slab(a):
+                s_ = torch.zeros((M, ld), dtype=torch.float64, device='cuda')
+                s_[:, :n_loc] = torch.from_numpy(a).cuda()
+                return s_
+
+            x = slab(X)
+            dev_lo = None if lo is None else torch.from_numpy(lo).cuda()
+            dev_hi = None if hi is None else torch.from_numpy(hi).cuda()
+            for k in range(nt):
+                t = rng.rand(3, n_loc)
+                T = np.diag(t[1]) + np.diag(t[0, 1:], -1) + np.diag(t[2, :-1], 1)
+                want = want + (mats[k] @ X) @ T.T
+                if lo is not None:
+                    want[:, 0] += t[0, 0] * (mats[k] @ lo)
+                if hi is not None:
+                    want[:, -1] += t[2, -1] * (mats[k] @ hi)
+                td = _lib_dev(t)
+                specs.append((td, k))
+                plain.append((td, k, x, dev_lo, dev_hi))
+            gh = None
+            if lo is not None or hi is not None:
+                gh = torch.zeros((M, 2), dtype=torch.float64, device='cuda')
+                if lo is not None:
+                    gh[:, 0] = dev_lo
+                if hi is not None:
+                    gh[:, 1] = dev_hi
+            y1, y2 = slab(y0), slab(y0)
+            ell.apply(plain, n_loc, ld, beta, y1)
+            two.apply(specs, x, gh, n_loc, ld, beta, y2)
+            assert relerr(y2[:, :n_loc].cpu().numpy(), want) < 1e-13, (name, n_loc, nt)
+            assert torch.equal(y1, y2), (name, n_loc, nt, float((y1 - y2).abs().max()))
+            if ld > n_loc:
+                assert float(y2[:, n_loc:].abs().max()) == 0.0
+            if gh is not None:
+                y3 = slab(y0)
+                two.apply(specs, x, None, n_loc, ld, beta, y3)
+                two.apply_ghost(specs, dev_lo, dev_hi, n_loc, ld, y3)
+                assert relerr(y3[:, :n_loc].cpu().numpy(), want) < 1e-13, (name, n_loc, nt)
+    # the operator classes pick the form up by themselves
+    from source.mpi_kron import SumMPI, TridiagKronMatMPI
+    M_x, A_x = space_matrices(problem_helper('lshape_jitter', J_space=3, J_time=2)[0])
+    N = 33
+    A_t = sp.diags([rng.rand(N - 1), rng.rand(N), rng.rand(N - 1)], (-1, 0, 1), format='csr')
+    M_t = sp.diags([rng.rand(N - 1), rng.rand(N), rng.rand(N - 1)], (-1, 0, 1), format='csr')
+    dd = _dd(N, M_x.shape[0])
+    op = SumMPI(dd, [TridiagKronMatMPI(dd, A_t, M_x), TridiagKronMatMPI(dd, M_t, A_x)])
+    assert 'explicit' in op._groups[0].kernel_name(N)
+    Xh = rng.rand(N, M_x.shape[0])
+    want = A_t @ Xh @ M_x.T + M_t @ Xh @ A_x.T
+    assert relerr(_np(op @ _vec(dd, Xh)), want) < 1e-13
 
 
 def test_row_engine_randomised_shapes(stk):
@@ -1736,8 +1877,9 @@ def test_byte_moving_kernels(stk):
         assert not blk.cpu().numpy()[:, nc:].any()
         u_t, u_x = rng.rand(n_loc), rng.rand(M)
         y = torch.full((M, ld), float('nan'), dtype=torch.float64, device=dev)
-        stk.check(lib.stk_outer(stk.stream(), M, n_loc, ld, stk.ptr(stk.to_dev(u_t)),
-                                stk.ptr(stk.to_dev(u_x)), stk.ptr(y)))
+        d_t, d_x = stk.to_dev(u_t), stk.to_dev(u_x)  # kept alive across the launch
+        stk.check(lib.stk_outer(stk.stream(), M, n_loc, ld, stk.ptr(d_t), stk.ptr(d_x),
+                                stk.ptr(y)))
         wy = np.zeros((M, ld))
         wy[:, :n_loc] = np.kron(u_t, u_x).reshape(n_loc, M).T
         assert np.array_equal(y.cpu().numpy(), wy)

@@ -10,7 +10,9 @@ fixture (tests/golden/o1_pcg_*.npz):
   gs=full rows       u_i += (f_i - row_i u) / a_ii (multigrid.py:89-97)
   family=reference   one hierarchy per wavelet level from the assembled
                      2^j M + alpha A (heateq_mpi.py:147-153)
-  arithmetic=reference   all three
+  restrict=R(Au-f)   the restricted residual as the reference forms it
+                     (multigrid.py:174-175) instead of (R A) u - R f
+  arithmetic=reference   all four
 
     python tools/history_attribution.py --configs square:5:8,square:6:9,lshape:5:8
 Writes gpurun_out/history_attribution.json (copy it to profiles/).
@@ -30,13 +32,17 @@ import heateq_mpi as hm  # noqa: E402
 from source import multigrid as mg  # noqa: E402
 from source.linalg import PCG  # noqa: E402
 
+# (name, HeatEquationMPI keywords, diagonal-free Gauss-Seidel rows, tuning keys)
 VARIANTS = [
-    ('default', {}, True),
-    ('schur=reference', {'schur': 'reference'}, True),
-    ('gs=full rows', {}, False),
-    ('family=reference', {'family': 'reference'}, True),
-    ('family=reference + gs=full rows', {'family': 'reference'}, False),
-    ('arithmetic=reference', {'arithmetic': 'reference'}, True),
+    ('default', {}, True, {}),
+    ('schur=reference', {'schur': 'reference'}, True, {}),
+    ('gs=full rows', {}, False, {}),
+    ('restrict=R(Au-f)', {}, True, {'mg_fuse_restrict': 0}),
+    ('family=reference', {'family': 'reference'}, True, {}),
+    ('family=reference + restrict=R(Au-f)', {'family': 'reference'}, True, {'mg_fuse_restrict': 0}),
+    ('family=reference + restrict=R(Au-f) + gs=full rows', {'family': 'reference'}, False,
+     {'mg_fuse_restrict': 0}),
+    ('arithmetic=reference', {'arithmetic': 'reference'}, True, {}),
 ]
 
 
@@ -55,9 +61,12 @@ def main():
         g = np.load(os.path.join(REPO, 'tests', 'golden', 'o1_pcg_%s_J%d_J%d.npz' % (problem, jt, js)))
         ref = np.asarray(g['hist'])
         rec = out.setdefault(spec, {})
-        for name, kw, diag_free in VARIANTS:
+        from source import _lib
+        for name, kw, diag_free, tune in VARIANTS:
             if want and name not in want:
                 continue
+            for key, value in tune.items():
+                _lib.check(_lib.lib().stk_set_tuning(key.encode(), value))
             mg.GS_DIAG_FREE = diag_free
             t0 = time.time()
             h = hm.HeatEquationMPI(J_space=js, J_time=jt, problem=problem, **kw)
@@ -69,6 +78,8 @@ def main():
             _, it = PCG(h.WT_S_W, h.P, h.rhs, history=hist)
             torch.cuda.synchronize()
             solve = time.time() - t0
+            for key in tune:
+                _lib.check(_lib.lib().stk_set_tuning(key.encode(), 1))
             hist = np.asarray(hist)
             n = min(len(hist), len(ref))
             rel = np.abs(hist[:n] / ref[:n] - 1.0)

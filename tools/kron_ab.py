@@ -74,7 +74,11 @@ def run(variant):
 forms = {rp: ell.packed_variant(rp) for rp in (1, 2)}
 print('packed forms: default %d row(s) per unit' % ell.packed.rows_per_unit, flush=True)
 y1 = torch.full_like(x, 3.0)
-forms[1].apply([(tri[0], 0), (tri[1], 1)], x, gh, n_loc, ld, 0.0, y1)
+if forms[1].ok and forms[1].rows_per_unit == 1:
+    forms[1].apply([(tri[0], 0), (tri[1], 1)], x, gh, n_loc, ld, 0.0, y1)
+else:  # values without a dictionary: the one-row form is the plain one
+    print('   no dictionary for these values: one-row form = plain sliced ELL', flush=True)
+    ell.apply([(tri[0], 0, x, lo, hi), (tri[1], 1, x, lo, hi)], n_loc, ld, 0.0, y1)
 for rp in (2,):
     f = forms[rp]
     if f.rows_per_unit != rp:
@@ -84,8 +88,8 @@ for rp in (2,):
     f.apply([(tri[0], 0), (tri[1], 1)], x, gh, n_loc, ld, 0.0, y2)
     torch.cuda.synchronize()
     same = torch.equal(y1, y2)
-    print('   %d rows per unit: %d units for %d rows, K=%d, %d codes; bit-identical with single rows: %s'
-          % (rp, f.n_units, M, f.K, f.n_codes, same), flush=True)
+    print('   %d rows per unit: %d units for %d rows, K=%d, %s; bit-identical with single rows: %s'
+          % (rp, f.n_units, M, f.K, 'explicit values' if f.explicit else '%d codes' % f.n_codes, same), flush=True)
     assert same
 
 

@@ -81,4 +81,39 @@ for shape in args.shapes.split(','):
         print('                     packed flags=%d: %.3f ms  %.0f GB/s algorithmic (%.1f%% of 8 TB/s)  max|diff to plain| %.1e  -> x%d ranks: %.2f TB/s aggregate'
               % (flags, msp, nbytes / msp / 1e6, nbytes / msp / 1e6 / 80, err, round(65 / n_loc),
                  round(65 / n_loc) * nbytes / msp / 1e9))
-    _lib.check(_lib.lib().stk_set_tuning(b'pack_flags', 0))
+    _lib.check(_lib.lib().stk_set_tuning(b'pack_flags', 3))
+    if lo or hi:
+        # the WHOLE step of a rank but for the wire time: what the exchange sends is
+        # packed out of the slab (stk_halo_pack) and what arrives enters the apply
+        lib = _lib.lib()
+        pk = ell.packed_for(n_loc)
+        send = torch.empty((2, M), dtype=torch.float64, device='cuda')
+        st = _lib.stream()
+
+        def pack():
+            _lib.check(lib.stk_halo_pack(st, M, n_loc, ld, _lib.ptr(x), _lib.ptr(send[0]) if lo else None, 1,
+                                         _lib.ptr(send[1]) if hi else None, 1))
+
+        def one_pass():  # wait for the halo, interleave it, one pass with ghost lanes
+            pack()
+            _lib.check(lib.stk_interleave_ghosts(st, M, _lib.ptr(g[0] if lo else None),
+                                                 _lib.ptr(g[1] if hi else None), _lib.ptr(gh)))
+            pk.apply(pspecs, x, gh, n_loc, ld, 0.0, y2)
+
+        def overlapped():  # pass without ghost steps (hides the wire), then their share
+            pack()
+            pk.apply(pspecs, x, None, n_loc, ld, 0.0, y2)
+            pk.apply_ghost(pspecs, g[0] if lo else None, g[1] if hi else None, n_loc, ld, y2)
+
+        ms_pack = timed(pack)
+        ms_a, ms_b = timed(one_pass), timed(overlapped)
+        ms_main = timed(lambda: pk.apply(pspecs, x, None, n_loc, ld, 0.0, y2))
+        ms_go = timed(lambda: pk.apply_ghost(pspecs, g[0] if lo else None, g[1] if hi else None, n_loc, ld, y2))
+        overlapped()
+        ell.apply(specs, n_loc, ld, 0.0, y)
+        err = float((y2 - y).abs().max() / y.abs().max())
+        print('                     step without the wire: pack %.3f ms; pack + interleave + one pass with ghost lanes %.3f ms; '
+              'pack + pass without ghosts (%.3f, runs beside the exchange) + ghost share (%.3f) = %.3f ms, of which %.3f ms '
+              'after the halo has arrived  (rel. diff to plain %.1e)' % (ms_pack, ms_a, ms_main, ms_go, ms_b,
+                                                                        ms_go, err))
+    _lib.check(_lib.lib().stk_set_tuning(b'pack_flags', 3))
