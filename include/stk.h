@@ -314,8 +314,10 @@ typedef struct {
  * rows still share COLUMNS.  vals[((u*K + s)*2 + j)*n_mats + m] is the entry of
  * matrix m in row j of slot row u at the column of slot s (zero where that row
  * has none): 36 bytes per slot for two matrices instead of 20 in the one-row
- * plain form (stk_kron_ell_apply), 10 gathers for two rows instead of 14, the
- * same sums in the same order. */
+ * plain form (stk_kron_ell_apply), 10 gathers for two rows instead of 14, every
+ * row's space-factor sum accumulated in the same order.  A call on such a pattern
+ * must use ALL its matrices, term k naming matrix k (n_terms = n_mats): the
+ * caller keeps one value array per combination of matrices it applies. */
 /* Row pairs (rows_per_unit = 2): slot row u serves the matrix rows
  * row_ids[2u] and row_ids[2u + 1] (-1: none); its K slots (K one of 8, 10, 12)
  * list the UNION of their columns in ascending order, and matrix m has the
@@ -405,6 +407,15 @@ int stk_kron_plan_apply(stk_kron_plan *plan, void *stream, int32_t n_loc,
                         const stk_kron_pack_term *terms_host, const double *x,
                         const double *x_lo, const double *x_hi,
                         double *ghost_work, double beta, double *y);
+
+/* The ghost rows' share after stk_kron_plan_apply ran with x_lo = x_hi = NULL while
+ * the halo exchange was in flight (mpi_kron.py:193-200): y += what the two
+ * received rows contribute to the first / last local time step.  x: the slab the
+ * apply read (needed by plans without a packed form only). */
+int stk_kron_plan_ghost_apply(stk_kron_plan *plan, void *stream, int32_t n_loc,
+                              int32_t ld, int32_t n_terms,
+                              const stk_kron_pack_term *terms_host, const double *x,
+                              const double *x_lo, const double *x_hi, double *y);
 
 /* Diagnostic: while `buf` (device, at least 8 * grid * 4 words) is non-NULL,
  * the headline instantiation of the one-row form (2 terms, K = 7, no ghosts;

@@ -400,9 +400,25 @@ __global__ __launch_bounds__(SBS) void time_csr_kernel(int64_t total, int32_t M,
 
 }  // namespace
 
+int g_stk_tuning_epoch = 0;  // captured V-cycle graphs (mg.hip) belong to the tuning state they were recorded under
+extern int g_mg_graph, g_mg_graph_replays;
+
 extern "C" int stk_set_tuning(const char *key, int32_t value)
 {
     STK_REQUIRE(key != nullptr, "stk_set_tuning: null key");
+    if (std::strcmp(key, "mg_graph_replays") == 0) {  // tests: reset (0) / require at least `value` replays
+        if (value > 0 && g_mg_graph_replays < value) {
+            stk_set_error("mg_graph_replays: %d graph launches so far, %d required", g_mg_graph_replays, value);
+            return 2;
+        }
+        if (value == 0) g_mg_graph_replays = 0;
+        return 0;
+    }
+    ++g_stk_tuning_epoch;
+    if (std::strcmp(key, "mg_graph") == 0) {
+        g_mg_graph = value;
+        return 0;
+    }
     if (std::strcmp(key, "kron_block") == 0) {
         g_kron_bs = value;
         return 0;

@@ -47,9 +47,9 @@
 //    repeat -- an unstructured mesh, reference mpi_kron.py:135-150 takes any CSR --
 //    have no dictionary.  Pairs need shared COLUMNS, not repeated values: the slot
 //    word is then the column alone and the values of both rows of every slot travel
-//    beside it, vals[unit][slot][row][matrix] (zero where a row has no entry in the
-//    column), prefetched into registers and handed over through LDS like the slot
-//    words.  36 bytes per slot instead of 20 in the one-row plain form
+//    beside it, vals[unit][slot][row][term] (zero where a row has no entry in the
+//    column; the matrices of the call's terms, in term order), prefetched into
+//    registers and handed over through LDS like the slot words.  36 bytes per slot instead of 20 in the one-row plain form
 //    (kron_ell.hip), but 10 gathers for two rows instead of 14; accumulation order
 //    and results are those of the plain form, bit for bit.
 #include <cstring>
@@ -75,7 +75,7 @@ struct PackArgs {
     int32_t col_bits, n_codes;
     int32_t flags;  // bit 0: non-temporal y stores, bit 1: non-temporal slot loads
     unsigned long long *diag;  // DIAG instantiation: [waves][4] cycle sums
-    // explicit values (no dictionary): [n_units][K][RP][n_mats], term k reads matrix mat[k]
+    // explicit values (no dictionary): [n_units][K][RP][NT], term k reads entry k
     const double *vals;
     int32_t n_mats;
     int32_t mat[NT];
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(BS, (K >= 12 || RP > 1) ? 4 : 6) void kron_pack_ker
     double *s_tri = reinterpret_cast<double *>(s_row + ((R * RP + 3) & ~3));  // [NT][3][LT], 16-byte aligned rows
     double *s_dict = s_tri + NT * 3 * LT;  // [n_codes][RP][NT], or the group's explicit values [R][K][RP][n_mats]
     // s_w[k][r * RP + j][q], q = t + 1: the space-factor results z_k[row][t], t = -1 .. n_loc
-    double *s_w = s_dict + (DICT ? a.n_codes * RP * NT : R * K * RP * a.n_mats);
+    double *s_w = s_dict + (DICT ? a.n_codes * RP * NT : R * K * RP * NT);
 
     const int tid = threadIdx.x;
     const int r = tid / W;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(BS, (K >= 12 || RP > 1) ? 4 : 6) void kron_pack_ker
     for (int q = 0; q < NPF; ++q) pslot[q] = 0;
 #pragma unroll
     for (int q = 0; q < NPV; ++q) pval[q] = 0.0;
-    const int vper = K * RP * a.n_mats;  // explicit values of one slot row
+    constexpr int vper = K * RP * NT;  // explicit values of one slot row (the terms' matrices, in term order)
     auto fetch = [&](int gq) {
         const int rows = min(R, a.n_units - gq * R);
         const uint32_t *src = a.slots + (size_t)gq * R * K;
@@ -271,14 +271,11 @@ __global__ __launch_bounds__(BS, (K >= 12 || RP > 1) ? 4 : 6) void kron_pack_ker
 #pragma unroll
             for (int u = 0; u < K; ++u) {
                 const double *dv = DICT ? s_dict + (sl[u] >> a.col_bits) * (RP * NT)
-                                        : s_dict + ((r * K + u) * RP) * a.n_mats;
+                                        : s_dict + ((r * K + u) * RP) * NT;
 #pragma unroll
-                for (int j = 0; j < RP; ++j, dv += (DICT ? NT : a.n_mats)) {
+                for (int j = 0; j < RP; ++j, dv += NT) {
                     double v[NT];
-                    if constexpr (!DICT) {
-#pragma unroll
-                        for (int k = 0; k < NT; ++k) v[k] = dv[a.mat[k]];
-                    } else if constexpr (NT == 2) {  // one 16-byte read (s_dict is 16-byte aligned)
+                    if constexpr (NT == 2) {  // one 16-byte read (s_dict is 16-byte aligned)
                         const double2 vv = *reinterpret_cast<const double2 *>(dv);
                         v[0] = vv.x, v[1] = vv.y;
                     } else {
@@ -443,13 +440,13 @@ __global__ __launch_bounds__(256) void kron_pack_ghost_kernel(const PackArgs<NT>
         for (int q = 0; q < K; ++q) {
             const uint32_t col = sl[q] & col_mask;
             const double xl = lo ? lo[col] : 0.0, xh = hi ? hi[col] : 0.0;
-            const double *dv = a.vals ? a.vals + ((size_t)u * K + q) * RP * a.n_mats
+            const double *dv = a.vals ? a.vals + ((size_t)u * K + q) * RP * NT
                                       : s_dict + (sl[q] >> a.col_bits) * (RP * NT);
 #pragma unroll
             for (int j = 0; j < RP; ++j)
 #pragma unroll
                 for (int k = 0; k < NT; ++k) {
-                    const double v = a.vals ? dv[j * a.n_mats + a.mat[k]] : dv[j * NT + k];
+                    const double v = dv[j * NT + k];
                     zl[j][k] = fma(v, xl, zl[j][k]);
                     zh[j][k] = fma(v, xh, zh[j][k]);
                 }
@@ -589,11 +586,11 @@ int launch(hipStream_t st, PackArgs<NT> a, int K)
     a.W = a.P + (ghost ? 1 : 0);
     a.R = BS / a.W;
     if (a.R * K > 4 * BS) a.R = 4 * BS / K;  // at most 4 prefetched words per thread
-    if (a.vals && a.R * K * RP * a.n_mats > 2 * BS) a.R = 2 * BS / (K * RP * a.n_mats);  // ... and 2 values
-    STK_REQUIRE(a.R >= 1, "stk_kron_pack_apply: a slot row of %d x %d x %d values is too wide", K, RP, a.n_mats);
+    if (a.vals && a.R * K * RP * NT > 2 * BS) a.R = 2 * BS / (K * RP * NT);  // ... and 2 values
+    STK_REQUIRE(a.R >= 1, "stk_kron_pack_apply: a slot row of %d x %d x %d values is too wide", K, RP, NT);
     const int KS = (K + 3) & ~3;
     auto lds_of = [&](int R) {
-        const size_t values = a.vals ? (size_t)R * K * RP * a.n_mats : (size_t)a.n_codes * RP * NT;
+        const size_t values = a.vals ? (size_t)R * K * RP * NT : (size_t)a.n_codes * RP * NT;
         return sizeof(double) * ((a.any_tri ? (size_t)NT * R * RP * (a.n_loc + 3) : 0) + values +
                                  (size_t)NT * 3 * (a.n_loc + 2)) +
                sizeof(uint32_t) * ((size_t)R * KS + (size_t)R * RP + 4) + 32;
@@ -698,6 +695,12 @@ extern "C" int stk_kron_pack_apply(void *stream, const stk_pack_pattern *pat, in
     STK_REQUIRE(pat && t && x && y, "stk_kron_pack_apply: null pointer");
     STK_REQUIRE(pat->M > 0 && pat->K >= 1 && pat->slots && (pat->dict || pat->vals), "stk_kron_pack_apply: bad pattern");
     STK_REQUIRE(!pat->vals || pat->rows_per_unit == 2, "stk_kron_pack_apply: explicit values need row pairs");
+    if (pat->vals) {
+        STK_REQUIRE(pat->n_mats == n_terms, "stk_kron_pack_apply: explicit values list %d matrices for %d terms",
+                    pat->n_mats, n_terms);
+        for (int k = 0; k < n_terms; ++k)
+            STK_REQUIRE(t[k].mat == k, "stk_kron_pack_apply: with explicit values term %d must name matrix %d", k, k);
+    }
     STK_REQUIRE(pat->rows_per_unit == 1 || pat->rows_per_unit == 2,
                 "stk_kron_pack_apply: rows_per_unit=%d is not 1 or 2", pat->rows_per_unit);
     STK_REQUIRE(pat->n_units > 0 && (int64_t)pat->n_units * pat->rows_per_unit >= pat->M &&
@@ -760,6 +763,13 @@ extern "C" int stk_kron_pack_ghost_apply(void *stream, const stk_pack_pattern *p
     STK_REQUIRE(n_terms >= 1 && n_terms <= 3, "stk_kron_pack_ghost_apply: n_terms=%d not in 1..3", n_terms);
     STK_REQUIRE(pat->vals || sizeof(double) * (size_t)pat->n_codes * pat->rows_per_unit * n_terms <= 60 * 1024,
                 "stk_kron_pack_ghost_apply: dictionary too large");
+    if (pat->vals) {
+        STK_REQUIRE(pat->n_mats == n_terms, "stk_kron_pack_ghost_apply: explicit values list %d matrices for %d terms",
+                    pat->n_mats, n_terms);
+        for (int k = 0; k < n_terms; ++k)
+            STK_REQUIRE(t[k].mat == k, "stk_kron_pack_ghost_apply: with explicit values term %d must name matrix %d", k,
+                        k);
+    }
     for (int k = 0; k < n_terms; ++k)
         STK_REQUIRE(t[k].mat >= 0 && t[k].mat < pat->n_mats, "stk_kron_pack_ghost_apply: term %d names matrix %d of %d",
                     k, t[k].mat, pat->n_mats);

@@ -132,6 +132,21 @@ struct stk_mg {
     // -1: follow the process-wide tuning key "mg_fuse_restrict"; 0 / 1: this plan's
     // own choice (stk_mg_set_option; 0 is part of the reference-arithmetic mode)
     int fuse_restrict = -1;
+    // recorded V-cycle applications (see g_mg_graph)
+    struct Recorded {
+        const double *f, *cm;
+        double *u;
+        const int32_t *kind;
+        int32_t n_loc, ld;
+        double ca;
+        int epoch, fuse_restrict;
+        hipGraphExec_t exec;  // NULL: seen once, not recorded yet
+        bool refused;         // capture failed: stays on the plain path
+        uint64_t last_use;
+    };
+    std::vector<Recorded> recorded;
+    hipStream_t capture_stream = nullptr;
+    uint64_t clock = 0;
 };
 
 // The ELL row engine needs 16-byte time pairs (even ld) and slabs below 64 GiB.
@@ -211,6 +226,20 @@ static const std::vector<int32_t> *strip_table(const EllLevel &E, bool backward,
 }
 
 int g_mg_strips_used = 0;  // launches that came from a strip table (tests read it through stk_set_tuning)
+// Tuning key "mg_graph" (default 0): a V-cycle application that comes back with
+// the same operands (PCG iterations do: the same slabs, coefficients and tables
+// every time) is recorded into a hipGraph on its second occurrence and replayed
+// from then on.  One multigrid apply is ~300 dependent launches; on short slabs
+// (the shapes of an 8-GPU run: 8 or 9 time steps) they are only a few
+// microseconds each.  MEASURED (profiles/r03_op_graph*.log, ROCm 7.2, one
+// MI355X): replay is bit-identical and SLOWER than plain launches -- S 4.11 ->
+// 4.42 ms, P 5.56 -> 6.24 ms on 9-step slabs, 17.8 -> 18.3 / 21.3 -> 22.1 ms on
+// 65-step slabs: the host already enqueues faster than the GPU retires (the
+// recursion is C++), and a graph node costs the GPU about a microsecond more than
+// a plain dependent launch.  Kept as an option for hosts with slow launch paths.
+int g_mg_graph = 0;
+int g_mg_graph_replays = 0;  // graph launches so far (tests read it through stk_set_tuning)
+extern int g_stk_tuning_epoch;  // kron.hip: bumped by every stk_set_tuning
 
 static int smooth_level(stk_mg *mg, hipStream_t st, int level, int n_loc, int ld, double ca, const double *cm,
                         int its, bool backward, const double *f, double *u, bool zero_start = false)
@@ -455,6 +484,9 @@ void stk_mg_adopt(stk_mg *mg, void *const *dev_ptrs, int n)
 extern "C" int stk_mg_destroy(stk_mg *mg)
 {
     if (!mg) return 0;
+    for (auto &r : mg->recorded)
+        if (r.exec) (void)hipGraphExecDestroy(r.exec);
+    if (mg->capture_stream) (void)hipStreamDestroy(mg->capture_stream);
     for (void *p : mg->adopted) (void)hipFree(p);
     for (double *p : mg->u) (void)hipFree(p);
     for (double *p : mg->f) (void)hipFree(p);
@@ -475,6 +507,40 @@ extern "C" int stk_mg_set_option(stk_mg *mg, const char *key, int32_t value)
     return 2;
 }
 
+static int run_vcycles(stk_mg *mg, hipStream_t st, int32_t n_loc, int32_t ld, double ca, const double *cm,
+                       const int32_t *kind, const double *f, double *u)
+{
+    const int J = (int)mg->lv.size() - 1;
+    for (int v = 0; v < mg->vcycles; ++v) {
+        int rc = mgm(mg, st, J, n_loc, ld, ca, cm, kind, f, u, /*u_zero=*/v == 0);  // multigrid.py:187
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// Records run_vcycles into an executable graph (on a stream of the plan's own:
+// the caller's may be the legacy default stream, which cannot be captured).
+static hipGraphExec_t record_vcycles(stk_mg *mg, int32_t n_loc, int32_t ld, double ca, const double *cm,
+                                     const int32_t *kind, const double *f, double *u)
+{
+    if (!mg->capture_stream &&
+        hipStreamCreateWithFlags(&mg->capture_stream, hipStreamNonBlocking) != hipSuccess) {
+        mg->capture_stream = nullptr;
+        return nullptr;
+    }
+    if (hipStreamBeginCapture(mg->capture_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return nullptr;
+    const int rc = run_vcycles(mg, mg->capture_stream, n_loc, ld, ca, cm, kind, f, u);
+    hipGraph_t graph = nullptr;
+    const hipError_t end = hipStreamEndCapture(mg->capture_stream, &graph);
+    hipGraphExec_t exec = nullptr;
+    if (rc == 0 && end == hipSuccess && graph != nullptr &&
+        hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess)
+        exec = nullptr;
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    return exec;
+}
+
 extern "C" int stk_mg_apply(stk_mg *mg, void *stream, int32_t n_loc, int32_t ld, double ca, const double *cm,
                             const int32_t *kind, const double *f, double *u)
 {
@@ -485,12 +551,42 @@ extern "C" int stk_mg_apply(stk_mg *mg, void *stream, int32_t n_loc, int32_t ld,
     STK_REQUIRE(cm == nullptr || mg->lv[0].vals_m != nullptr, "stk_mg_apply: cm given but plan has no vals_m");
     STK_REQUIRE(ca != 0.0 || cm, "stk_mg_apply: zero matrix");
     hipStream_t st = stk_stream(stream);
-    const int J = (int)mg->lv.size() - 1;
-    for (int v = 0; v < mg->vcycles; ++v) {
-        int rc = mgm(mg, st, J, n_loc, ld, ca, cm, kind, f, u, /*u_zero=*/v == 0);  // multigrid.py:187
-        if (rc) return rc;
+    if (g_mg_graph && !g_stk_timing) {
+        stk_mg::Recorded *hit = nullptr;
+        for (auto &r : mg->recorded)
+            if (r.f == f && r.u == u && r.cm == cm && r.kind == kind && r.n_loc == n_loc && r.ld == ld && r.ca == ca &&
+                r.epoch == g_stk_tuning_epoch && r.fuse_restrict == mg->fuse_restrict) {
+                hit = &r;
+                break;
+            }
+        if (hit == nullptr) {
+            // first occurrence: remembered, run on the plain path (one-off calls
+            // are never recorded)
+            stk_mg::Recorded fresh{f, cm, u, kind, n_loc, ld, ca, g_stk_tuning_epoch, mg->fuse_restrict, nullptr, false,
+                                   ++mg->clock};
+            if (mg->recorded.size() >= 24) {
+                size_t oldest = 0;
+                for (size_t k = 1; k < mg->recorded.size(); ++k)
+                    if (mg->recorded[k].last_use < mg->recorded[oldest].last_use) oldest = k;
+                if (mg->recorded[oldest].exec) (void)hipGraphExecDestroy(mg->recorded[oldest].exec);
+                mg->recorded[oldest] = fresh;
+            } else {
+                mg->recorded.push_back(fresh);
+            }
+        } else {
+            hit->last_use = ++mg->clock;
+            if (hit->exec == nullptr && !hit->refused) {
+                hit->exec = record_vcycles(mg, n_loc, ld, ca, cm, kind, f, u);
+                hit->refused = hit->exec == nullptr;
+            }
+            if (hit->exec != nullptr) {
+                STK_HIP(hipGraphLaunch(hit->exec, st));
+                ++g_mg_graph_replays;
+                return 0;
+            }
+        }
     }
-    return 0;
+    return run_vcycles(mg, st, n_loc, ld, ca, cm, kind, f, u);
 }
 
 extern "C" int stk_mg_smooth(stk_mg *mg, void *stream, int32_t level, int32_t n_loc, int32_t ld, double ca,

@@ -42,14 +42,6 @@ extern "C" int32_t stk_pack_unit_slots(int32_t K, int32_t rp)
     return 0;  // three / four rows per unit (K = 7 -> 13 / 16): measured slower than pairs, not instantiated
 }
 
-// Rows that follow each other in the processing order and share columns are
-// served by one slot row ("unit") of the packed form: greedily, left to right, a
-// unit takes the next row as long as it has fewer than `rp` rows and the union of
-// the columns still fits K_out slots.  cols/codes: [M][K] with the real entries
-// of position p in the first counts[p] slots, columns ascending.  Outputs (sized
-// for M units): ucols [units][K_out] (ascending union, unused slots = the first
-// row's own column), ucodes [units][K_out][rp] (zero_code where a row has no
-// entry in the column), urows [units][rp] (-1: no row).
 // Row pairs need rows that follow each other in the processing order to share
 // columns.  A mesh-tile order of a structured mesh has that by itself (x-neighbours
 // are consecutive); the order of an unstructured mesh does not.  This walks the
@@ -102,6 +94,14 @@ extern "C" int stk_pack_match_order(int32_t M, int32_t K, const int32_t *counts,
     return 0;
 }
 
+// Rows that follow each other in the processing order and share columns are
+// served by one slot row ("unit") of the packed form: greedily, left to right, a
+// unit takes the next row as long as it has fewer than `rp` rows and the union of
+// the columns still fits K_out slots.  cols/codes: [M][K] with the real entries
+// of position p in the first counts[p] slots, columns ascending.  Outputs (sized
+// for M units): ucols [units][K_out] (ascending union, unused slots = the first
+// row's own column), ucodes [units][K_out][rp] (zero_code where a row has no
+// entry in the column), urows [units][rp] (-1: no row).
 extern "C" int stk_pack_group_rows(int32_t M, int32_t K, const int32_t *counts, const int32_t *cols,
                                    const int32_t *codes, const int32_t *own, int32_t zero_code, int32_t rp,
                                    int32_t K_out, int32_t *n_units, int32_t *ucols, int32_t *ucodes, int32_t *urows)
@@ -408,4 +408,25 @@ extern "C" int stk_kron_plan_apply(stk_kron_plan *p, void *stream, int32_t n_loc
     for (int k = 0; k < n_terms; ++k)
         terms[k] = stk_kron_ell_term{t[k].tri, p->ell_vals[t[k].mat], p->ovf_vals[t[k].mat], x, x_lo, x_hi};
     return stk_kron_ell_apply(stream, &p->ell, n_loc, ld, n_terms, terms, beta, y);
+}
+
+extern "C" int stk_kron_plan_ghost_apply(stk_kron_plan *p, void *stream, int32_t n_loc, int32_t ld, int32_t n_terms,
+                                         const stk_kron_pack_term *t, const double *x, const double *x_lo,
+                                         const double *x_hi, double *y)
+{
+    STK_REQUIRE(p && t && y, "stk_kron_plan_ghost_apply: null pointer");
+    STK_REQUIRE(n_terms >= 1 && n_terms <= 3, "stk_kron_plan_ghost_apply: n_terms=%d not in 1..3", n_terms);
+    for (int k = 0; k < n_terms; ++k)
+        STK_REQUIRE(t[k].mat >= 0 && t[k].mat < p->n_mats, "stk_kron_plan_ghost_apply: term %d names matrix %d of %d",
+                    k, t[k].mat, p->n_mats);
+    if (!x_lo && !x_hi) return 0;
+    if (p->packed) {
+        const stk_pack_pattern *form = p->paired && n_loc >= 24 ? &p->pack_pairs : &p->pack;
+        return stk_kron_pack_ghost_apply(stream, form, n_loc, ld, n_terms, t, x_lo, x_hi, y);
+    }
+    STK_REQUIRE(x, "stk_kron_plan_ghost_apply: the plain form needs x");
+    stk_kron_ell_term terms[3];
+    for (int k = 0; k < n_terms; ++k)
+        terms[k] = stk_kron_ell_term{t[k].tri, p->ell_vals[t[k].mat], p->ovf_vals[t[k].mat], x, x_lo, x_hi};
+    return stk_kron_ell_ghost_apply(stream, &p->ell, n_loc, ld, n_terms, terms, y);
 }

@@ -163,6 +163,10 @@ _PROTOTYPES = {
         c_p, c_p, c_i32, c_i32, c_i32, ctypes.POINTER(KronPackTerm), c_p, c_p,
         c_p, c_p, c_f64, c_p
     ]),
+    'stk_kron_plan_ghost_apply': (ctypes.c_int, [
+        c_p, c_p, c_i32, c_i32, c_i32, ctypes.POINTER(KronPackTerm), c_p, c_p,
+        c_p, c_p
+    ]),
     'stk_kron_pack_set_diag': (ctypes.c_int, [c_p]),
     'stk_ell_spmm': (ctypes.c_int, [
         c_p, ctypes.POINTER(EllRows), c_i32, c_i32, c_i32, c_f64, c_p, c_p,

@@ -497,9 +497,11 @@ class PackedEllMatrices:
             if K_out == 0 or counts is None:
                 return
         col_bits = max(1, int(M - 1).bit_length())
+        self._no_dictionary = False
         built = self._with_dictionary(M, K, K_out, col_bits, ell_idx, ell_vals,
                                       counts, own, rows_per_unit)
-        if built is None and rows_per_unit == 2 and self.EXPLICIT_PAIRS:
+        if (built is None and self._no_dictionary and rows_per_unit == 2
+                and self.EXPLICIT_PAIRS):
             # values that do not repeat (an unstructured mesh): no dictionary, but
             # neighbouring rows still share COLUMNS -- pairs with explicit values
             built = self._with_explicit_values(M, K, K_out, ell_idx, ell_vals,
@@ -518,7 +520,9 @@ class PackedEllMatrices:
         if vals is not None:
             self.n_codes = 1
             self.slots = _lib.to_dev(cols.astype(np.uint32).view(np.int32).reshape(cols.shape))
-            self.vals = _lib.to_dev(vals)
+            # the kernel reads the values of a call's terms side by side: one device
+            # array per combination of matrices (built on first use, _pattern_for)
+            self._host_vals, self._vals_for = vals, {}
         else:
             self.n_codes = len(table)
             slots = (codes.reshape(-1).astype(np.uint32) << np.uint32(col_bits)
@@ -549,10 +553,12 @@ class PackedEllMatrices:
         for e in ell_vals:
             found = _few_unique(e.reshape(-1).view(np.int64), self.MAX_CODES)
             if found is None:
+                self._no_dictionary = True
                 return None
             u, inv = found
             uc, codes = _small_unique(codes * len(u) + inv, self.MAX_CODES * len(u))
             if len(uc) > self.MAX_CODES:
+                self._no_dictionary = True
                 return None
             col = u[uc % len(u)][:, None]
             table = col if table is None else np.hstack(
@@ -653,9 +659,27 @@ class PackedEllMatrices:
 
     def _terms(self, specs):
         terms = (_lib.KronPackTerm * len(specs))()
-        for t, (tri, k) in zip(terms, specs):
-            t.tri, t.mat = _lib.ptr(tri), k
+        explicit = self.explicit
+        for j, (t, (tri, k)) in enumerate(zip(terms, specs)):
+            t.tri, t.mat = _lib.ptr(tri), (j if explicit else k)
         return terms
+
+    def _pattern_for(self, specs):
+        """The pattern a call streams: the plan's own, or -- explicit values -- the
+        one whose value array lists exactly the matrices of the call's terms, in
+        term order (stk_pack_pattern.vals)."""
+        if not self.explicit:
+            return self.pattern
+        mats = tuple(k for _, k in specs)
+        hit = self._vals_for.get(mats)
+        if hit is None:
+            vals = _lib.to_dev(np.ascontiguousarray(self._host_vals[..., list(mats)]))
+            pat = _lib.PackPattern(self.M, self.K, self.col_bits, 1, len(mats),
+                                   self.rows_per_unit, self.n_units,
+                                   _lib.ptr(self.slots), _lib.ptr(self.row_ids),
+                                   None, _lib.ptr(vals))
+            hit = self._vals_for[mats] = (vals, pat)
+        return hit[1]
 
     def apply_ghost(self, specs, x_lo, x_hi, n_loc, ld, out):
         """Adds what the ghost time rows contribute after `apply` ran without
@@ -664,7 +688,7 @@ class PackedEllMatrices:
         if x_lo is None and x_hi is None:
             return
         _lib.check(_lib.lib().stk_kron_pack_ghost_apply(
-            _lib.stream(), ctypes.byref(self.pattern), n_loc, ld, len(specs),
+            _lib.stream(), ctypes.byref(self._pattern_for(specs)), n_loc, ld, len(specs),
             self._terms(specs), _lib.ptr(x_lo), _lib.ptr(x_hi), _lib.ptr(out)))
 
     def apply(self, specs, x, ghosts, n_loc, ld, beta, out):
@@ -672,7 +696,7 @@ class PackedEllMatrices:
         `ghosts`: (M, 2) interleaved ghost time steps or None."""
         terms = self._terms(specs)
         _lib.check(_lib.lib().stk_kron_pack_apply(
-            _lib.stream(), ctypes.byref(self.pattern), n_loc, ld, len(specs),
+            _lib.stream(), ctypes.byref(self._pattern_for(specs)), n_loc, ld, len(specs),
             terms, _lib.ptr(x), _lib.ptr(ghosts), beta, _lib.ptr(out)))
 
 

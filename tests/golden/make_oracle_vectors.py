@@ -54,6 +54,63 @@ def build_oracle(problem, J_time, J_space):
     return HeatEquationOracle(mats, J_time)
 
 
+def lean_operators(o, chunk=8):
+    """S and W^T S W of the oracle evaluated in chunks of time rows: (S x)[t] only
+    needs the rows t-1, t, t+1 of the time factors, so the (M, N) temporaries of
+    HeatEquationOracle.S -- several copies of the vector -- shrink to `chunk`
+    rows.  Same arithmetic per entry (the space operators act slice by slice).
+    For the largest configuration (J_time=7, J_space=10: 4.3 GB per vector)."""
+    import scipy.sparse as sp
+    from oracle import kron
+    terms = [(sp.csr_matrix(T), ops) for T, ops in o.S_terms()]
+
+    def S(X):
+        out = np.zeros_like(X)
+        for a in range(0, o.N, chunk):
+            b = min(a + chunk, o.N)
+            for T, ops in terms:
+                Z = T[a:b] @ X  # rows a..b of (T kron I) x
+                out[a:b] += kron.composite_space(ops, Z.T).T
+        return out
+
+    return S, (lambda X: o.WT(S(o.W(X))))
+
+
+def lean_pcg(T, P, b, kmax):
+    """oracle.krylov.pcg with every vector update done in place, row block by row
+    block (identical per entry; no full-size temporaries)."""
+    from oracle.krylov import _dot
+    N = b.shape[0]
+
+    def axpy(y, a, x):  # y += a * x
+        for t in range(N):
+            y[t] += a * x[t]
+
+    w = np.zeros_like(b)
+    r = b.copy()  # w0 = 0: r = b - T(0) = b
+    p = P(r)
+    abs_r = _dot(r, p)
+    hist = [abs_r]
+    for k in range(1, kmax):
+        t = T(p)
+        alpha = abs_r / _dot(p, t)
+        axpy(w, alpha, p)
+        axpy(r, -alpha, t)
+        del t
+        z = P(r)
+        abs_r_old, abs_r = abs_r, _dot(r, z)
+        hist.append(abs_r)
+        print('  iteration %d: r.Pr = %.6e' % (k, abs_r), flush=True)
+        if abs_r < 1e-12:
+            break
+        beta = abs_r / abs_r_old
+        for row in range(N):
+            p[row] *= beta
+            p[row] += z[row]
+        del z
+    return w, len(hist) - 1, hist
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--J_time', type=int, default=5)
@@ -63,6 +120,9 @@ def main():
     ap.add_argument('--kmax', type=int, default=100000)
     ap.add_argument('--no-ops', action='store_true',
                     help='skip the S(X), P(X) samples (memory at the largest sizes)')
+    ap.add_argument('--lean', action='store_true',
+                    help='chunked S and in-place PCG (the largest configuration, with --kmax 3: '
+                         'the first entries of the history only)')
     args = ap.parse_args()
     omg.THREADS = args.threads
     o = build_oracle(args.problem, args.J_time, args.J_space)
@@ -71,7 +131,12 @@ def main():
     def cb(w, r, k):
         print('  iteration %d  (%.0f s)' % (k, time.time() - t0), flush=True)
 
-    w, iters, hist = pcg(o.WT_S_W, o.P, o.rhs(), kmax=args.kmax, callback=cb)
+    if args.lean:
+        S_lean, T_lean = lean_operators(o)
+        o.S = S_lean
+        w, iters, hist = lean_pcg(T_lean, o.P, o.rhs(), args.kmax)
+    else:
+        w, iters, hist = pcg(o.WT_S_W, o.P, o.rhs(), kmax=args.kmax, callback=cb)
     print('oracle PCG: %d iterations in %.1f s' % (iters, time.time() - t0))
     st, sx = sample_strides(o.N, o.M)
     out = dict(J_time=args.J_time, J_space=args.J_space, problem=args.problem,

@@ -448,7 +448,7 @@ def test_direct_preconditioner_matches_reference_golden(stk, g3):
     w, iters = PCG(WT_S_W, P, _vec(dd, g3['rhs']),
                    callback=lambda w, r, k: rr.append(r.dot(r)))
     assert iters == int(g3['pcg_iters_direct'])
-    _hist_dev('golden_%d_%d_direct_rr' % (N, M), rr, g3['pcg_rr_direct'], 1e-9)
+    _hist_dev('golden_%d_%d_direct_rr' % (N, M), rr, g3['pcg_rr_direct'], 1e-10)
     assert relerr(_np(w), g3['pcg_w_direct']) < 1e-9
 
 
@@ -777,7 +777,7 @@ def test_serial_driver_against_oracle(stk, precond):
     w, iters = PCG(h.WT_S_W, h.P, h.WT @ h.f, history=hist)
     wo, iters_o, hist_o = pcg(o.WT_S_W, o.P, o.WT(o.f()))
     assert iters == iters_o
-    _hist_dev('serial_driver_%s' % precond, hist, hist_o, 1e-9 if precond == 'direct' else 1e-10)
+    _hist_dev('serial_driver_%s' % precond, hist, hist_o, 1e-10)
     assert relerr(w, wo) < 1e-9
     # the parallel driver builds the same Schur complement from five terms
     hp = hm.HeatEquationMPI(J_space=J_space, J_time=J_time, precond=precond)
@@ -1228,9 +1228,8 @@ def test_kron_pack_explicit_value_pairs(stk):
     "unstructured spatial mesh, irregular CSR"; the reference takes any CSR,
     mpi_kron.py:135-150) and banded matrices with random entries.  The planner
     must take the explicit form, rows must really be paired, and the result must
-    be bit for bit that of the one-row plain form (stk_kron_ell_apply: same
-    accumulation order, absent columns add exact zeros) and agree with dense
-    NumPy; ghost lanes, the overlapped ghost share, 1-3 terms, beta, slab lengths
+    agree with the one-row plain form (stk_kron_ell_apply) to the last bits and
+    with dense NumPy; ghost lanes, the overlapped ghost share, 1-3 terms, beta, slab lengths
     through the lane / group / prefetch instances."""
     from source.assembly import space_matrices
     from source.linop import EllMatrices
@@ -1292,7 +1291,9 @@ def test_kron_pack_explicit_value_pairs(stk):
             ell.apply(plain, n_loc, ld, beta, y1)
             two.apply(specs, x, gh, n_loc, ld, beta, y2)
             assert relerr(y2[:, :n_loc].cpu().numpy(), want) < 1e-13, (name, n_loc, nt)
-            assert torch.equal(y1, y2), (name, n_loc, nt, float((y1 - y2).abs().max()))
+            # the space-factor sums are those of the plain form; the two kernels
+            # combine terms and time stencil in their own order: last bits only
+            assert float((y1 - y2).abs().max()) <= 4e-15 * float(y1.abs().max()), (name, n_loc, nt)
             if ld > n_loc:
                 assert float(y2[:, n_loc:].abs().max()) == 0.0
             if gh is not None:
@@ -1426,6 +1427,54 @@ def test_zero_start_first_sweep_is_exact(stk):
             stk.check(stk.lib().stk_set_tuning(b'mg_zero_start', 1))
         assert np.array_equal(res[0][0], res[1][0])
         assert np.array_equal(res[0][1], res[1][1])
+
+
+def test_recorded_vcycles_replay_exactly(stk):
+    """A multigrid application that recurs with the same operands can be recorded
+    into a hipGraph on its second occurrence and replayed afterwards (tuning key
+    "mg_graph", csrc/mg.hip; off by default -- measured slower than plain launches,
+    profiles/r03_op_graph*.log).  Replays must really happen, must read the CURRENT
+    contents of the operands (only pointers and scalars are baked in), and must
+    be bit for bit the plain path -- for a single matrix, for the batched family
+    with per-slice coefficients, and in a whole solve."""
+    import heateq_mpi as hm
+    from source.linalg import PCG
+    lib = stk.lib()
+    h = hm.HeatEquationMPI(J_space=4, J_time=3)
+    n_loc, M = h.N, h.M
+    rng = np.random.RandomState(77)
+    dd = h.dofs_distr
+    xs = [_vec(dd, rng.rand(n_loc, M)) for _ in range(3)]
+    fam, (cm, kind) = h.C_family, h.C_family.slice_tables(list(h.W.levels))
+    try:
+        outs = {}
+        for graph in (0, 1):
+            stk.check(lib.stk_set_tuning(b'mg_graph', graph))
+            stk.check(lib.stk_set_tuning(b'mg_graph_replays', 0))
+            buf_in = torch.empty_like(xs[0].buf)
+            out_k, out_f = torch.empty_like(buf_in), torch.empty_like(buf_in)
+            res = []
+            for rep in range(6):  # same buffers, new contents every time
+                buf_in.copy_(xs[rep % 3].buf)
+                h.Kinv_x.apply(buf_in, out=out_k, n_loc=n_loc)
+                fam.apply(buf_in, out=out_f, n_loc=n_loc, cm=cm, kind=kind)
+                res.append((out_k.clone(), out_f.clone()))
+            outs[graph] = res
+            if graph:
+                stk.check(lib.stk_set_tuning(b'mg_graph_replays', 8))  # 2 x (6 - 2) at least
+            else:
+                assert lib.stk_set_tuning(b'mg_graph_replays', 1) != 0  # none without the key
+        for (k0, f0), (k1, f1) in zip(outs[0], outs[1]):
+            assert torch.equal(k0, k1) and torch.equal(f0, f1)
+        hists = {}
+        for graph in (0, 1):
+            stk.check(lib.stk_set_tuning(b'mg_graph', graph))
+            hist = []
+            _, it = PCG(h.WT_S_W, h.P, h.rhs, history=hist)
+            hists[graph] = (it, hist)
+        assert hists[0] == hists[1]
+    finally:
+        stk.check(lib.stk_set_tuning(b'mg_graph', 0))
 
 
 def test_strip_wise_sweeps_are_exact(stk):
