@@ -398,7 +398,9 @@ int stk_kron_plan_destroy(stk_kron_plan *plan);
  * if the dictionary form was built; rows_per_unit = 2 if a row-pair form was
  * built as well -- stk_kron_plan_apply uses it for slabs of 24 time steps and
  * more, the one-row form below (tuning key "pack_rows" = 1: no pairs in plans
- * created afterwards). */
+ * created afterwards).  packed = 0 with rows_per_unit = 2: matrices without a
+ * dictionary whose rows still share columns -- pairs with explicit values
+ * (stk_pack_pattern.vals), the plain sliced-ELL form below 24 time steps. */
 int stk_kron_plan_info(const stk_kron_plan *plan, int32_t *K, int32_t *n_codes,
                        int32_t *packed, int64_t *nnz_union,
                        int32_t *rows_per_unit);

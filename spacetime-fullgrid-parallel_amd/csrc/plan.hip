@@ -27,6 +27,14 @@ struct stk_kron_plan {
     // packed form: one row per slot row, and row pairs (slabs of >= PAIR_MIN_STEPS steps)
     stk_pack_pattern pack{}, pack_pairs{};
     bool paired = false;
+    // row pairs with explicit values (matrices without a dictionary): slot words
+    // and rows on the device, the values of all matrices on the host; the device
+    // array of a call lists the matrices of its terms in term order and is built
+    // on first use (stk_pack_pattern.vals)
+    bool explicit_pairs = false;
+    stk_pack_pattern pairs_x{};
+    std::vector<double> pairs_x_vals;  // [units][K][2][n_mats]
+    std::map<std::vector<int32_t>, double *> pairs_x_for;
     std::vector<void *> owned;  // every device allocation
     int64_t nnz_union = 0;
 };
@@ -172,6 +180,73 @@ int upload(stk_kron_plan *p, const std::vector<T> &host, T **dev)
     return 0;
 }
 
+// Row pairs for matrices whose values do not repeat: partners first brought next to
+// each other (stk_pack_match_order), then grouped like the dictionary form with
+// every entry as its own code (its position in the ELL arrays, 0 = no entry).
+int build_explicit_pairs(stk_kron_plan *p, int32_t M, int K, int n_mats, int col_bits,
+                         const std::vector<int32_t> &counts, const std::vector<int32_t> &ell_idx,
+                         const std::vector<int32_t> &row_ids, const std::vector<std::vector<double>> &ell_val)
+{
+    const int rp = 2, K2 = stk_pack_unit_slots(K, rp);
+    if (K2 == 0 || g_plan_pack_rows < 2) return 0;
+    std::vector<int32_t> perm(M);
+    if (stk_pack_match_order(M, K, counts.data(), ell_idx.data(), row_ids.data(), K2, 8192, perm.data())) return 1;
+    std::vector<int32_t> cnt2(M), idx2((size_t)M * K), own2(M), ent2((size_t)M * K);
+    for (int q = 0; q < M; ++q) {
+        const int pos = perm[q];
+        cnt2[q] = counts[pos];
+        own2[q] = row_ids[pos];
+        for (int e = 0; e < K; ++e) {
+            idx2[(size_t)q * K + e] = ell_idx[(size_t)pos * K + e];
+            ent2[(size_t)q * K + e] = (int32_t)((size_t)pos * K + e) + 1;
+        }
+    }
+    std::vector<int32_t> ucol((size_t)M * K2), ucode((size_t)M * K2 * rp), urows((size_t)M * rp);
+    int32_t n_units = 0;
+    if (stk_pack_group_rows(M, K, cnt2.data(), idx2.data(), ent2.data(), own2.data(), 0, rp, K2, &n_units, ucol.data(),
+                            ucode.data(), urows.data()))
+        return 1;
+    const size_t U = (size_t)n_units;
+    if (U > (size_t)(0.95 * M)) return 0;
+    std::vector<uint32_t> slots(U * K2);
+    for (size_t s2 = 0; s2 < U * K2; ++s2) slots[s2] = (uint32_t)ucol[s2];
+    p->pairs_x_vals.assign(U * K2 * rp * n_mats, 0.0);
+    for (size_t s2 = 0; s2 < U * K2 * rp; ++s2) {
+        const int32_t ent = ucode[s2];
+        if (ent > 0)
+            for (int m = 0; m < n_mats; ++m) p->pairs_x_vals[s2 * n_mats + m] = ell_val[m][(size_t)ent - 1];
+    }
+    urows.resize(U * rp);
+    uint32_t *d_slots;
+    int32_t *d_urows;
+    if (upload(p, slots, &d_slots) || upload(p, urows, &d_urows)) return 1;
+    p->pairs_x = stk_pack_pattern{M, K2, col_bits, 1, n_mats, rp, (int32_t)U, d_slots, d_urows, nullptr, nullptr};
+    p->explicit_pairs = true;
+    return 0;
+}
+
+// The explicit-value pattern for the matrices of a call's terms, in term order.
+const stk_pack_pattern *explicit_pattern_for(stk_kron_plan *p, int32_t n_terms, const stk_kron_pack_term *t,
+                                             stk_pack_pattern *out)
+{
+    std::vector<int32_t> mats(n_terms);
+    for (int k = 0; k < n_terms; ++k) mats[k] = t[k].mat;
+    auto it = p->pairs_x_for.find(mats);
+    if (it == p->pairs_x_for.end()) {
+        const size_t slots = (size_t)p->pairs_x.n_units * p->pairs_x.K * 2;
+        std::vector<double> sub(slots * n_terms);
+        for (size_t s2 = 0; s2 < slots; ++s2)
+            for (int k = 0; k < n_terms; ++k) sub[s2 * n_terms + k] = p->pairs_x_vals[s2 * p->n_mats + mats[k]];
+        double *dev = nullptr;
+        if (upload(p, sub, &dev)) return nullptr;
+        it = p->pairs_x_for.emplace(mats, dev).first;
+    }
+    *out = p->pairs_x;
+    out->n_mats = n_terms;
+    out->vals = it->second;
+    return out;
+}
+
 int build(stk_kron_plan *p, int32_t M, int32_t n_mats, const int32_t *const *indptr, const int32_t *const *indices,
           const double *const *data, const int32_t *order)
 {
@@ -251,7 +326,13 @@ int build(stk_kron_plan *p, int32_t M, int32_t n_mats, const int32_t *const *ind
         for (int m = 0; m < n_mats; ++m) std::memcpy(&key[m], &ell_val[m][s], 8);
         auto it = dict.find(key);
         if (it == dict.end()) {
-            if ((int64_t)dict.size() >= max_codes) return 0;  // too many distinct tuples: plain form only
+            if ((int64_t)dict.size() >= max_codes) {
+                // too many distinct tuples for a dictionary: rows may still share
+                // COLUMNS -- pairs with explicit values (kron_pack.hip, DICT = false)
+                std::vector<int32_t> counts(M);
+                for (int pos = 0; pos < M; ++pos) counts[pos] = u_ptr[pos + 1] - u_ptr[pos];
+                return build_explicit_pairs(p, M, K, n_mats, col_bits, counts, ell_idx, row_ids, ell_val);
+            }
             it = dict.emplace(key, (uint32_t)dict.size()).first;
         }
         code[s] = it->second;
@@ -376,7 +457,7 @@ extern "C" int stk_kron_plan_info(const stk_kron_plan *p, int32_t *K, int32_t *n
                                   int64_t *nnz_union, int32_t *rows_per_unit)
 {
     STK_REQUIRE(p, "stk_kron_plan_info: null plan");
-    if (rows_per_unit) *rows_per_unit = p->paired ? p->pack_pairs.rows_per_unit : 1;
+    if (rows_per_unit) *rows_per_unit = p->paired ? p->pack_pairs.rows_per_unit : (p->explicit_pairs ? 2 : 1);
     if (K) *K = p->K;
     if (n_codes) *n_codes = p->packed ? p->pack.n_codes : 0;
     if (packed) *packed = p->packed ? 1 : 0;
@@ -404,6 +485,20 @@ extern "C" int stk_kron_plan_apply(stk_kron_plan *p, void *stream, int32_t n_loc
         const stk_pack_pattern *form = p->paired && n_loc >= 24 ? &p->pack_pairs : &p->pack;
         return stk_kron_pack_apply(stream, form, n_loc, ld, n_terms, t, x, ghosts ? ghost_work : nullptr, beta, y);
     }
+    if (p->explicit_pairs && n_loc >= 24) {
+        // no dictionary, but pairs: the values of the terms' matrices travel with the slots
+        stk_pack_pattern form;
+        if (!explicit_pattern_for(p, n_terms, t, &form)) return 1;
+        stk_kron_pack_term in_order[3];
+        for (int k = 0; k < n_terms; ++k) in_order[k] = stk_kron_pack_term{t[k].tri, k};
+        if (ghosts) {
+            STK_REQUIRE(ghost_work, "stk_kron_plan_apply: ghost rows need ghost_work (2*M doubles)");
+            int rc = stk_interleave_ghosts(stream, p->M, x_lo, x_hi, ghost_work);
+            if (rc) return rc;
+        }
+        return stk_kron_pack_apply(stream, &form, n_loc, ld, n_terms, in_order, x, ghosts ? ghost_work : nullptr, beta,
+                                   y);
+    }
     stk_kron_ell_term terms[3];
     for (int k = 0; k < n_terms; ++k)
         terms[k] = stk_kron_ell_term{t[k].tri, p->ell_vals[t[k].mat], p->ovf_vals[t[k].mat], x, x_lo, x_hi};
@@ -423,6 +518,13 @@ extern "C" int stk_kron_plan_ghost_apply(stk_kron_plan *p, void *stream, int32_t
     if (p->packed) {
         const stk_pack_pattern *form = p->paired && n_loc >= 24 ? &p->pack_pairs : &p->pack;
         return stk_kron_pack_ghost_apply(stream, form, n_loc, ld, n_terms, t, x_lo, x_hi, y);
+    }
+    if (p->explicit_pairs && n_loc >= 24) {
+        stk_pack_pattern form;
+        if (!explicit_pattern_for(p, n_terms, t, &form)) return 1;
+        stk_kron_pack_term in_order[3];
+        for (int k = 0; k < n_terms; ++k) in_order[k] = stk_kron_pack_term{t[k].tri, k};
+        return stk_kron_pack_ghost_apply(stream, &form, n_loc, ld, n_terms, in_order, x_lo, x_hi, y);
     }
     STK_REQUIRE(x, "stk_kron_plan_ghost_apply: the plain form needs x");
     stk_kron_ell_term terms[3];

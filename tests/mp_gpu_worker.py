@@ -58,8 +58,8 @@ def main():
                          TridiagKronMatMPI(dd, h.M_t, h.A_x)])
     got = gathered(metric @ x)
     if rank == 0:
-        want = okron.sum_apply([(h.A_t, h.M_x), (h.M_t, h.A_x)], X)
-        assert rel(got, want) < 1e-12, ('metric', rel(got, want))
+        want_metric = okron.sum_apply([(h.A_t, h.M_x), (h.M_t, h.A_x)], X)
+        assert rel(got, want_metric) < 1e-12, ('metric', rel(got, want_metric))
     for name, op, ref in [('W', h.W, 'W'), ('WT', h.WT, 'WT'), ('S', h.S, 'S'),
                           ('P', h.P, 'P'), ('WTSW', h.WT_S_W, 'WT_S_W')]:
         x._invalidate()
@@ -92,6 +92,28 @@ def main():
         assert its == it_o, (its, it_o)
         assert np.allclose(hist, hist_o, rtol=1e-10, atol=1e-30), float(np.max(np.abs(np.asarray(hist) / np.asarray(hist_o) - 1)))
         assert rel(got, wo) < 1e-8
+    # the reference-arithmetic mode across ranks (general block-diagonal path: one
+    # hierarchy per wavelet level, time slices gathered per operator and rank)
+    h3 = hm.HeatEquationMPI(J_space=J_space, J_time=J_time, problem=problem, arithmetic='reference')
+    hist3 = []
+    w3, its3 = PCG(h3.WT_S_W, h3.P, h3.rhs, history=hist3)
+    got3 = gathered(w3)
+    if rank == 0:
+        assert its3 == it_o, (its3, it_o)
+        assert np.allclose(hist3, hist_o, rtol=1e-10, atol=1e-30)
+        assert rel(got3, wo) < 1e-9
+    # both forms of the halo on the packed path give the same operator
+    from source.mpi_kron import _FusedKronSum
+    x._invalidate()
+    y_overlap = gathered(metric @ x)
+    _FusedKronSum.overlap = False
+    try:
+        x._invalidate()
+        y_one_pass = gathered(metric @ x)
+    finally:
+        _FusedKronSum.overlap = True
+    if rank == 0:
+        assert rel(y_overlap, y_one_pass) < 1e-14 and rel(y_overlap, want_metric) < 1e-12
         print('mp_gpu_worker ok: size %d, %d PCG iterations' % (size, its))
     comm.Barrier()
 

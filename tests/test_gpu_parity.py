@@ -1766,6 +1766,72 @@ def test_kron_plan_from_csr_through_ctypes_only(stk):
     assert b'permutation' in lib.stk_last_error()
 
 
+def test_kron_plan_without_dictionary_through_ctypes_only(stk):
+    """stk_kron_plan_create on matrices whose values do not repeat (jittered
+    L-shape): the C planner reports no dictionary but row pairs (explicit values),
+    and stk_kron_plan_apply / _ghost_apply agree with dense NumPy and, bit for bit,
+    with the Python-planned explicit form -- for a subset and a permutation of the
+    plan's matrices as terms, with and without ghost rows, long and short slabs."""
+    import ctypes
+    from source.assembly import space_matrices
+    from source.linop import EllMatrices
+    from source.problem import problem_helper
+    lib = stk.lib()
+    rng = np.random.RandomState(99)
+    M_x, A_x = space_matrices(problem_helper('lshape_jitter', J_space=3, J_time=2)[0])
+    mats = [sp.csr_matrix(m) for m in (M_x, A_x, M_x + 0.5 * A_x)]
+    M = M_x.shape[0]
+    keep = [(m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data.astype(np.float64)) for m in mats]
+    arr = lambda j: (ctypes.c_void_p * len(mats))(*[k[j].ctypes.data for k in keep])
+    order = np.asarray(M_x.stk_row_order, dtype=np.int32)
+    plan = ctypes.c_void_p()
+    stk.check(lib.stk_kron_plan_create(M, len(mats), arr(0), arr(1), arr(2), order.ctypes.data, ctypes.byref(plan)))
+    K, codes, packed, rpu = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    stk.check(lib.stk_kron_plan_info(plan, ctypes.byref(K), ctypes.byref(codes), ctypes.byref(packed), None,
+                                     ctypes.byref(rpu)))
+    assert packed.value == 0 and rpu.value == 2 and K.value == 7
+    try:
+        for n_loc, use in [(33, (0, 1)), (65, (2, 0)), (24, (1,)), (40, (0, 1, 2)), (9, (0, 1))]:
+            ld = n_loc + (n_loc & 1)
+            X = rng.rand(M, n_loc)
+            lo, hi = rng.rand(M), rng.rand(M)
+            x = torch.zeros((M, ld), dtype=torch.float64, device='cuda')
+            x[:, :n_loc] = torch.from_numpy(X).cuda()
+            d_lo, d_hi = torch.from_numpy(lo).cuda(), torch.from_numpy(hi).cuda()
+            work = torch.empty((M, 2), dtype=torch.float64, device='cuda')
+            tris, terms = [], (stk.KronPackTerm * len(use))()
+            want = np.zeros((M, n_loc))
+            for k, m in enumerate(use):
+                t = rng.rand(3, n_loc)
+                T = np.diag(t[1]) + np.diag(t[0, 1:], -1) + np.diag(t[2, :-1], 1)
+                want += (mats[m] @ X) @ T.T
+                want[:, 0] += t[0, 0] * (mats[m] @ lo)
+                want[:, -1] += t[2, -1] * (mats[m] @ hi)
+                tris.append(_lib_dev(t))
+                terms[k].tri, terms[k].mat = stk.ptr(tris[-1]), m
+            y = torch.full((M, ld), float('nan'), dtype=torch.float64, device='cuda')
+            stk.check(lib.stk_kron_plan_apply(plan, stk.stream(), n_loc, ld, len(use), terms, stk.ptr(x),
+                                              stk.ptr(d_lo), stk.ptr(d_hi), stk.ptr(work), 0.0, stk.ptr(y)))
+            assert relerr(y[:, :n_loc].cpu().numpy(), want) < 1e-13, (n_loc, use)
+            # the overlapped form: without ghost rows, then their share
+            y2 = torch.full((M, ld), float('nan'), dtype=torch.float64, device='cuda')
+            stk.check(lib.stk_kron_plan_apply(plan, stk.stream(), n_loc, ld, len(use), terms, stk.ptr(x), None,
+                                              None, None, 0.0, stk.ptr(y2)))
+            stk.check(lib.stk_kron_plan_ghost_apply(plan, stk.stream(), n_loc, ld, len(use), terms, stk.ptr(x),
+                                                    stk.ptr(d_lo), stk.ptr(d_hi), stk.ptr(y2)))
+            assert relerr(y2[:, :n_loc].cpu().numpy(), want) < 1e-13, (n_loc, use)
+            if n_loc >= 24:  # the Python planner's explicit pairs: the same kernel on the same arrays
+                ell = EllMatrices([mats[m] for m in use], [M_x])
+                two = ell.packed_variant(2)
+                assert two.ok and two.explicit
+                gh = torch.stack([d_lo, d_hi], dim=1).contiguous()
+                y3 = torch.empty_like(y)
+                two.apply([(tris[k], k) for k in range(len(use))], x, gh, n_loc, ld, 0.0, y3)
+                assert torch.equal(y, y3), (n_loc, use)
+    finally:
+        stk.check(lib.stk_kron_plan_destroy(plan))
+
+
 def test_multigrid_plan_from_csr_through_ctypes_only(stk):
     """Row b / f1: the multigrid plan without any Python planner.
     stk_mg_create_from_csr gets the finest-level CSR matrices and the
