@@ -143,6 +143,47 @@ int stk_comm_exchange(stk_comm *comm, void *stream, int32_t n_send,
                       const stk_comm_msg *sends_host, int32_t n_recv,
                       const stk_comm_msg *recvs_host);
 
+/* ---- plan construction on the device (the set-up of MultiGrid.__init__,
+ *      multigrid.py:130-166, that the reference does with SciPy on the host) --------
+ * stk_ell_from_csr: the sliced-ELL copy (stk_ell_rows) of a CSR matrix resident on
+ * the device.  ELL row `pos` is CSR row order[pos] (order NULL: pos); K slots per
+ * row, unused ones = (pad_col, 0); pad_col < 0: the row's first kept column, or
+ * the row itself if it keeps none.  strip_diag: the diagonal entry goes to dia_a /
+ * dia_m only (Gauss-Seidel copies, diag_free); otherwise it stays among the slots
+ * and dia_a / dia_m (either may be NULL) still receive it.  grp (or NULL): keep
+ * only the entries whose column lies in an EARLIER dependency group than the row,
+ * grp[col] < grp[row] (the zero-start copies of the first sweep of a level visit).
+ * *overflow (device int32, zeroed by the caller) receives the longest row if one
+ * has more than K entries.
+ * stk_csr_galerkin: C = R A P for CSR matrices on the device, one row of C per
+ * thread, every sum accumulated in the order SciPy's (R @ A) @ P accumulates it and
+ * with separately rounded products and sums -- C is bit for bit the reference's
+ * Galerkin matrix.  Row i: row_counts[i] entries at out_indices / out_data
+ * [i*cap ...], columns ascending; cap <= 64; *overflow as above.  P = NULL (all
+ * three arrays): C = R A alone, the product the restricted residual uses.
+ * stk_gs_depth_step: one relaxation of the depth of every row in the dependency
+ * DAG of a Gauss-Seidel sweep in dof order (forward: row i waits for its
+ * neighbours j < i; backward: j > i), depth_out[i] = max depth_in[j] + 1;
+ * *changed (device int32) is set when any depth moved.  The host repeats it from
+ * depth = 0 until nothing changes; rows of equal depth are the groups mg.hip
+ * launches together (source/multigrid.py gauss_seidel_schedule). */
+int stk_ell_from_csr(void *stream, int32_t n_pos, int32_t K, const int32_t *order,
+                     const int32_t *indptr, const int32_t *indices,
+                     const double *vals_a, const double *vals_m, int32_t strip_diag,
+                     const int32_t *grp, int32_t pad_col, int32_t *idx_out,
+                     double *va_out, double *vm_out, double *dia_a, double *dia_m,
+                     int32_t *overflow);
+int stk_gs_depth_step(void *stream, int32_t n, const int32_t *indptr,
+                      const int32_t *indices, int32_t backward,
+                      const int32_t *depth_in, int32_t *depth_out, int32_t *changed);
+int stk_csr_galerkin(void *stream, int32_t nc, const int32_t *r_indptr,
+                     const int32_t *r_indices, const double *r_data,
+                     const int32_t *a_indptr, const int32_t *a_indices,
+                     const double *a_data, const int32_t *p_indptr,
+                     const int32_t *p_indices, const double *p_data, int32_t cap,
+                     int32_t *row_counts, int32_t *out_indices, double *out_data,
+                     int32_t *overflow);
+
 /* ---- BLAS-1 on flat arrays (KronVectorMPI arithmetic, mpi_vector.py:84-122,
  *      and dot, mpi_vector.py:205-210, local part) -------------------------- */
 /* y = a * x + b * y   (b == 0 ignores the old y; x == y allowed) */

@@ -285,7 +285,8 @@ static const int ROW_SLOTS[] = {2, 4, 5, 6, 7, 9, 12, 16, 20};
 
 // sliced-ELL copy of the rows `order` of a union pattern (source/linop.py
 // EllRowsMatrix): K = smallest slot count that holds the longest listed row,
-// unused slots: column pad_col, value 0.  ok = false if a row is too long.
+// unused slots: column pad_col (pad_col < 0: the row's first listed column, or the
+// row itself if it lists none), value 0.  ok = false if a row is too long.
 // diag = true (Gauss-Seidel copies): the diagonal entries go to dia_a / dia_m and
 // NOT into the slots (stk_ell_rows.diag_free).
 bool ell_rows(Builder &B, const Union &u, const std::vector<int32_t> &order, bool diag, int pad_col,
@@ -302,7 +303,7 @@ bool ell_rows(Builder &B, const Union &u, const std::vector<int32_t> &order, boo
     if (K == 0) return false;
     const size_t np = order.size();
     const bool has_m = !u.vm.empty();
-    std::vector<int32_t> idx(np * K, pad_col), rows(np);
+    std::vector<int32_t> idx(np * K, pad_col < 0 ? 0 : pad_col), rows(np);
     std::vector<double> va(np * K, 0.0), vm(has_m ? np * K : 0, 0.0), da, dm;
     if (diag || dia_a) {
         da.resize(np);
@@ -325,6 +326,11 @@ bool ell_rows(Builder &B, const Union &u, const std::vector<int32_t> &order, boo
         if (dia_a) {
             da[p] = (*dia_a)[i];
             if (has_m && dia_m) dm[p] = (*dia_m)[i];
+        }
+        if (pad_col < 0) {
+            int s = u.ptr[i + 1] - u.ptr[i] - (diag ? 1 : 0);
+            const int32_t pad = s > 0 ? idx[p * K] : i;
+            for (; s < K; ++s) idx[p * K + s] = pad;
         }
     }
     out->n_pos = (int32_t)np;
@@ -563,7 +569,9 @@ extern "C" int stk_mg_create_from_csr(int32_t n_levels, const stk_csr_host *A_fi
                     da[i] = u.va[diag[i]];
                     if (M_fine) dm[i] = u.vm[diag[i]];
                 }
-                const int safe = fwd_groups[0][0];
+                // unused slots repeat the row's first kept column (a row of an earlier
+                // group, written before this row in every order of the sweeps)
+                const int safe = -1;
                 K.fwd0.resize(fwd_groups.size());
                 bool ok0 = true;
                 for (size_t g = 0; g < fwd_groups.size(); ++g) {

@@ -119,6 +119,11 @@ _PROTOTYPES = {
     'stk_comm_halo_exchange': (ctypes.c_int, [c_p, c_p, c_i32, c_p, c_p, c_p, c_p]),
     'stk_comm_exchange': (ctypes.c_int, [c_p, c_p, c_i32, ctypes.POINTER(CommMsg), c_i32,
                                          ctypes.POINTER(CommMsg)]),
+    'stk_ell_from_csr': (ctypes.c_int, [c_p, c_i32, c_i32, c_p, c_p, c_p, c_p, c_p, c_i32, c_p,
+                                        c_i32, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'stk_gs_depth_step': (ctypes.c_int, [c_p, c_i32, c_p, c_p, c_i32, c_p, c_p, c_p]),
+    'stk_csr_galerkin': (ctypes.c_int, [c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                        c_i32, c_p, c_p, c_p, c_p]),
     'stk_timing_enable': (ctypes.c_int, [c_i32]),
     'stk_timing_reset': (ctypes.c_int, []),
     'stk_timing_get': (ctypes.c_int, [ctypes.c_char_p, c_p, c_p]),

@@ -170,27 +170,29 @@ class CompositeLinOp(SpaceOp):
 def union_pattern(mats):
     """One CSR pattern containing the patterns of all `mats`, and every
     matrix's values expanded onto it (zeros where it has no entry).  The fused
-    kernels walk the pattern once for all matrices."""
+    kernels walk the pattern once for all matrices.
+
+    The patterns are added with weights 2^k, so that an entry of the sum says
+    which matrices own it; a matrix's values then fall onto the union in their own
+    (row-major, column-sorted) order -- no search."""
     mats = [sp.csr_matrix(m) for m in mats]
-    pat = sp.csr_matrix(mats[0].shape)
     for m in mats:
-        ones = sp.csr_matrix((np.ones(m.nnz), m.indices, m.indptr),
-                             shape=m.shape)
-        pat = pat + ones
+        if not m.has_sorted_indices:
+            m.sort_indices()
+        m.sum_duplicates()
+    assert len(mats) <= 30
+    pat = None
+    for k, m in enumerate(mats):
+        own = sp.csr_matrix((np.full(m.nnz, float(1 << k)), m.indices, m.indptr),
+                            shape=m.shape)
+        pat = own if pat is None else pat + own
     pat = sp.csr_matrix(pat)
     pat.sort_indices()
-    rows_p = np.repeat(np.arange(pat.shape[0]), np.diff(pat.indptr))
-    key_p = rows_p.astype(np.int64) * pat.shape[1] + pat.indices
+    owners = pat.data.astype(np.int64)
     vals = []
-    for m in mats:
-        m = m.tocsr()
-        m.sort_indices()
-        rows_m = np.repeat(np.arange(m.shape[0]), np.diff(m.indptr))
-        key_m = rows_m.astype(np.int64) * m.shape[1] + m.indices
-        pos = np.searchsorted(key_p, key_m)
-        assert np.array_equal(key_p[pos], key_m)
+    for k, m in enumerate(mats):
         full = np.zeros(pat.nnz)
-        full[pos] = m.data
+        full[((owners >> k) & 1) == 1] = m.data
         vals.append(full)
     return pat.indptr.astype(np.int32), pat.indices.astype(np.int32), vals
 
@@ -233,85 +235,147 @@ class EllRowsMatrix:
     pattern) in the sliced-ELL form of the row-gather engine (stk_ell_rows,
     include/stk.h).  `order` lists the rows in processing order; `diag` makes
     the Gauss-Seidel copy (diagonal entries in their own arrays, off-diagonal
-    entries in the slots: stk_ell_rows.diag_free).  `ok` is False when a row
-    has more entries than the largest instantiated slot count."""
+    entries in the slots: stk_ell_rows.diag_free); `dia_values=True` keeps the whole
+    row in the slots and records the diagonal beside it; `earlier_group` (a group
+    index per row) keeps only the entries whose column lies in an earlier group
+    than the row (the zero-start copies of csrc/mg.hip).  `ok` is False when a row
+    has more entries than the largest instantiated slot count.
+
+    On a GPU the copy is made by libstk from the CSR arrays, which are uploaded
+    once per matrix (stk_ell_from_csr); without one (CPU tests of the planner) by
+    the NumPy code below, which produces the same arrays."""
     SLOTS = (2, 4, 5, 6, 7, 9, 12, 16, 20)
-    _tls = threading.local()  # per-thread (key, base arrays, referents)
+    _tls = threading.local()  # per-thread upload cache: (key, device arrays, referents)
 
     def __init__(self, indptr, indices, va, vm=None, order=None, n_cols=None,
-                 diag=False, pad_col=0, dia_values=None):
+                 diag=False, pad_col=0, dia_values=None, earlier_group=None,
+                 kept_counts=None):
         n = len(indptr) - 1
-        if diag:
-            # Gauss-Seidel copy: the diagonal goes to dia_a / dia_m and NOT into
-            # the slots (stk_ell_rows.diag_free, include/stk.h).  The forward and
-            # the backward copy of a level strip the same arrays: done once.
-            assert dia_values is None
-            key = (id(indptr), id(indices), id(va), id(vm))
-            held = getattr(EllRowsMatrix._tls, 'stripped', None)
-            if held is None or held[0] != key:
-                rows_of = np.repeat(np.arange(n), np.diff(indptr))
-                on = indices == rows_of
-                assert np.array_equal(np.bincount(rows_of[on], minlength=n),
-                                      np.ones(n, dtype=np.int64)), 'matrix lacks a diagonal entry'
-                off = ~on
-                ptr = np.concatenate([[0], np.cumsum(np.bincount(
-                    rows_of[off], minlength=n))]).astype(np.int32)
-                held = (key, (ptr, indices[off], va[off],
-                              None if vm is None else vm[off],
-                              (va[on], None if vm is None else vm[on])),
-                        (indptr, indices, va, vm))
-                EllRowsMatrix._tls.stripped = held
-            indptr, indices, va, vm, dia_values = held[1]
-        counts_all = np.diff(indptr)
         order = np.arange(n, dtype=np.int64) if order is None else np.asarray(
             order, dtype=np.int64)
+        counts = np.diff(indptr).astype(np.int64)
+        if earlier_group is not None:
+            counts = kept_counts  # entries per row that pass the filter (shared by the groups' copies)
+            if counts is None:
+                rows_of = np.repeat(np.arange(n), np.diff(indptr))
+                keep = earlier_group[indices] < earlier_group[rows_of]
+                counts = np.bincount(rows_of[keep], minlength=n)
+        elif diag:
+            counts = counts - 1  # every row has its diagonal entry (checked below)
         # slot count of THIS copy: widest of the rows it lists
-        kmax = int(counts_all[order].max()) if len(order) else 1
-        kmax_all = int(counts_all.max()) if n else 1
+        kmax = int(counts[order].max()) if len(order) else 1
         self.ok = kmax <= self.SLOTS[-1]
         if not self.ok:
             return
-        K = next(k for k in self.SLOTS if k >= kmax)
-        K_base = max(K, min(kmax_all, self.SLOTS[-1]))
-        # the (n, K) arrays in index order are built once per matrix and shared
-        # by all copies that only differ in the row order (a, fwd, bwd, ...)
-        key = (id(indptr), id(indices), id(va), id(vm), K_base, pad_col)
-        cache = getattr(EllRowsMatrix._tls, 'cache', None)  # threads build hierarchies side by side
-        base = cache[1] if cache is not None and cache[0] == key else None
-        if base is None:
-            pos = np.repeat(np.arange(n), counts_all)
-            slot = np.arange(len(indices)) - np.repeat(indptr[:-1], counts_all)
-            keep = slot < K_base  # wider rows are not listed by any copy sharing this base
-            pos, slot = pos[keep], slot[keep]
-            # unused slots: value 0 and a column the caller knows to be readable
-            idx0 = np.full((n, K_base), pad_col, dtype=np.int32)
-            idx0[pos, slot] = indices[keep]
-            ea0 = np.zeros((n, K_base))
-            ea0[pos, slot] = va[keep]
-            em0 = None
-            if vm is not None:
-                em0 = np.zeros((n, K_base))
-                em0[pos, slot] = vm[keep]
-            base = (idx0, ea0, em0)
-            # the key holds ids: the referents are kept alive with it
-            EllRowsMatrix._tls.cache = (key, base, (indptr, indices, va, vm))
-        idx0, ea0, em0 = base
+        K = next(k for k in self.SLOTS if k >= max(kmax, 1))
         npos = len(order)
         self.K, self.n_pos, self.n_rows = K, npos, n
-        self.idx = _lib.to_dev(idx0[order][:, :K])
-        self.va = _lib.to_dev(ea0[order][:, :K])
-        self.vm = None if em0 is None else _lib.to_dev(em0[order][:, :K])
+        want_dia = diag or dia_values is not None
+        if _lib.compute_device().type == 'cuda':
+            self._build_on_device(indptr, indices, va, vm, order, K, diag, pad_col,
+                                  want_dia, earlier_group)
+        else:
+            self._build_with_numpy(indptr, indices, va, vm, order, K, diag, pad_col,
+                                   want_dia, earlier_group)
         self.row_ids = _lib.to_dev(order.astype(np.int32))
-        self.dia_a = self.dia_m = None
-        if dia_values is not None:  # per-row diagonal given (rows in index order)
-            self.dia_a = _lib.to_dev(np.asarray(dia_values[0])[order])
-            if dia_values[1] is not None:
-                self.dia_m = _lib.to_dev(np.asarray(dia_values[1])[order])
         self.struct = _lib.EllRows(npos, n, K, _lib.ptr(self.idx),
                                    _lib.ptr(self.va), _lib.ptr(self.vm),
                                    _lib.ptr(self.row_ids),
                                    _lib.ptr(self.dia_a), _lib.ptr(self.dia_m),
                                    int(diag))
+
+    @classmethod
+    def _uploaded(cls, indptr, indices, va, vm):
+        """The CSR arrays on the device, uploaded once per matrix and thread (the
+        copies of one level -- a, fwd, bwd, the zero-start ones -- share them)."""
+        key = (id(indptr), id(indices), id(va), id(vm))
+        held = getattr(cls._tls, 'dev', None)
+        if held is None or held[0] != key:
+            dev = (_lib.to_dev(np.asarray(indptr, dtype=np.int32)),
+                   _lib.to_dev(np.asarray(indices, dtype=np.int32)),
+                   _lib.to_dev(np.asarray(va, dtype=np.float64)),
+                   None if vm is None else _lib.to_dev(np.asarray(vm, dtype=np.float64)))
+            held = (key, dev, (indptr, indices, va, vm))  # the key holds ids: keep the referents
+            cls._tls.dev = held
+        return held[1]
+
+    def _build_on_device(self, indptr, indices, va, vm, order, K, diag, pad_col,
+                         want_dia, earlier_group):
+        d_ptr, d_idx, d_va, d_vm = self._uploaded(indptr, indices, va, vm)
+        dev, npos = d_ptr.device, len(order)
+        f64 = dict(dtype=torch.float64, device=dev)
+        self.idx = torch.empty((npos, K), dtype=torch.int32, device=dev)
+        self.va = torch.empty((npos, K), **f64)
+        self.vm = None if vm is None else torch.empty((npos, K), **f64)
+        self.dia_a = torch.empty(npos, **f64) if want_dia else None
+        self.dia_m = torch.empty(npos, **f64) if want_dia and vm is not None else None
+        d_order = _lib.to_dev(order.astype(np.int32))
+        d_grp = None
+        if earlier_group is not None:  # uploaded once for the copies of all groups
+            held = getattr(self._tls, 'grp', None)
+            if held is None or held[0] is not earlier_group:
+                held = (earlier_group, _lib.to_dev(np.asarray(earlier_group, dtype=np.int32)))
+                self._tls.grp = held
+            d_grp = held[1]
+        overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(_lib.lib().stk_ell_from_csr(
+            _lib.stream(), npos, K, _lib.ptr(d_order), _lib.ptr(d_ptr), _lib.ptr(d_idx),
+            _lib.ptr(d_va), _lib.ptr(d_vm), int(diag), _lib.ptr(d_grp), int(pad_col),
+            _lib.ptr(self.idx), _lib.ptr(self.va), _lib.ptr(self.vm),
+            _lib.ptr(self.dia_a), _lib.ptr(self.dia_m), _lib.ptr(overflow)))
+        self._overflow = overflow  # read lazily: no synchronisation per copy
+        self._keep = (d_order, d_grp)
+
+    def check(self):
+        """Synchronises and verifies that no listed row was longer than K (the
+        host sizes K from the row lengths, so this can only fail for a matrix
+        without a diagonal entry in a Gauss-Seidel copy)."""
+        ov = getattr(self, '_overflow', None)
+        if ov is not None and int(ov.item()) != 0:
+            raise _lib.StkError('EllRowsMatrix: a row has %d entries for %d slots'
+                                % (int(ov.item()), self.K))
+
+    def _build_with_numpy(self, indptr, indices, va, vm, order, K, diag, pad_col,
+                          want_dia, earlier_group):
+        n = len(indptr) - 1
+        rows_of = np.repeat(np.arange(n), np.diff(indptr))
+        on = indices == rows_of
+        dia = None
+        if want_dia:
+            assert np.array_equal(np.bincount(rows_of[on], minlength=n),
+                                  np.ones(n, dtype=np.int64)), 'matrix lacks a diagonal entry'
+            dia = (np.asarray(va)[on], None if vm is None else np.asarray(vm)[on])
+        keep = np.ones(len(indices), dtype=bool)
+        if diag:
+            keep &= ~on
+        if earlier_group is not None:
+            keep &= earlier_group[indices] < earlier_group[rows_of]
+        counts = np.bincount(rows_of[keep], minlength=n)
+        ptr = np.concatenate([[0], np.cumsum(counts)])
+        k_idx, k_rows = np.asarray(indices)[keep], rows_of[keep]
+        slot = np.arange(len(k_idx)) - np.repeat(ptr[:-1], counts)
+        fits = slot < K
+        idx0 = np.full((n, K), max(pad_col, 0), dtype=np.int32)
+        if pad_col < 0:  # the row's first kept column, or the row itself
+            first = np.arange(n, dtype=np.int32)
+            has = counts > 0
+            first[has] = k_idx[ptr[:-1][has]]
+            idx0[:] = first[:, None]
+        idx0[k_rows[fits], slot[fits]] = k_idx[fits]
+        ea0 = np.zeros((n, K))
+        ea0[k_rows[fits], slot[fits]] = np.asarray(va)[keep][fits]
+        self.idx = _lib.to_dev(idx0[order])
+        self.va = _lib.to_dev(ea0[order])
+        self.vm = None
+        if vm is not None:
+            em0 = np.zeros((n, K))
+            em0[k_rows[fits], slot[fits]] = np.asarray(vm)[keep][fits]
+            self.vm = _lib.to_dev(em0[order])
+        self.dia_a = self.dia_m = None
+        if dia is not None:
+            self.dia_a = _lib.to_dev(dia[0][order])
+            if dia[1] is not None:
+                self.dia_m = _lib.to_dev(dia[1][order])
 
 
 class EllMatrices:

@@ -61,13 +61,85 @@ def _drop_roundoff(mat, rel=1e-14):
     return mat
 
 
-def gauss_seidel_schedule(indptr, indices, backward=False):
+def galerkin_product(R, A, P, cache=None):
+    """R A P (reference multigrid.py:142-145) as a SciPy CSR matrix with sorted
+    rows.  On a GPU the product is formed by libstk (stk_csr_galerkin: one coarse
+    row per thread, every sum accumulated in the order and with the roundings of
+    SciPy's `(R @ A) @ P`, so the result is bit for bit the host's -- asserted by
+    test_device_plan_construction_matches_host); without one, or for rows longer
+    than the kernel holds, by SciPy itself.  `cache`: dict that keeps the device
+    copies of R and P between the products of one level."""
+    R, A = sp.csr_matrix(R), sp.csr_matrix(A)
+    P = None if P is None else sp.csr_matrix(P)  # None: R A alone (restricted-residual product)
+
+    def on_host():
+        out = sp.csr_matrix(R @ A if P is None else R @ A @ P)
+        out.sort_indices()
+        return out
+
+    if _lib.compute_device().type != 'cuda' or R.shape[0] < 64:
+        return on_host()
+
+    def up(m, key=None):
+        if cache is not None and key is not None and key in cache:
+            return cache[key]
+        dev = (_lib.to_dev(m.indptr.astype(np.int32)), _lib.to_dev(m.indices.astype(np.int32)),
+               _lib.to_dev(m.data.astype(np.float64)))
+        if cache is not None and key is not None:
+            cache[key] = dev
+        return dev
+
+    nc, cap = R.shape[0], (16 if P is not None else 32)
+    dR, dA = up(R, ('R', id(R))), up(A)
+    dP = up(P, ('P', id(P))) if P is not None else (None, None, None)
+    dev = dR[0].device
+    counts = torch.empty(nc, dtype=torch.int32, device=dev)
+    idx = torch.empty((nc, cap), dtype=torch.int32, device=dev)
+    val = torch.empty((nc, cap), dtype=torch.float64, device=dev)
+    overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().stk_csr_galerkin(
+        _lib.stream(), nc, *[_lib.ptr(t) for t in dR + dA + dP], cap, _lib.ptr(counts),
+        _lib.ptr(idx), _lib.ptr(val), _lib.ptr(overflow)))
+    if int(overflow.item()) != 0:  # a row with more than `cap` entries: SciPy does it
+        return on_host()
+    counts = counts.cpu().numpy().astype(np.int64)
+    idx, val = idx.cpu().numpy(), val.cpu().numpy()
+    mask = np.arange(cap)[None, :] < counts[:, None]
+    indptr = np.concatenate([[0], np.cumsum(counts)])
+    out = sp.csr_matrix((val[mask], idx[mask], indptr),
+                        shape=(nc, A.shape[1] if P is None else P.shape[1]))
+    out.has_sorted_indices = True
+    return out
+
+
+def _depth_on_device(n, d_indptr, d_indices, backward):
+    """The DAG depth of every row by repeated relaxation on the device
+    (stk_gs_depth_step) -- the same fixed point as the NumPy loop below."""
+    dev = d_indptr.device
+    depth = [torch.zeros(n, dtype=torch.int32, device=dev),
+             torch.empty(n, dtype=torch.int32, device=dev)]
+    changed = torch.zeros(1, dtype=torch.int32, device=dev)
+    for it in range(n + 1):
+        changed.zero_()
+        _lib.check(_lib.lib().stk_gs_depth_step(
+            _lib.stream(), n, _lib.ptr(d_indptr), _lib.ptr(d_indices), int(backward),
+            _lib.ptr(depth[it & 1]), _lib.ptr(depth[1 - (it & 1)]), _lib.ptr(changed)))
+        if int(changed.item()) == 0:
+            break
+    return depth[it & 1].cpu().numpy().astype(np.int64)
+
+
+def gauss_seidel_schedule(indptr, indices, backward=False, on_device=None):
     """Groups the rows of a CSR pattern by their depth in the dependency DAG
     of a Gauss-Seidel sweep in dof order: row i must wait for its neighbours
     j < i (forward) or j > i (backward).  Returns (ptr, rows): rows of group g
     are rows[ptr[g]:ptr[g+1]], ascending (descending for backward), and are
-    mutually independent."""
+    mutually independent.  `on_device`: (indptr, indices) of the pattern as
+    device tensors -- the depths are then computed by libstk."""
     n = len(indptr) - 1
+    if on_device is not None and n > 0 and on_device[0].is_cuda:
+        depth = _depth_on_device(n, on_device[0], on_device[1], backward)
+        return _groups_by_depth(depth, n, backward)
     rows_of = np.repeat(np.arange(n), np.diff(indptr))
     dep = indices > rows_of if backward else indices < rows_of
     depth = np.zeros(n, dtype=np.int64)
@@ -81,6 +153,10 @@ def gauss_seidel_schedule(indptr, indices, backward=False):
         if np.array_equal(new, depth):
             break
         depth = new
+    return _groups_by_depth(depth, n, backward)
+
+
+def _groups_by_depth(depth, n, backward):
     order = np.argsort(depth, kind='stable')
     if backward:
         # descending row index inside a group, like the sequential sweep
@@ -146,9 +222,10 @@ class _DeviceHierarchy:
         Mm = [sp.csr_matrix(mat_m)] if self.has_m else None
         for j in reversed(range(self.J)):
             R, P = hierarchy.R_mats[j], hierarchy.P_mats[j]
-            A.insert(0, _drop_roundoff(sp.csr_matrix(R @ A[0] @ P)))
+            held = {}  # device copies of R and P, shared by the two products of the level
+            A.insert(0, _drop_roundoff(galerkin_product(R, A[0], P, held)))
             if self.has_m:
-                Mm.insert(0, _drop_roundoff(sp.csr_matrix(R @ Mm[0] @ P)))
+                Mm.insert(0, _drop_roundoff(galerkin_product(R, Mm[0], P, held)))
         self.mats_a, self.mats_m = A, Mm
         self.shape = A[-1].shape
         self._keep = []  # device tensors / host arrays the plan points into
@@ -209,7 +286,8 @@ class _DeviceHierarchy:
             transfers.start()
             ells = {'a': EllRowsMatrix(indptr, indices, vals[0], vm, tile)}
             for name, bw in (('fwd', False), ('bwd', True)):
-                ptr, rows = gauss_seidel_schedule(indptr, indices, bw)
+                ptr, rows = gauss_seidel_schedule(indptr, indices, bw,
+                                                  on_device=(dev['indptr'], dev['indices']))
                 host[name + '_ptr'] = ptr
                 dev[name + '_rows'] = _lib.to_dev(rows)
                 setattr(L, 'n_' + name, len(ptr) - 1)
@@ -225,9 +303,8 @@ class _DeviceHierarchy:
                     ells[name] = EllRowsMatrix(indptr, indices, vals[0], vm,
                                                listed, diag=True)
                 else:
-                    ells[name] = EllRowsMatrix(
-                        indptr, indices, vals[0], vm, listed,
-                        dia_values=(vals[0][diag], None if vm is None else vm[diag]))
+                    ells[name] = EllRowsMatrix(indptr, indices, vals[0], vm, listed,
+                                               dia_values=True)
                 if band is not None:
                     # band of every ELL position (ascending inside a group):
                     # lets the plan run the sweeps strip by strip (mg.hip)
@@ -278,7 +355,7 @@ class _DeviceHierarchy:
                 dev[name + '_indices'] = _lib.to_dev(m.indices.astype(np.int32))
                 dev[name + '_vals'] = _lib.to_dev(m.data.astype(np.float64))
                 ells[name] = EllRowsMatrix(m.indptr, m.indices, m.data, None, order)
-            prods = [_drop_roundoff(sp.csr_matrix(R @ m)) for m in mats]
+            prods = [_drop_roundoff(galerkin_product(R, m, None)) for m in mats]
             ra_ptr, ra_idx, ra_vals = union_pattern(prods)
             out['ra'] = EllRowsMatrix(ra_ptr, ra_idx, ra_vals[0],
                                       ra_vals[1] if self.has_m else None, tile_c)
@@ -293,8 +370,10 @@ class _DeviceHierarchy:
         updated neighbour is an exact zero.  Per dependency group, an ELL copy
         that keeps only the entries whose column lies in an EARLIER group --
         narrower rows, fewer gathers, and no need to zero u beforehand.  Unused
-        slots point at a row of group 0 (already written when groups >= 1 run;
-        group 0 itself gathers from f instead of u, see mg.hip)."""
+        slots repeat the row's first kept column (a row of an earlier group: written
+        before this row in every order the sweeps run in, strip-wise included);
+        group 0 keeps nothing, gathers from f instead of u (mg.hip) and pads with
+        its own row."""
         n = len(indptr) - 1
         if not groups or any(len(g) == 0 for g in groups):
             return
@@ -302,15 +381,10 @@ class _DeviceHierarchy:
         for g, rows in enumerate(groups):
             grp[rows] = g
         rows_of = np.repeat(np.arange(n), np.diff(indptr))
-        keep = grp[indices] < grp[rows_of]
-        counts = np.bincount(rows_of[keep], minlength=n)
-        f_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
-        f_idx, f_va = indices[keep], va[keep]
-        f_vm = vm[keep] if vm is not None else None
-        dia = (va[diag], vm[diag] if vm is not None else None)
-        safe = int(groups[0][0])
-        ells = [EllRowsMatrix(f_ptr, f_idx, f_va, f_vm, rows, pad_col=safe,
-                              dia_values=dia) for rows in groups]
+        kept = np.bincount(rows_of[grp[indices] < grp[rows_of]], minlength=n)
+        ells = [EllRowsMatrix(indptr, indices, va, vm, rows, pad_col=-1,
+                              dia_values=True, earlier_group=grp, kept_counts=kept)
+                for rows in groups]
         if not all(e.ok for e in ells):
             return
         arr = (_lib.EllRows * len(ells))(*[e.struct for e in ells])

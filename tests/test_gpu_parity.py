@@ -670,8 +670,10 @@ def test_baseline_configs_full_size_against_oracle(stk, problem, J_space, J_time
     with the oracle on the WHOLE vector; S and P, whose oracle needs seconds
     per time slice, on sampled time slices (space operators act slice by slice,
     so (S x)[t] only needs the rows t-1, t, t+1 of the time factors).  Config 5
-    has no oracle trajectory (hours of CPU): its solve is held to the iteration
-    count of the smaller configs' pattern and a monotone history."""
+    has no full oracle trajectory (hours of CPU): its solve is held to the
+    iteration count of the smaller configs' pattern and a monotone history, and
+    its HEAD -- the first three r.Pr, the iterate after two iterations, S / P / W
+    of the bench vector -- to an oracle fixture."""
     import heateq_mpi as hm
     from oracle import kron as okron
     from oracle import wavelets as ow
@@ -711,6 +713,31 @@ def test_baseline_configs_full_size_against_oracle(stk, problem, J_space, J_time
     w, iters = PCG(h.WT_S_W, h.P, h.rhs, history=hist)
     assert 10 <= iters <= 16 and hist[-1] < 1e-12
     assert all(b < a for a, b in zip(hist, hist[1:]))
+    if (problem, J_space, J_time) == ('square', 10, 7):
+        # config 5 has an oracle fixture for the HEAD of the trajectory (the first
+        # three r.Pr and the iterate after two iterations; tests/golden/
+        # make_oracle_vectors.py --lean --kmax 3: 21 minutes and 35 GB on the host)
+        # and for S, P, W of the bench's vector on the fixture's sample
+        g = load_golden('o1_pcg_square_J7_J10')
+        st, sx = (int(v) for v in g['sample_strides'])
+        _hist_dev('config5_head_fast', hist[:3], g['hist'][:3], 1e-9)
+        del w
+        xb = _vec(dd, _bench_vector(N, M))
+        assert relerr(_np(h.W @ xb)[::st, ::sx], g['WX_sample']) < 1e-13
+        assert relerr(_np(h.S @ xb)[::st, ::sx], g['SX_sample']) < 1e-10
+        assert relerr(_np(h.P @ xb)[::st, ::sx], g['PX_sample']) < 1e-10
+        del xb, h
+        torch.cuda.empty_cache()
+        # the reference-arithmetic mode on the same head: 1e-10 per entry, and the
+        # iterate after the oracle's two iterations
+        h = hm.HeatEquationMPI(J_space=J_space, J_time=J_time, problem=problem, arithmetic='reference')
+        hist = []
+        w, iters = PCG(h.WT_S_W, h.P, h.rhs, kmax=3, history=hist)
+        assert iters == int(g['iters']) == 2
+        _hist_dev('config5_head_reference_arithmetic', hist, g['hist'], 1e-10)
+        wn = _np(w)
+        assert abs(np.linalg.norm(wn) - g['w_norm']) < 1e-10 * g['w_norm']
+        assert relerr(wn[::st, ::sx], g['w_sample']) < 1e-10
 
 
 def test_serial_kron_linop_rectangular_and_operator_factors(stk):
@@ -1427,6 +1454,77 @@ def test_zero_start_first_sweep_is_exact(stk):
             stk.check(stk.lib().stk_set_tuning(b'mg_zero_start', 1))
         assert np.array_equal(res[0][0], res[1][0])
         assert np.array_equal(res[0][1], res[1][1])
+
+
+def test_device_plan_construction_matches_host(stk):
+    """the Galerkin products R A P (reference multigrid.py:142-145) and
+    the sliced-ELL copies of a hierarchy are made on the device (stk_csr_galerkin,
+    stk_ell_from_csr).  The products must be BIT FOR BIT SciPy's `R @ A @ P` --
+    pattern and values, on the square, the L-shape and the cube, for mass and
+    stiffness down the whole hierarchy -- and the ELL copies exactly the arrays the
+    NumPy planner builds (plain, Gauss-Seidel with and without the diagonal among
+    the slots, zero-start copies with their padding rule)."""
+    from source import multigrid as mgm
+    from source.assembly import prolongation_matrices, space_matrices
+    from source.linop import EllRowsMatrix, union_pattern
+    from source.problem import problem_helper
+    rng = np.random.RandomState(4)
+    for problem, J in (('square', 5), ('lshape', 4), ('cube', 2)):
+        mesh = problem_helper(problem, J_space=J, J_time=2)[0]
+        M_x, A_x = space_matrices(mesh)
+        P_mats = [sp.csr_matrix(P) for P in prolongation_matrices(mesh)]
+        for mat in (A_x, M_x, sp.csr_matrix(4.0 * M_x + 0.3 * A_x)):
+            fine = sp.csr_matrix(mat)
+            for P in reversed(P_mats):
+                R = P.T.tocsr()
+                want = sp.csr_matrix(R @ fine @ P)
+                want.sort_indices()
+                got = mgm.galerkin_product(R, fine, P)
+                if R.shape[0] >= 64:
+                    assert got.has_sorted_indices
+                assert np.array_equal(got.indptr, want.indptr), (problem, R.shape)
+                assert np.array_equal(got.indices, want.indices)
+                assert np.array_equal(got.data, want.data), (problem, R.shape,
+                                                             np.abs(got.data - want.data).max())
+                ra_want = sp.csr_matrix(R @ fine)
+                ra_want.sort_indices()
+                ra = mgm.galerkin_product(R, fine, None)
+                assert (np.array_equal(ra.indptr, ra_want.indptr) and np.array_equal(ra.indices, ra_want.indices)
+                        and np.array_equal(ra.data, ra_want.data)), (problem, R.shape, 'R A')
+                # the dependency groups of the sweeps: device relaxation = NumPy loop
+                if fine.shape[0] >= 64:
+                    fs = sp.csr_matrix(fine)
+                    fs.sort_indices()
+                    ip, ix = fs.indptr.astype(np.int32), fs.indices.astype(np.int32)
+                    for bw in (False, True):
+                        p_h, r_h = mgm.gauss_seidel_schedule(ip, ix, bw)
+                        p_d, r_d = mgm.gauss_seidel_schedule(ip, ix, bw, on_device=(stk.to_dev(ip), stk.to_dev(ix)))
+                        assert np.array_equal(p_h, p_d) and np.array_equal(r_h, r_d)
+                fine = want
+        # ELL copies: the device builder against the NumPy builder, array by array
+        indptr, indices, vals = union_pattern([A_x, M_x])
+        n = len(indptr) - 1
+        order = rng.permutation(n)
+        grp = rng.randint(0, 4, size=n)
+        rows_of = np.repeat(np.arange(n), np.diff(indptr))
+        kept = np.bincount(rows_of[grp[indices] < grp[rows_of]], minlength=n)
+        for kw in (dict(), dict(diag=True), dict(dia_values=True),
+                   dict(dia_values=True, earlier_group=grp, kept_counts=kept, pad_col=-1),
+                   dict(pad_col=3)):
+            for vm in (vals[1], None):
+                sub = order[:max(1, n // 3)]
+                dev = EllRowsMatrix(indptr, indices, vals[0], vm, sub, **kw)
+                dev.check()
+                host = EllRowsMatrix.__new__(EllRowsMatrix)
+                host._build_with_numpy(indptr, indices, vals[0], vm, np.asarray(sub, dtype=np.int64), dev.K,
+                                       kw.get('diag', False), kw.get('pad_col', 0),
+                                       kw.get('diag', False) or kw.get('dia_values') is not None,
+                                       kw.get('earlier_group'))
+                for name in ('idx', 'va', 'vm', 'dia_a', 'dia_m'):
+                    a, b = getattr(dev, name), getattr(host, name)
+                    assert (a is None) == (b is None), (problem, kw.keys(), name)
+                    if a is not None:
+                        assert torch.equal(a, b.to(a.device)), (problem, list(kw), name)
 
 
 def test_recorded_vcycles_replay_exactly(stk):
