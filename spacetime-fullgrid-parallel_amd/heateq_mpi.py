@@ -175,6 +175,10 @@ class HeatEquationMPI:
                  arithmetic='fast',
                  comm=None):
         start_time = MPI.Wtime()
+        # (label, seconds since the start) of the stages of the set-up, for
+        # tools/setup_profile.py --timeline
+        self.setup_timeline = []
+        mark = lambda label: self.setup_timeline.append((label, MPI.Wtime() - start_time))
         comm = MPI.COMM_WORLD if comm is None else comm
         assert arithmetic in ('fast', 'reference')
         if arithmetic == 'reference':
@@ -188,11 +192,13 @@ class HeatEquationMPI:
 
         mesh_space, bc_space, mesh_time, data, fn = problem_helper(
             problem, J_space=J_space, J_time=J_time)
+        mark('meshes')
         # --- TIME --- (heateq_mpi.py:78-88)
         self.A_t, self.L_t, self.M_t, self.G_t, self.u0_t = time_matrices(
             mesh_time)
         # --- SPACE --- (heateq_mpi.py:91-98)
         self.M_x, self.A_x = space_matrices(mesh_space)
+        mark('time and space matrices')
         self.N = self.A_t.shape[0]
         self.M = self.M_x.shape[0]
         assert (len(data['g']) == 0)
@@ -217,6 +223,7 @@ class HeatEquationMPI:
 
         # ---- Preconditioners in space ---- (heateq_mpi.py:141-162)
         hierarchy = MeshHierarchy(mesh_space)
+        mark('wavelets, prolongations')
         self.hierarchy = hierarchy
         from source import multigrid as _mg
         gs_form = _mg.GS_DIAG_FREE
@@ -266,6 +273,7 @@ class HeatEquationMPI:
                 for j in range(self.J_time + 1)
             ]
         _mg.GS_DIAG_FREE = gs_form
+        mark('multigrid plans, Kronecker plan, load vector')
         self.CAC_j = [
             CompositeLinOp([self.C_j[j], self.A_x, self.C_j[j]])
             for j in range(self.J_time + 1)
@@ -306,6 +314,7 @@ class HeatEquationMPI:
             _lib.stream(), self.M, self.rhs.n_loc, self.rhs.ld, _lib.ptr(u_t),
             _lib.ptr(u_x), _lib.ptr(self.rhs.buf)))
 
+        mark('operators and right-hand side')
         self.setup_time = MPI.Wtime() - start_time
         self.mem_after_mpi = mem()
 

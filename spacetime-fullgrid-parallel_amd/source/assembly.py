@@ -124,7 +124,25 @@ def free_dofs(mesh):
 
 
 def _restrict(mat, fd):
-    return _finish(sp.csr_matrix(mat)[fd, :].tocsc()[:, fd].tocsr())
+    """Rows and columns `fd` (ascending) of a matrix, explicit zeros dropped
+    (ngsolve_helper.py:38-45): a filter over the CSR arrays -- the entries keep
+    their values and their order, so the result is that of
+    `mat[fd, :][:, fd]` bit for bit, without the three format conversions."""
+    mat = sp.csr_matrix(mat)
+    mat.sum_duplicates()
+    n = mat.shape[0]
+    free = np.zeros(n, dtype=bool)
+    free[fd] = True
+    new_id = np.cumsum(free) - 1
+    rows_of = np.repeat(np.arange(n), np.diff(mat.indptr))
+    keep = free[rows_of] & free[mat.indices] & (mat.data != 0)
+    counts = np.bincount(new_id[rows_of[keep]], minlength=len(fd))
+    indptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    out = sp.csr_matrix((mat.data[keep].astype(np.float64),
+                         new_id[mat.indices[keep]].astype(np.int32), indptr),
+                        shape=(len(fd), len(fd)))
+    out.has_sorted_indices = True
+    return out
 
 
 def _rows_per_tile(rows_per_tile):

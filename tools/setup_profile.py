@@ -21,8 +21,24 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--J_space', type=int, default=9)
 ap.add_argument('--J_time', type=int, default=6)
 ap.add_argument('--top', type=int, default=18)
+ap.add_argument('--timeline', action='store_true', help='stages of HeatEquationMPI.__init__ as the driver runs them (threads and all), three times')
 args = ap.parse_args()
 torch.zeros(1, device='cuda')
+
+
+if args.timeline:
+    import heateq_mpi as hm
+    for rep in range(3):
+        t = time.time()
+        h = hm.HeatEquationMPI(J_space=args.J_space, J_time=args.J_time)
+        torch.cuda.synchronize()
+        print('set-up %d: %.2f s' % (rep, time.time() - t))
+        last = 0.0
+        for label, at in h.setup_timeline:
+            print('   %-48s +%.2f s  (at %.2f s)' % (label, at - last, at))
+            last = at
+        del h
+    sys.exit(0)
 
 
 def section(name, fn):
