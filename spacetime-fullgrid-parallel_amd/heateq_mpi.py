@@ -45,7 +45,11 @@ class SchurMPI(LinearOperatorMPI):
         S x = (I kron M_x) K u1 + (I kron A_x) K u2 + (G_t kron M_x) x
                                                    one fused kernel
     This equals the five-term sum in exact arithmetic because K (a fixed number
-    of V-cycles from zero) is linear; tests bound the difference."""
+    of V-cycles from zero) is linear; tests bound the difference.  The two K
+    applies are independent: they run side by side on two HIP streams
+    (MultiGrid.apply_pair; two_streams = False: one after the other)."""
+    two_streams = True
+
     def __init__(self, dofs_distr, A_t, L_t, M_t, G_t, M_x, A_x, Kinv_x):
         super().__init__(dofs_distr)
         self._factors = (A_t, L_t, M_t, G_t, M_x, A_x)
@@ -98,6 +102,7 @@ class SchurMPI(LinearOperatorMPI):
         n_loc, ld = vec_in.n_loc, vec_in.ld
         u = torch.empty_like(x)
         packed = self.ell.packed_for(n_loc)
+        pair = getattr(self.Kinv_x, 'apply_pair', None) if self.two_streams else None
         if packed.ok:
             # packed matrix stream, ghost time steps fused into the one pass
             # (csrc/kron_pack.hip); the halo has to be there first
@@ -115,10 +120,17 @@ class SchurMPI(LinearOperatorMPI):
                     self.time_communication = vec_in.communicate_bdr()
                     ghosts = vec_in.ghost_interleaved()
                 packed.apply(first, x, ghosts, n_loc, ld, 0.0, u)
-            v1 = self.Kinv_x.apply(u, n_loc=n_loc)
-            packed.apply([(self.tLT, 0), (self.tM, 1)], x, ghosts, n_loc, ld,
-                         0.0, u)
-            v2 = self.Kinv_x.apply(u, n_loc=n_loc)
+            if pair is not None:
+                # both right-hand sides first, then the two K applies side by side
+                u2 = torch.empty_like(x)
+                packed.apply([(self.tLT, 0), (self.tM, 1)], x, ghosts, n_loc, ld,
+                             0.0, u2)
+                v1, v2 = pair(u, u2, n_loc=n_loc)
+            else:
+                v1 = self.Kinv_x.apply(u, n_loc=n_loc)
+                packed.apply([(self.tLT, 0), (self.tM, 1)], x, ghosts, n_loc, ld,
+                             0.0, u)
+                v2 = self.Kinv_x.apply(u, n_loc=n_loc)
         else:
             first = [(self.tA, 0, x, None, None), (self.tL, 1, x, None, None)]
             if self.dofs_distr.size > 1:

@@ -89,8 +89,8 @@ class SpaceMatrix(SpaceOp):
         return self._ell if self._ell.ok else None
 
     def apply(self, x, out=None, n_loc=None, alpha=1.0, beta=0.0, z=None,
-              **kw):
-        ld = x.shape[1]
+              ld=None, **kw):
+        ld = x.shape[1] if ld is None else ld  # given: x / out are column ranges of wider slabs
         n_loc = ld if n_loc is None else n_loc
         if out is None:
             out = torch.empty((self.shape[0], ld),

@@ -190,6 +190,16 @@ class CompositeMPI(LinearOperatorMPI):
         return vec_out
 
 
+_SIDE = []
+
+
+def _side_stream():
+    """The second HIP stream of the process (independent halves of an operator)."""
+    if not _SIDE:
+        _SIDE.append(torch.cuda.Stream())
+    return _SIDE[0]
+
+
 class BlockDiagMPI(LinearOperatorMPI):
     """y[t] = C_t x[t] for a list of space operators indexed by the GLOBAL
     time index (reference mpi_kron.py:113-132).
@@ -197,7 +207,17 @@ class BlockDiagMPI(LinearOperatorMPI):
     Equal operator objects are applied to all their time slices in one batched
     call.  When every block is ``CompositeLinOp([C, A, C])`` with the C's taken
     from one MultiGrid family (multigrid.MultiGridFamily), all slices run
-    through a single batched V-cycle with per-slice matrix coefficients."""
+    through a single batched V-cycle with per-slice matrix coefficients.
+
+    two_streams (default False): two column ranges of the slab through C A C side
+    by side on two HIP streams, the way S runs its two independent K applies
+    (heateq_mpi.SchurMPI).  Bit-identical, and measured SLOWER for P -- 21.1 ->
+    25.9 ms on 65-step slabs, 5.5 -> 10.0 ms on 9-step slabs
+    (profiles/r03_op_times_two_streams_P_*.log): the two halves read the same
+    cache lines of every row and each streams the matrices once more.  The K
+    applies of S gain because they are whole, independent slabs."""
+    two_streams = False
+
     def __init__(self, dofs_distr, matrices_space):
         M = matrices_space[0].shape[0]
         for mat in matrices_space:
@@ -243,9 +263,32 @@ class BlockDiagMPI(LinearOperatorMPI):
             b[1].apply(vec_in.buf, out=vec_out.buf, n_loc=n_loc)
         elif b is not None and b[0] == 'family':
             _, fam, (cm, kind), mid = b
-            t1 = fam.apply(vec_in.buf, n_loc=n_loc, cm=cm, kind=kind)
-            t2 = mid.apply(t1, n_loc=n_loc)
-            fam.apply(t2, out=vec_out.buf, n_loc=n_loc, cm=cm, kind=kind)
+            half = ((n_loc + 1) // 2 + 1) & ~1  # even: the second range starts on a 16-byte pair
+            if type(self).two_streams and n_loc >= 8 and vec_in.buf.is_cuda and hasattr(mid, 'mat'):
+                # time slices are independent: two column ranges of the slab go
+                # through C A C side by side on two HIP streams (a twin plan owns
+                # the second set of level workspaces), filling each other's launch
+                # gaps and tails like the two K applies inside S
+                x, ld = vec_in.buf, vec_in.ld
+                t1, t2 = torch.empty_like(x), torch.empty_like(x)
+                main = torch.cuda.current_stream()
+                side = _side_stream()
+                side.wait_stream(main)
+                for (off, n), stream, twin in (((0, half), main, False),
+                                               ((half, n_loc - half), side, True)):
+                    with torch.cuda.stream(stream):
+                        cols = lambda t: t[:, off:]
+                        kw = dict(n_loc=n, cm=cm[off:], kind=kind[off:], twin=twin, ld=ld)
+                        fam.apply(cols(x), out=cols(t1), **kw)
+                        mid.apply(cols(t1), out=cols(t2), n_loc=n, ld=ld)
+                        fam.apply(cols(t2), out=cols(vec_out.buf), **kw)
+                for t in (x, t1, t2, vec_out.buf):
+                    t.record_stream(side)
+                main.wait_stream(side)
+            else:
+                t1 = fam.apply(vec_in.buf, n_loc=n_loc, cm=cm, kind=kind)
+                t2 = mid.apply(t1, n_loc=n_loc)
+                fam.apply(t2, out=vec_out.buf, n_loc=n_loc, cm=cm, kind=kind)
         else:
             # general case: the time slices of every distinct operator object
             # together (one slice at a time if all operators differ)

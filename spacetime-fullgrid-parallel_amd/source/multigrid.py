@@ -243,6 +243,8 @@ class _DeviceHierarchy:
         self.n_kinds = inv.shape[0]
         self.plan = None
         self.plan_ld = 0
+        self.twin = None  # a second plan on the same matrices with workspaces of its own
+        self.twin_ld = 0
         self.options = {}  # stk_mg_set_option keys of this hierarchy's plans
 
     def _fill_level(self, j, hierarchy):
@@ -391,32 +393,45 @@ class _DeviceHierarchy:
         host['fwd0'] = (ells, arr)
         L.ell_fwd0 = ctypes.cast(arr, ctypes.POINTER(_lib.EllRows))
 
-    def ensure_plan(self, ld):
-        if self.plan is not None and ld <= self.plan_ld:
-            return self.plan
-        if self.plan is not None:
-            _lib.check(_lib.lib().stk_mg_destroy(self.plan))
+    def _create_plan(self, ld):
         handle = ctypes.c_void_p()
         _lib.check(_lib.lib().stk_mg_create(
             self.J + 1, self.levels, self.smoothsteps, self.vcycles,
             self.n_kinds, _lib.ptr(self.coarse_inv), ld,
             ctypes.byref(handle)))
-        self.plan, self.plan_ld = handle, ld
         for key, value in self.options.items():
             _lib.check(_lib.lib().stk_mg_set_option(handle, key.encode(), int(value)))
-        return self.plan
+        return handle
+
+    def ensure_plan(self, ld, twin=False):
+        """The plan for slabs up to `ld` columns.  twin=True: a second plan on the
+        SAME matrices with level workspaces of its own, so that two applies can be
+        in flight at once on two streams (the two K applies inside S)."""
+        name, name_ld = ('twin', 'twin_ld') if twin else ('plan', 'plan_ld')
+        have = getattr(self, name)
+        if have is not None and ld <= getattr(self, name_ld):
+            return have
+        if have is not None:
+            _lib.check(_lib.lib().stk_mg_destroy(have))
+        handle = self._create_plan(ld)
+        setattr(self, name, handle)
+        setattr(self, name_ld, ld)
+        return handle
 
     def set_option(self, key, value):
         self.options[key] = int(value)
-        if self.plan is not None:
-            _lib.check(_lib.lib().stk_mg_set_option(self.plan, key.encode(), int(value)))
+        for handle in (self.plan, self.twin):
+            if handle is not None:
+                _lib.check(_lib.lib().stk_mg_set_option(handle, key.encode(), int(value)))
 
-    def apply(self, x, out, n_loc, ca, cm, kind):
-        ld = x.shape[1]
+    def apply(self, x, out, n_loc, ca, cm, kind, twin=False, ld=None):
+        """`ld`: leading dimension when x / out are column ranges of wider slabs
+        (their data pointers then start inside a row)."""
+        ld = x.shape[1] if ld is None else ld
         n_loc = ld if n_loc is None else n_loc
         if out is None:
             out = torch.empty_like(x)
-        plan = self.ensure_plan(ld)
+        plan = self.ensure_plan(ld, twin)
         _lib.check(_lib.lib().stk_mg_apply(plan, _lib.stream(), n_loc, ld, ca,
                                            _lib.ptr(cm), _lib.ptr(kind),
                                            _lib.ptr(x), _lib.ptr(out)))
@@ -424,8 +439,9 @@ class _DeviceHierarchy:
 
     def __del__(self):
         try:
-            if self.plan is not None:
-                _lib.lib().stk_mg_destroy(self.plan)
+            for handle in (self.plan, self.twin):
+                if handle is not None:
+                    _lib.lib().stk_mg_destroy(handle)
         except Exception:
             pass
 
@@ -454,9 +470,33 @@ class MultiGrid(SpaceOp):
         self.shape = self.mats[-1].shape
         self.dtype = np.float64
 
-    def apply(self, x, out=None, n_loc=None, **kw):
+    def apply(self, x, out=None, n_loc=None, twin=False, **kw):
         self.num_applies += 1
-        return self._dev.apply(x, out, n_loc, 1.0, None, None)
+        return self._dev.apply(x, out, n_loc, 1.0, None, None, twin=twin)
+
+    def apply_pair(self, x1, x2, n_loc=None):
+        """(K x1, K x2) with the two independent V-cycle chains side by side on two
+        HIP streams (a twin plan owns the second set of level workspaces).  Two
+        chains of ~300 dependent launches each fill each other's launch gaps and
+        tails: measured 15.8 -> 14.9 ms on 65-step slabs, 3.66 -> 2.97 ms on 9-step
+        slabs (profiles/r03_two_stream_k.log), bit-identical results."""
+        main = torch.cuda.current_stream()
+        side = self._side_stream()
+        side.wait_stream(main)
+        y1 = self.apply(x1, n_loc=n_loc)
+        with torch.cuda.stream(side):
+            y2 = self.apply(x2, n_loc=n_loc, twin=True)
+        x2.record_stream(side)   # allocated on the main stream, read on the side one
+        y2.record_stream(main)   # allocated on the side stream, read on the main one
+        main.wait_stream(side)
+        return y1, y2
+
+    _side = None
+
+    def _side_stream(self):
+        if MultiGrid._side is None:
+            MultiGrid._side = torch.cuda.Stream()
+        return MultiGrid._side
 
     def smooth(self, level, u, f, its, backward, n_loc=None):
         """`its` Gauss-Seidel sweeps on one level, in place on the slab u
@@ -498,8 +538,8 @@ class MultiGridFamily:
         kind = _lib.to_dev(np.array([k + 1 for k in members], dtype=np.int32))
         return cm, kind
 
-    def apply(self, x, out=None, n_loc=None, cm=None, kind=None):
-        return self._dev.apply(x, out, n_loc, self.ca, cm, kind)
+    def apply(self, x, out=None, n_loc=None, cm=None, kind=None, twin=False, ld=None):
+        return self._dev.apply(x, out, n_loc, self.ca, cm, kind, twin=twin, ld=ld)
 
     def apply_member(self, k, x, out=None, n_loc=None):
         n = x.shape[1] if n_loc is None else n_loc
@@ -511,6 +551,8 @@ class MultiGridFamily:
 
 
 class _FamilyMember(MultiGrid):
+    apply_pair = None  # members share the family's one plan: no second set of workspaces
+
     def __init__(self, family, k):
         self.family, self.member = family, k
         self.hierarchy = family.hierarchy

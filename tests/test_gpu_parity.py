@@ -1527,6 +1527,51 @@ def test_device_plan_construction_matches_host(stk):
                         assert torch.equal(a, b.to(a.device)), (problem, list(kw), name)
 
 
+def test_two_stream_multigrid_pair_is_exact(stk):
+    """S applies K to two independent right-hand sides; MultiGrid.apply_pair runs
+    the two V-cycle chains side by side on two HIP streams (twin plan = second set
+    of level workspaces).  Results must be bit for bit those of two applies on one
+    stream, buffers must survive the caching allocator across streams (repeated
+    with fresh allocations), and S itself must not depend on the switch.  P does
+    the same with two column ranges of the slab (time slices are independent):
+    BlockDiagMPI.two_streams."""
+    import heateq_mpi as hm
+    h = hm.HeatEquationMPI(J_space=5, J_time=4)
+    K = h.Kinv_x
+    rng = np.random.RandomState(31)
+    n_loc, M = h.N, h.M
+    for rep in range(6):
+        a = _vec(h.dofs_distr, rng.rand(n_loc, M)).buf
+        b = _vec(h.dofs_distr, rng.rand(n_loc, M)).buf
+        want = (K.apply(a, n_loc=n_loc).clone(), K.apply(b, n_loc=n_loc).clone())
+        got = K.apply_pair(a, b, n_loc=n_loc)
+        torch.cuda.synchronize()
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), rep
+        del a, b, got  # released while the side stream may still hold them
+        junk = [torch.rand((M, n_loc + (n_loc & 1)), dtype=torch.float64, device='cuda') for _ in range(3)]
+        del junk
+    from source.mpi_kron import BlockDiagMPI
+    for J_time in (4, 3, 5):  # 17, 9 and 33 time steps: odd slabs, uneven halves
+        hh = h if J_time == 4 else hm.HeatEquationMPI(J_space=4, J_time=J_time)
+        x = _vec(hh.dofs_distr, rng.rand(hh.N, hh.M))
+        BlockDiagMPI.two_streams = True  # (off by default: measured slower for P)
+        try:
+            y_two, p_two = _np(hh.S @ x), _np(hh.P @ x)
+            # zero-start off: the level-wide memset of the first sweep must stay
+            # inside the columns of its own half
+            stk.check(stk.lib().stk_set_tuning(b'mg_zero_start', 0))
+            p_two_memset = _np(hh.P @ x)
+            stk.check(stk.lib().stk_set_tuning(b'mg_zero_start', 1))
+            hm.SchurMPI.two_streams = BlockDiagMPI.two_streams = False
+            x._invalidate()
+            y_one, p_one = _np(hh.S @ x), _np(hh.P @ x)
+        finally:
+            hm.SchurMPI.two_streams, BlockDiagMPI.two_streams = True, False
+            stk.check(stk.lib().stk_set_tuning(b'mg_zero_start', 1))
+        assert np.array_equal(y_two, y_one) and np.array_equal(p_two, p_one), J_time
+        assert np.array_equal(p_two_memset, p_one), J_time
+
+
 def test_recorded_vcycles_replay_exactly(stk):
     """A multigrid application that recurs with the same operands can be recorded
     into a hipGraph on its second occurrence and replayed afterwards (tuning key
