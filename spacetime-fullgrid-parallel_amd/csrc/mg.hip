@@ -308,9 +308,14 @@ static int mgm(stk_mg *mg, hipStream_t st, int j, int n_loc, int ld, double ca, 
     const bool zero_start = u_zero && j >= 1 && can_zero_start(mg, j, ld);
     // (only the n_loc columns of this call, rounded up to a pair: the caller's slab may be a
     // column range of a wider one whose other columns another stream is working on)
-    if (u_zero && j >= 1 && !zero_start)
-        STK_HIP(hipMemset2DAsync(u_j, sizeof(double) * (size_t)ld, 0, sizeof(double) * (size_t)((n_loc + 1) & ~1),
-                                 (size_t)L.n, st));
+    if (u_zero && j >= 1 && !zero_start) {
+        const int cols = std::min(ld, (n_loc + 1) & ~1);
+        if (cols == ld)
+            STK_HIP(hipMemsetAsync(u_j, 0, sizeof(double) * (size_t)L.n * ld, st));
+        else
+            STK_HIP(hipMemset2DAsync(u_j, sizeof(double) * (size_t)ld, 0, sizeof(double) * (size_t)cols, (size_t)L.n,
+                                     st));
+    }
     if (j == 0) {
         const int total = L.n * n_loc;
         // the stored inverses are those of (vals_a + cm*vals_m) for cm != NULL,

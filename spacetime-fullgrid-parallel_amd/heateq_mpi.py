@@ -121,11 +121,15 @@ class SchurMPI(LinearOperatorMPI):
                     ghosts = vec_in.ghost_interleaved()
                 packed.apply(first, x, ghosts, n_loc, ld, 0.0, u)
             if pair is not None:
-                # both right-hand sides first, then the two K applies side by side
-                u2 = torch.empty_like(x)
-                packed.apply([(self.tLT, 0), (self.tM, 1)], x, ghosts, n_loc, ld,
-                             0.0, u2)
-                v1, v2 = pair(u, u2, n_loc=n_loc)
+                # the second right-hand side and its K apply on the side stream,
+                # beside the first K apply
+                def second():
+                    u2 = torch.empty_like(x)
+                    packed.apply([(self.tLT, 0), (self.tM, 1)], x, ghosts, n_loc,
+                                 ld, 0.0, u2)
+                    return u2
+
+                v1, v2 = pair(u, second, n_loc=n_loc, shared=(x, ghosts))
             else:
                 v1 = self.Kinv_x.apply(u, n_loc=n_loc)
                 packed.apply([(self.tLT, 0), (self.tM, 1)], x, ghosts, n_loc, ld,

@@ -474,20 +474,25 @@ class MultiGrid(SpaceOp):
         self.num_applies += 1
         return self._dev.apply(x, out, n_loc, 1.0, None, None, twin=twin)
 
-    def apply_pair(self, x1, x2, n_loc=None):
+    def apply_pair(self, x1, x2, n_loc=None, shared=()):
         """(K x1, K x2) with the two independent V-cycle chains side by side on two
         HIP streams (a twin plan owns the second set of level workspaces).  Two
         chains of ~300 dependent launches each fill each other's launch gaps and
         tails: measured 15.8 -> 14.9 ms on 65-step slabs, 3.66 -> 2.97 ms on 9-step
-        slabs (profiles/r03_two_stream_k.log), bit-identical results."""
+        slabs (profiles/r03_two_stream_k.log), bit-identical results.  x2 may be a
+        callable that produces the second right-hand side; it then runs on the
+        side stream too (`shared`: tensors of the main stream it reads)."""
         main = torch.cuda.current_stream()
         side = self._side_stream()
         side.wait_stream(main)
-        y1 = self.apply(x1, n_loc=n_loc)
         with torch.cuda.stream(side):
+            if callable(x2):
+                x2 = x2()
             y2 = self.apply(x2, n_loc=n_loc, twin=True)
-        x2.record_stream(side)   # allocated on the main stream, read on the side one
-        y2.record_stream(main)   # allocated on the side stream, read on the main one
+        y1 = self.apply(x1, n_loc=n_loc)
+        for t in (x2, y2) + tuple(t for t in shared if t is not None):
+            t.record_stream(side)
+            t.record_stream(main)
         main.wait_stream(side)
         return y1, y2
 
