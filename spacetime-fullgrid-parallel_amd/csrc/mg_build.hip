@@ -75,9 +75,14 @@ Csr transpose(const Csr &a)
     return t;  // rows come out sorted
 }
 
-// C = A B, each entry accumulated in the order of A's row entries and then B's
-// row entries (the order of SciPy's csr_matmat, so the sums round alike)
-Csr matmul(const Csr &a, const Csr &b)
+// C = A B exactly as SciPy's csr_matmat forms it: each entry accumulated in the
+// order of A's row entries and then B's row entries, exact zeros not emitted, and
+// -- `emit_sorted` false -- a row's entries emitted in REVERSE order of first touch
+// (csr_matmat's linked list), which is the order the next product of a chain
+// traverses them in.  (R A) P formed this way is bit for bit SciPy's `R @ A @ P`,
+// i.e. the reference's Galerkin matrix (multigrid.py:142-145), the Python
+// planner's, and stk_csr_galerkin's.
+Csr matmul(const Csr &a, const Csr &b, bool emit_sorted = true)
 {
     Csr c;
     c.rows = a.rows;
@@ -97,11 +102,16 @@ Csr matmul(const Csr &a, const Csr &b)
                     acc[j] = 0.0;
                     list.push_back(j);
                 }
-                acc[j] += v * b.val[f];
+                const double prod = v * b.val[f];  // rounded on its own, as the SciPy build does
+                acc[j] = acc[j] + prod;
             }
         }
-        std::sort(list.begin(), list.end());
+        if (emit_sorted)
+            std::sort(list.begin(), list.end());
+        else
+            std::reverse(list.begin(), list.end());
         for (int j : list) {
+            if (acc[j] == 0.0) continue;
             c.idx.push_back(j);
             c.val.push_back(acc[j]);
         }
@@ -412,10 +422,10 @@ extern "C" int stk_mg_create_from_csr(int32_t n_levels, const stk_csr_host *A_fi
         P[j] = from_host(P_host[j]);
         sort_rows(P[j]);
         R[j] = transpose(P[j]);
-        A[j] = matmul(matmul(R[j], A[j + 1]), P[j]);
+        A[j] = matmul(matmul(R[j], A[j + 1], /*emit_sorted=*/false), P[j]);
         drop_roundoff(A[j]);
         if (M_fine) {
-            Mm[j] = matmul(matmul(R[j], Mm[j + 1]), P[j]);
+            Mm[j] = matmul(matmul(R[j], Mm[j + 1], false), P[j]);
             drop_roundoff(Mm[j]);
         }
     }

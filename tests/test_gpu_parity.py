@@ -2032,6 +2032,9 @@ def test_multigrid_plan_from_csr_through_ctypes_only(stk):
                 assert relerr(got, want) < 1e-12, (problem, with_coords)
                 py = MultiGrid(A_x, hier, smoothsteps=3, vcycles=2) @ F
                 assert relerr(got, py) < 1e-13, (problem, with_coords)
+                # (the Galerkin matrices of the two planners agree bit for bit -- SciPy's
+                # accumulation order in both; the coarsest level's dense inverse comes
+                # from LAPACK in one and from Gauss-Jordan in the other)
                 stk.check(lib.stk_mg_destroy(plan))
                 # --- a family: C_j = (2^j M + 0.3 A)^-1, per-slice coefficients
                 cms = np.array([1.0, 2.0, 4.0])
