@@ -86,6 +86,44 @@ def _time_rows(buf, t_idx):
     return out
 
 
+def halo_route_plan(size, M, routes):
+    """Who sends which piece of which halo row to whom, in two phases, when every
+    row is cut into `routes` pieces that travel over different links: piece 0 goes
+    straight to the neighbour, piece j >= 1 through an intermediate rank (two hops).
+    A time slab sends its whole boundary row to ONE neighbour, i.e. over one of the
+    seven xGMI links of its GPU; on a fully connected node the other six idle.
+
+    Returns a list of transfers (phase, sender, receiver, row owner, direction,
+    a, b): `direction` +1 = the owner's LAST time row on its way to rank owner+1
+    (that rank's X_lo), -1 = its FIRST row on its way to owner-1 (X_hi); [a, b) =
+    the piece.  The list is the same on every rank and ordered, so that the
+    messages between any two ranks are posted in the same order on both sides."""
+    routes = max(1, min(int(routes), size - 1))
+    cuts = np.linspace(0, M, routes + 1).astype(np.int64)
+    plan = []
+    for phase in (1, 2):
+        for owner in range(size):
+            for direction in (+1, -1):
+                dest = owner + direction
+                if not 0 <= dest < size:
+                    continue
+                others = [q for q in range(size) if q not in (owner, dest)]
+                for j in range(routes):
+                    a, b = int(cuts[j]), int(cuts[j + 1])
+                    if b <= a:
+                        continue
+                    if j == 0 or not others:
+                        if phase == 1:
+                            plan.append((1, owner, dest, owner, direction, a, b))
+                        continue
+                    via = others[(j - 1 + owner) % len(others)]
+                    if phase == 1:
+                        plan.append((1, owner, via, owner, direction, a, b))
+                    else:
+                        plan.append((2, via, dest, owner, direction, a, b))
+    return plan
+
+
 _dot_ws = {}
 
 
@@ -348,10 +386,14 @@ class KronVectorMPI:
                     last.copy_(self.buf[:, self.n_loc - 1])
         if rank > 0:
             self.X_lo = self._ghost[0]
+        if rank + 1 < size:
+            self.X_hi = self._ghost[1]
+        if self.HALO_ROUTES > 1 and size > 2:
+            return self._routed_halo(first, last, callback)
+        if rank > 0:
             sends.append((first, rank - 1))
             recvs.append((self.X_lo, rank - 1))
         if rank + 1 < size:
-            self.X_hi = self._ghost[1]
             sends.append((last, rank + 1))
             recvs.append((self.X_hi, rank + 1))
         reqs = comm.exchange(sends, recvs)
@@ -366,6 +408,53 @@ class KronVectorMPI:
         self.communicated_bdr = True
         self._ghost_il_stale = True
         return time_communication
+
+    # Pieces a halo row is cut into so that they travel over different links
+    # (environment STK_HALO_ROUTES; 1 = the whole row straight to the neighbour).
+    # Opt-in: it has only ever run over gloo -- no multi-GPU node was available to
+    # measure it or to prove it on RCCL.
+    HALO_ROUTES = int(__import__('os').environ.get('STK_HALO_ROUTES', '1'))
+
+    def _routed_halo(self, first, last, callback):
+        """communicate_bdr with every row cut into HALO_ROUTES pieces: phase 1 =
+        the direct pieces and the first hops, phase 2 = the intermediates forward
+        what they hold (halo_route_plan)."""
+        comm, rank, size = self.dofs_distr.comm, self.rank, self.dofs_distr.size
+        plan = halo_route_plan(size, self.M, self.HALO_ROUTES)
+        held = {}
+
+        def source(owner, direction, a, b):  # a piece of MY row
+            return (last if direction > 0 else first)[a:b]
+
+        def target(direction, a, b):  # where a piece of a neighbour's row ends up
+            return (self.X_lo if direction > 0 else self.X_hi)[a:b]
+
+        waited = 0.0
+        for phase in (1, 2):
+            sends, recvs = [], []
+            for ph, src, dst, owner, direction, a, b in plan:
+                if ph != phase:
+                    continue
+                final = dst == owner + direction
+                if src == rank:
+                    buf = source(owner, direction, a, b) if owner == rank else held[(owner, direction, a)]
+                    sends.append((buf, dst))
+                if dst == rank:
+                    if final:
+                        recvs.append((target(direction, a, b), src))
+                    else:
+                        held[(owner, direction, a)] = torch.empty(
+                            b - a, dtype=torch.float64, device=self.buf.device)
+                        recvs.append((held[(owner, direction, a)], src))
+            reqs = comm.exchange(sends, recvs)
+            if phase == 1 and callback is not None:
+                callback()  # what does not need the halo, beside the first phase
+            start_time = MPI.Wtime()
+            comm.wait_all(reqs)
+            waited += MPI.Wtime() - start_time
+        self.communicated_bdr = True
+        self._ghost_il_stale = True
+        return waited
 
     def ghost_pair(self):
         """(2, M) buffer [X_lo; X_hi] filled by communicate_bdr."""

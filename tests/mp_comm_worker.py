@@ -58,6 +58,38 @@ def main():
     assert v.communicate_bdr(lambda: called.append(1)) == 0.0 and called  # cached
     v._invalidate()
     assert not v.communicated_bdr
+    # the same rows cut into pieces that travel through intermediate ranks (two
+    # hops; opt-in STK_HALO_ROUTES): every route count up to the ranks there are
+    from source.mpi_vector import halo_route_plan
+    for routes in (2, 3, 7):
+        KronVectorMPI.HALO_ROUTES = routes
+        try:
+            v._invalidate()
+            if v._ghost is not None:
+                v._ghost.fill_(-1.0)
+            called = []
+            v.communicate_bdr(lambda: called.append(1))
+            assert called == [1]
+            if rank > 0:
+                assert np.array_equal(v.X_lo.cpu().numpy(), X[dd.t_begin - 1]), routes
+            if rank + 1 < size:
+                assert np.array_equal(v.X_hi.cpu().numpy(), X[dd.t_end]), routes
+        finally:
+            KronVectorMPI.HALO_ROUTES = 1
+        plan = halo_route_plan(size, M, routes)
+        if size > 2:  # pieces really leave the direct link
+            assert any(ph == 2 for ph, *_ in plan), (size, routes)
+        # every row arrives whole: the pieces delivered to a rank tile [0, M)
+        for dest in range(size):
+            for direction in (+1, -1):
+                owner = dest - direction
+                if 0 <= owner < size:
+                    got = sorted((a, b) for ph, s_, d_, o_, dr, a, b in plan
+                                 if d_ == dest and o_ == owner and dr == direction
+                                 and d_ == o_ + dr)
+                    assert got[0][0] == 0 and got[-1][1] == M
+                    assert all(x[1] == y[0] for x, y in zip(got, got[1:]))
+    v._invalidate()
     # a5: arbitrary remote rows, pattern of every wavelet level
     for j in range(1, J + 1):
         S = wavelets.split(J, j).tocoo()
