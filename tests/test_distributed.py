@@ -52,6 +52,15 @@ def test_distributed_solve_ranks_sharing_one_gpu(nproc, problem):
 
 
 @pytest.mark.gpu
+def test_distributed_solve_with_routed_halo():
+    """The whole multi-rank worker (operators, both halo forms, solve in both
+    arithmetic modes) with every halo row cut into three pieces that travel through
+    intermediate ranks (opt-in STK_HALO_ROUTES)."""
+    out = _run('mp_gpu_worker.py', 4, {'STK_BACKEND': 'gloo', 'STK_HALO_ROUTES': '3'})
+    assert 'mp_gpu_worker ok' in out
+
+
+@pytest.mark.gpu
 def test_distributed_solve_on_slabs_long_enough_for_row_pairs():
     """Two ranks with 32 and 33 time steps each (J_time = 6): the Kronecker
     operators then run the row-pair form of the packed kernel together with its
