@@ -648,15 +648,21 @@ class SerialKron:
         self._space = as_space_op(mat_space)
 
     def matvec(self, x):
-        X = np.asarray(x, dtype=np.float64).reshape(self.K, self.L)
+        X = np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(self.K, self.L))
         ld_in, ld_out = self.K + (self.K & 1), self.N + (self.N & 1)
-        xin = torch.zeros((self.L, ld_in), dtype=torch.float64,
-                          device=_lib.compute_device())
-        xin[:, :self.K].copy_(torch.from_numpy(X).to(xin.device).t())
-        z = torch.empty((self.L, ld_out), dtype=torch.float64,
-                        device=xin.device)
-        _lib.check(_lib.lib().stk_time_dense_apply(
-            _lib.stream(), self.L, self.K, ld_in, self.N, ld_out,
+        dev = _lib.compute_device()
+        lib, st = _lib.lib(), _lib.stream()
+        # the reference's time-major host block <-> the space-major slab: libstk's
+        # upload / download (transposed on the device, padding columns zero)
+        xin = torch.empty((self.L, ld_in), dtype=torch.float64, device=dev)
+        _lib.check(lib.stk_slab_upload(st, self.L, self.K, ld_in, X.ctypes.data,
+                                       _lib.ptr(xin)))
+        z = torch.empty((self.L, ld_out), dtype=torch.float64, device=dev)
+        _lib.check(lib.stk_time_dense_apply(
+            st, self.L, self.K, ld_in, self.N, ld_out,
             _lib.ptr(self._time), _lib.ptr(xin), _lib.ptr(z)))
         y = self._space.apply(z, n_loc=self.N)
-        return y[:, :self.N].t().contiguous().cpu().numpy().reshape(-1)
+        out = np.empty((self.N, self.M))
+        _lib.check(lib.stk_slab_download(st, self.M, self.N, y.shape[1], _lib.ptr(y),
+                                         out.ctypes.data))
+        return out.reshape(-1)
