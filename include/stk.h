@@ -230,8 +230,10 @@ int stk_pcg_solve(void *stream, int64_t n, stk_operator_fn T, void *T_ctx,
  * "kron" (stk_kron_*_apply), "space" (stk_csr_spmm, stk_ell_spmm), "time"
  * (stk_time_*_apply), "wavelet", "multigrid" (stk_mg_apply, stk_mg_smooth),
  * "blas1" (stk_axpby(z), stk_dot).  Classes nest where entry points do (the
- * BLAS-1 calls of stk_pcg_solve are counted as blas1).  Communication time is
- * the caller's: the library does not communicate. */
+ * BLAS-1 calls of stk_pcg_solve are counted as blas1).  Applies enqueued on
+ * DIFFERENT streams are each timed on their own stream: where they overlap (the two
+ * K applies inside S run side by side), the seconds of a class add up to more than
+ * the wall time they took.  Communication time is the caller's. */
 int stk_timing_enable(int32_t on);
 int stk_timing_reset(void);
 int stk_timing_get(const char *op_class, int64_t *calls, double *seconds);

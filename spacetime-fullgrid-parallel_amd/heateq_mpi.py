@@ -343,7 +343,10 @@ class HeatEquationMPI:
 def main(argv=None):
     args = driver.parse('Solve heatequation on MI355X GPUs, one time slab each.', argv,
                         extra=[('schur', str, 'fused',
-                                'fused (2 multigrid applies per S) or reference')])
+                                'fused (2 multigrid applies per S) or reference'),
+                               ('arithmetic', str, 'fast',
+                                'fast, or reference: every regrouping of the build off '
+                                '(r.Pr history within 1e-10 of the CPU path, 2.3x slower)')])
     comm, rank, size = driver.start(args)
     heat = HeatEquationMPI(**driver.solver_arguments(args))
     # per-rank record, gathered and printed as one blob at the end

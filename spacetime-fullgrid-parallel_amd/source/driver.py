@@ -41,7 +41,7 @@ def parse(description, argv, extra=()):
 
 def solver_arguments(args):
     """Keyword arguments of HeatEquationMPI from a parsed command line."""
-    keys = [flag for flag, _, _, _ in _PROBLEM_OPTIONS] + ['schur']
+    keys = [flag for flag, _, _, _ in _PROBLEM_OPTIONS] + ['schur', 'arithmetic']
     return {k: getattr(args, k) for k in keys if hasattr(args, k)}
 
 
