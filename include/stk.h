@@ -612,7 +612,11 @@ int stk_mg_destroy(stk_mg *mg);
  * section 5).  "fuse_restrict": 1 = the restricted residual as (R A) u - R f from
  * the precomputed product R A (no fine-level residual is written), 0 = the
  * reference's R (A u - f) (multigrid.py:174-175), -1 = follow the process-wide
- * tuning key "mg_fuse_restrict" (default 1). */
+ * tuning key "mg_fuse_restrict" (default 1).  "strip_pct": the strips of the
+ * strip-wise smoothing of THIS plan as a percentage of the tuning key
+ * "mg_strip_mb" (results do not depend on it): plans whose applies run two at a
+ * time share the caches and want smaller strips, a plan that runs alone larger
+ * ones. */
 int stk_mg_set_option(stk_mg *plan, const char *key, int32_t value);
 /* u = MG(f): `vcycles` V-cycles from u = 0.  cm/kind: per-time-slice mass
  * coefficient and coarse-inverse index (device, n_loc) or NULL. */

@@ -132,6 +132,7 @@ struct stk_mg {
     // -1: follow the process-wide tuning key "mg_fuse_restrict"; 0 / 1: this plan's
     // own choice (stk_mg_set_option; 0 is part of the reference-arithmetic mode)
     int fuse_restrict = -1;
+    int strip_pct = 100;  // this plan's strips as a percentage of the tuning key "mg_strip_mb"
     // recorded V-cycle applications (see g_mg_graph)
     struct Recorded {
         const double *f, *cm;
@@ -184,11 +185,13 @@ static bool can_zero_start(const stk_mg *mg, int level, int ld)
 // with it the result bit for bit, is unchanged, while u and f of a strip
 // (`strip_mb` MB) are read from HBM once per smoothing call, not once per pass.
 // Returns the [S][its*ng][2] position table (positions of group q % ng), or NULL.
-static const std::vector<int32_t> *strip_table(const EllLevel &E, bool backward, int64_t rows, int ld, int its)
+static const std::vector<int32_t> *strip_table(const EllLevel &E, bool backward, int64_t rows, int ld, int its,
+                                               double strip_mb)
 {
+    const double g_mg_strip_mb = strip_mb;  // the process-wide strip size scaled by the plan's strip_pct
     static const bool debug = getenv("STK_DEBUG_STRIPS") != nullptr;
     if (debug)
-        fprintf(stderr, "strip_table: rows=%lld ld=%d its=%d bands=%d strip_mb=%d width=%d groups=%d\n",
+        fprintf(stderr, "strip_table: rows=%lld ld=%d its=%d bands=%d strip_mb=%g width=%d groups=%d\n",
                 (long long)rows, ld, its, E.n_tile_rows, g_mg_strip_mb, g_mg_strip_width,
                 (int)(backward ? E.bwd_pos : E.fwd_pos).size() - 1);
     if (g_mg_strip_mb <= 0 || E.n_tile_rows < 2 || its < 1) return nullptr;
@@ -251,7 +254,8 @@ static int smooth_level(stk_mg *mg, hipStream_t st, int level, int n_loc, int ld
         const std::vector<int32_t> &pos = backward ? E.bwd_pos : E.fwd_pos;
         const int ng = (int)pos.size() - 1;
         const bool zs = zero_start && !backward && its >= 1;
-        const std::vector<int32_t> *strips = strip_table(E, backward, L.n, ld, its);
+        const std::vector<int32_t> *strips =
+            strip_table(E, backward, L.n, ld, its, g_mg_strip_mb * (mg->strip_pct / 100.0));
         const int S = strips ? (int)(strips->size() / (2 * (size_t)ng * its)) : 1;
         const int Q = its * ng;
         for (int s = 0; s < S; ++s)
@@ -512,7 +516,12 @@ extern "C" int stk_mg_set_option(stk_mg *mg, const char *key, int32_t value)
         mg->fuse_restrict = value < 0 ? -1 : (value != 0);
         return 0;
     }
-    stk_set_error("stk_mg_set_option: unknown key '%s' (fuse_restrict)", key);
+    if (std::strcmp(key, "strip_pct") == 0) {
+        STK_REQUIRE(value >= 1 && value <= 10000, "stk_mg_set_option: strip_pct=%d not in 1..10000", value);
+        mg->strip_pct = value;
+        return 0;
+    }
+    stk_set_error("stk_mg_set_option: unknown key '%s' (fuse_restrict, strip_pct)", key);
     return 2;
 }
 

@@ -279,6 +279,11 @@ class HeatEquationMPI:
                     smoothsteps=smoothsteps, vcycles=vcycles)
                 self.Kinv_x, self.C_family = kinv.result(), family.result()
                 self.u0_x = u0_x.result()
+            # strips of the strip-wise smoothing (csrc/mg.hip), measured at config 3
+            # (profiles/r03_strip_sizes_two_streams.log): K's applies run two at a time
+            # inside S and share the caches, the family's applies run alone
+            self.Kinv_x._dev.set_option('strip_pct', 60)
+            self.C_family._dev.set_option('strip_pct', 160)
             self.C_j = self.C_family.members
         else:
             assert (precond == 'direct')
