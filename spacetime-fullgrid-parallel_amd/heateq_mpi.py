@@ -171,6 +171,14 @@ class HeatEquationMPI:
     hierarchies; family='reference' builds one MultiGrid per j from the assembled
     matrix, as reference heateq_mpi.py:147-153 does.
 
+    arithmetic='accurate' keeps the fast structure (two multigrid applies per S on
+    two streams, one batched V-cycle for P) and switches back only the two
+    regroupings that own the gap to the CPU path's r.Pr history (DESIGN.md section
+    5): Gauss-Seidel rows with their diagonal and the reference's update
+    u_i += (f_i - row_i u) / a_ii (multigrid.py:89-97), and the restricted residual
+    as R (A u - f) (multigrid.py:174-175).  Every entry of the history within 1e-10
+    of the CPU path (measured <= 5e-11 at configs 1-4) for 15 % of the solve time.
+
     arithmetic='reference' = schur='reference' + family='reference' + Gauss-Seidel
     rows with their diagonal (u_i += (f_i - row_i u) / a_ii, multigrid.py:89-97) +
     the restricted residual as R (A u - f) (multigrid.py:174-175) instead of
@@ -196,7 +204,7 @@ class HeatEquationMPI:
         self.setup_timeline = []
         mark = lambda label: self.setup_timeline.append((label, MPI.Wtime() - start_time))
         comm = MPI.COMM_WORLD if comm is None else comm
-        assert arithmetic in ('fast', 'reference')
+        assert arithmetic in ('fast', 'accurate', 'reference')
         if arithmetic == 'reference':
             schur = family = 'reference'
         self.arithmetic = arithmetic
@@ -243,8 +251,9 @@ class HeatEquationMPI:
         self.hierarchy = hierarchy
         from source import multigrid as _mg
         gs_form = _mg.GS_DIAG_FREE
-        if arithmetic == 'reference':
+        if arithmetic in ('reference', 'accurate'):
             _mg.GS_DIAG_FREE = False
+        unfused = False if arithmetic == 'accurate' else None  # restricted residual as R (A u - f)
         if precond == 'multigrid' and family == 'reference':
             # one hierarchy per wavelet level from the assembled matrix
             # (reference heateq_mpi.py:147-153)
@@ -272,11 +281,12 @@ class HeatEquationMPI:
                         [self.M_x, self.A_x]).packed_for(n_steps)))
                 u0_x = pool.submit(space_load, mesh_space, data['u0'])
                 kinv = pool.submit(on_dev(MultiGrid), self.A_x, hierarchy,
-                                   smoothsteps=smoothsteps, vcycles=vcycles)
+                                   smoothsteps=smoothsteps, vcycles=vcycles,
+                                   fuse_restrict=unfused)
                 family = pool.submit(
                     on_dev(MultiGridFamily), self.A_x, self.M_x, hierarchy, ca=alpha,
                     cms=[2**j for j in range(self.J_time + 1)],
-                    smoothsteps=smoothsteps, vcycles=vcycles)
+                    smoothsteps=smoothsteps, vcycles=vcycles, fuse_restrict=unfused)
                 self.Kinv_x, self.C_family = kinv.result(), family.result()
                 self.u0_x = u0_x.result()
             # strips of the strip-wise smoothing (csrc/mg.hip), measured at config 3
@@ -350,8 +360,10 @@ def main(argv=None):
                         extra=[('schur', str, 'fused',
                                 'fused (2 multigrid applies per S) or reference'),
                                ('arithmetic', str, 'fast',
-                                'fast, or reference: every regrouping of the build off '
-                                '(r.Pr history within 1e-10 of the CPU path, 2.3x slower)')])
+                                'fast; accurate: Gauss-Seidel and restricted residual in the '
+                                'reference\'s arithmetic (r.Pr history within 1e-10 of the CPU '
+                                'path, 15 %% slower); reference: every regrouping of the build '
+                                'off (2.3x slower)')])
     comm, rank, size = driver.start(args)
     heat = HeatEquationMPI(**driver.solver_arguments(args))
     # per-rank record, gathered and printed as one blob at the end

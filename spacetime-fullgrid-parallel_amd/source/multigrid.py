@@ -521,7 +521,7 @@ class MultiGridFamily:
     BlockDiagMPI recognises members of one family and runs all time slices in
     one batched V-cycle."""
     def __init__(self, mat_a, mat_m, hierarchy, ca, cms, smoothsteps=2,
-                 vcycles=1):
+                 vcycles=1, fuse_restrict=None):
         self.ca = float(ca)
         self.cms = [float(c) for c in cms]
         self.hierarchy = hierarchy
@@ -532,6 +532,8 @@ class MultiGridFamily:
 
         self._dev = _DeviceHierarchy(mat_a, mat_m, hierarchy, smoothsteps,
                                      vcycles, coarse)
+        if fuse_restrict is not None:
+            self._dev.set_option('fuse_restrict', bool(fuse_restrict))
         self.shape = self._dev.shape
         self.members = [_FamilyMember(self, k) for k in range(len(self.cms))]
         self._uniform = {}

@@ -15,13 +15,14 @@ from source.assembly import space_matrices  # noqa: E402
 from source.mesh import construct_2d_square_mesh  # noqa: E402
 from source.multigrid import MeshHierarchy, MultiGrid, MultiGridFamily  # noqa: E402
 
-n_loc = 65
-ld = 66
+n_loc = int(sys.argv[2]) if len(sys.argv) > 2 else 65
+ld = n_loc + (n_loc & 1)
 for J in [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else '7,8,9').split(',')]:
     mesh, _ = construct_2d_square_mesh(J)
     M_x, A_x = space_matrices(mesh)
     h = MeshHierarchy(mesh)
-    for name, mg in (('A-only', MultiGrid(A_x, h, 3, 2)),):
+    for name, mg in (('A-only (3 groups)', MultiGrid(A_x, h, 3, 2)),
+                     ('M+A (4 groups)', MultiGrid((M_x + A_x).tocsr(), h, 3, 2))):
         M = A_x.shape[0]
         u = torch.zeros((M, ld), dtype=torch.float64, device='cuda')
         f = torch.rand((M, ld), dtype=torch.float64, device='cuda')

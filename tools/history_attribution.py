@@ -38,6 +38,7 @@ VARIANTS = [
     ('schur=reference', {'schur': 'reference'}, True, {}),
     ('gs=full rows', {}, False, {}),
     ('restrict=R(Au-f)', {}, True, {'mg_fuse_restrict': 0}),
+    ('restrict=R(Au-f) + gs=full rows', {}, False, {'mg_fuse_restrict': 0}),
     ('family=reference', {'family': 'reference'}, True, {}),
     ('family=reference + restrict=R(Au-f)', {'family': 'reference'}, True, {'mg_fuse_restrict': 0}),
     ('family=reference + restrict=R(Au-f) + gs=full rows', {'family': 'reference'}, False,
