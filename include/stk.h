@@ -656,6 +656,27 @@ int stk_mg_create_from_csr(int32_t n_levels, const stk_csr_host *A_fine,
                            int32_t n_cms, const double *cms_host,
                            int32_t max_ld, stk_mg **out);
 
+/* ---- problem set-up: P1 assembly on the host threads of the library ----------
+ * Mass M and stiffness A of a triangulation, restricted to its free dofs, explicit
+ * zeros dropped: what the reference gets from NGSolve's BilForm(...).assemble()
+ * and source/ngsolve_helper.py:38-45 (heateq_mpi.py:91-96).  HOST arrays:
+ * points [nv][2], cells [nc][3] (vertex numbers), boundary [nv] (1 = Dirichlet
+ * vertex).  Every row sums the contributions of the triangles around its vertex in
+ * ascending triangle number, without fused multiply-adds: the result depends on
+ * the mesh alone, not on the number of threads.  Stiffness entries below zero_rel
+ * times the largest one are rounding noise of exact zeros and are dropped.
+ * The result is read with stk_p1_result_sizes / _copy (which = 0: A, 1: M; CSR with
+ * int32 indices, as mpi_shared_mem.py:46-48) and released with stk_p1_result_free. */
+typedef struct stk_p1_result stk_p1_result;
+int stk_p1_assemble_2d(int64_t nv, int64_t nc, const double *points,
+                       const int64_t *cells, const uint8_t *boundary,
+                       double zero_rel, stk_p1_result **out);
+int stk_p1_result_sizes(const stk_p1_result *r, int32_t *n_free, int64_t *nnz_a,
+                        int64_t *nnz_m);
+int stk_p1_result_copy(const stk_p1_result *r, int32_t which, int32_t *indptr,
+                       int32_t *indices, double *data);
+int stk_p1_result_free(stk_p1_result *r);
+
 #ifdef __cplusplus
 }
 #endif

@@ -217,6 +217,12 @@ class HeatEquationMPI:
         mesh_space, bc_space, mesh_time, data, fn = problem_helper(
             problem, J_space=J_space, J_time=J_time)
         mark('meshes')
+        # the load vector and the prolongations need the mesh only: beside the
+        # assembly, which runs on the host threads of libstk (no GIL held)
+        from concurrent.futures import ThreadPoolExecutor
+        early = ThreadPoolExecutor(max_workers=2)
+        u0_x = early.submit(space_load, mesh_space, data['u0'])
+        hierarchy = early.submit(MeshHierarchy, mesh_space)
         # --- TIME --- (heateq_mpi.py:78-88)
         self.A_t, self.L_t, self.M_t, self.G_t, self.u0_t = time_matrices(
             mesh_time)
@@ -246,7 +252,7 @@ class HeatEquationMPI:
             raise ValueError(wavelettransform)
 
         # ---- Preconditioners in space ---- (heateq_mpi.py:141-162)
-        hierarchy = MeshHierarchy(mesh_space)
+        hierarchy = hierarchy.result()
         mark('wavelets, prolongations')
         self.hierarchy = hierarchy
         from source import multigrid as _mg
@@ -257,7 +263,6 @@ class HeatEquationMPI:
         if precond == 'multigrid' and family == 'reference':
             # one hierarchy per wavelet level from the assembled matrix
             # (reference heateq_mpi.py:147-153)
-            self.u0_x = space_load(mesh_space, data['u0'])
             fuse = False if arithmetic == 'reference' else None
             self.Kinv_x = MultiGrid(self.A_x, hierarchy, smoothsteps=smoothsteps,
                                     vcycles=vcycles, fuse_restrict=fuse)
@@ -271,7 +276,6 @@ class HeatEquationMPI:
         elif precond == 'multigrid':
             # the two hierarchies (A_x alone; 2^j M_x + alpha A_x, all j in one
             # family) are independent host work (SciPy / NumPy release the GIL)
-            from concurrent.futures import ThreadPoolExecutor
             # worker threads start on device 0: pin them to this rank's GPU
             on_dev = _lib.in_device_context
             with ThreadPoolExecutor(max_workers=4) as pool:
@@ -279,7 +283,6 @@ class HeatEquationMPI:
                     n_steps = self.dofs_distr.t_end - self.dofs_distr.t_begin
                     pool.submit(on_dev(lambda: EllMatrices.shared(
                         [self.M_x, self.A_x]).packed_for(n_steps)))
-                u0_x = pool.submit(space_load, mesh_space, data['u0'])
                 kinv = pool.submit(on_dev(MultiGrid), self.A_x, hierarchy,
                                    smoothsteps=smoothsteps, vcycles=vcycles,
                                    fuse_restrict=unfused)
@@ -288,7 +291,6 @@ class HeatEquationMPI:
                     cms=[2**j for j in range(self.J_time + 1)],
                     smoothsteps=smoothsteps, vcycles=vcycles, fuse_restrict=unfused)
                 self.Kinv_x, self.C_family = kinv.result(), family.result()
-                self.u0_x = u0_x.result()
             # strips of the strip-wise smoothing (csrc/mg.hip), measured at config 3
             # (profiles/r03_strip_sizes_two_streams.log): K's applies run two at a time
             # inside S and share the caches, the family's applies run alone
@@ -297,13 +299,14 @@ class HeatEquationMPI:
             self.C_j = self.C_family.members
         else:
             assert (precond == 'direct')
-            self.u0_x = space_load(mesh_space, data['u0'])
             self.Kinv_x = InvLinOp(self.A_x)
             self.C_j = [
                 InvLinOp(2**j * self.M_x + alpha * self.A_x)
                 for j in range(self.J_time + 1)
             ]
         _mg.GS_DIAG_FREE = gs_form
+        self.u0_x = u0_x.result()
+        early.shutdown()
         mark('multigrid plans, Kronecker plan, load vector')
         self.CAC_j = [
             CompositeLinOp([self.C_j[j], self.A_x, self.C_j[j]])

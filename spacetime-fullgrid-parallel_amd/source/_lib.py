@@ -199,6 +199,10 @@ _PROTOTYPES = {
         ctypes.POINTER(CsrHost), c_p, c_i32, c_i32, c_i32, c_f64, c_i32, c_p,
         c_i32, ctypes.POINTER(c_p)
     ]),
+    'stk_p1_assemble_2d': (ctypes.c_int, [c_i64, c_i64, c_p, c_p, c_p, c_f64, ctypes.POINTER(c_p)]),
+    'stk_p1_result_sizes': (ctypes.c_int, [c_p, c_p, c_p, c_p]),
+    'stk_p1_result_copy': (ctypes.c_int, [c_p, c_i32, c_p, c_p, c_p]),
+    'stk_p1_result_free': (ctypes.c_int, [c_p]),
     'stk_mg_destroy': (ctypes.c_int, [c_p]),
     'stk_mg_set_option': (ctypes.c_int, [c_p, ctypes.c_char_p, c_i32]),
     'stk_mg_apply': (ctypes.c_int,

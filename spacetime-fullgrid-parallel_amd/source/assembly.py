@@ -199,8 +199,53 @@ def tile_row_order(mesh, rows_per_tile=None):
                                   small_lexsort=False)
 
 
-def space_matrices(mesh):
-    """Mass M_x and stiffness A_x on the free dofs (heateq_mpi.py:91-96)."""
+def _space_matrices_libstk(mesh):
+    """The 2-D assembly on the host threads of libstk (csrc/assemble.hip,
+    stk_p1_assemble_2d): rows summed triangle by triangle in ascending triangle
+    number.  Bit for bit the matrices of the SciPy path below on uniformly
+    refined meshes (every partial sum there is exact or a sum of equal terms)."""
+    import ctypes
+
+    from . import _lib
+    lib = _lib.lib()
+    pts = np.ascontiguousarray(mesh.points, dtype=np.float64)
+    cells = np.ascontiguousarray(mesh.cells, dtype=np.int64)
+    bnd = np.ascontiguousarray(mesh.boundary, dtype=np.uint8)
+    res = ctypes.c_void_p()
+    _lib.check(lib.stk_p1_assemble_2d(mesh.nv, len(cells), pts.ctypes.data, cells.ctypes.data,
+                                      bnd.ctypes.data, 1e-14, ctypes.byref(res)))
+    try:
+        n_free, nnz_a, nnz_m = ctypes.c_int32(), ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(lib.stk_p1_result_sizes(res, ctypes.byref(n_free), ctypes.byref(nnz_a),
+                                           ctypes.byref(nnz_m)))
+        mats = []
+        for which, nnz in ((0, nnz_a.value), (1, nnz_m.value)):
+            indptr = np.empty(n_free.value + 1, dtype=np.int32)
+            indices = np.empty(nnz, dtype=np.int32)
+            data = np.empty(nnz, dtype=np.float64)
+            _lib.check(lib.stk_p1_result_copy(res, which, indptr.ctypes.data, indices.ctypes.data,
+                                              data.ctypes.data))
+            mat = sp.csr_matrix((data, indices, indptr), shape=(n_free.value, n_free.value))
+            mat.has_sorted_indices = True
+            mat.has_canonical_format = True
+            mats.append(mat)
+    finally:
+        lib.stk_p1_result_free(res)
+    return mats[1], mats[0]
+
+
+def space_matrices(mesh, scipy_path=False):
+    """Mass M_x and stiffness A_x on the free dofs (heateq_mpi.py:91-96).
+    Triangulations are assembled by libstk (stk_p1_assemble_2d); tetrahedral
+    meshes, and scipy_path=True, take the NumPy / SciPy form below."""
+    if mesh.cells.shape[1] == 3 and not scipy_path:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            order = pool.submit(tile_row_order, mesh)
+            M, A = _space_matrices_libstk(mesh)
+            order = order.result()
+        M.stk_row_order = A.stk_row_order = order
+        return M, A
     vol, g = _simplex_geometry(mesh)
     c = mesh.cells
     nl = c.shape[1]
@@ -264,9 +309,20 @@ def _keast4():
 _QW3, _QL3 = _keast4()
 
 
+def _simplex_volumes(mesh):
+    """The volumes alone (same expressions as _simplex_geometry)."""
+    c = mesh.cells
+    if c.shape[1] != 3 or getattr(mesh, '_stk_geometry', None) is not None:
+        return _simplex_geometry(mesh)[0]
+    p = mesh.points
+    p0 = p[c[:, 0]]
+    e0, e1 = p[c[:, 1]] - p0, p[c[:, 2]] - p0
+    return np.abs(e0[:, 0] * e1[:, 1] - e0[:, 1] * e1[:, 0]) / 2.0
+
+
 def space_load(mesh, fn):
     """int fn * phi_i on the free dofs (heateq_mpi.py:102-103)."""
-    vol, _ = _simplex_geometry(mesh)
+    vol = _simplex_volumes(mesh)
     p = mesh.points
     c = mesh.cells
     qw, ql = (_QW, _QL) if c.shape[1] == 3 else (_QW3, _QL3)

@@ -255,7 +255,7 @@ def main():
         mesh, _ = meshfn(J_space)
         tmesh = mesh_mod.construct_interval(2**J_time)
         A_t, L_t, M_t, G_t, u0_t = asm.time_matrices(tmesh)
-        M_x, A_x = asm.space_matrices(mesh)
+        M_x, A_x = asm.space_matrices(mesh, scipy_path=True)  # the generator does not load libstk
         P_mats = asm.prolongation_matrices(mesh)
         u0_x = asm.space_load(
             mesh, lambda *c: np.prod([np.sin(np.pi * ck) for ck in c], axis=0))

@@ -47,7 +47,7 @@ def sample_strides(N, M):
 def build_oracle(problem, J_time, J_space):
     mesh, _, tmesh, data, _ = problem_helper(problem, J_space, J_time)
     A_t, L_t, M_t, G_t, u0_t = time_matrices(tmesh)
-    M_x, A_x = space_matrices(mesh)
+    M_x, A_x = space_matrices(mesh, scipy_path=True)  # the generator does not load libstk
     mats = dict(A_t=A_t, L_t=L_t, M_t=M_t, G_t=G_t, M_x=M_x, A_x=A_x,
                 P_mats=prolongation_matrices(mesh), u0_t=u0_t,
                 u0_x=space_load(mesh, data['u0']))

@@ -331,6 +331,42 @@ def test_mesh_assembly_identities(name):
         assert relerr(b, M_x @ u3(pts[:, 0], pts[:, 1], pts[:, 2])) < 5e-2
 
 
+def test_p1_assembler_matches_scipy_path(monkeypatch):
+    """stk_p1_assemble_2d (csrc/assemble.hip; host threads of libstk) against the
+    NumPy / SciPy form of the same assembly (heateq_mpi.py:91-96,
+    ngsolve_helper.py:38-45): bit for bit on the uniformly refined meshes of the
+    BASELINE configurations -- the oracle fixtures were produced from the SciPy
+    form --, the same pattern and values within a few ulp of the row's largest entry
+    on a mesh without any symmetry, and the same matrices whatever the number of
+    threads (the order of every sum is fixed by the mesh)."""
+    from source.assembly import space_matrices
+    from source.problem import problem_helper
+
+    def same(a, b):
+        return (a.shape == b.shape and np.array_equal(a.indptr, b.indptr)
+                and np.array_equal(a.indices, b.indices) and np.array_equal(a.data, b.data))
+
+    for problem, J in (('square', 1), ('square', 4), ('square', 7), ('lshape', 2), ('lshape', 6)):
+        mesh = problem_helper(problem, J_space=J, J_time=2)[0]
+        M1, A1 = space_matrices(mesh)
+        M0, A0 = space_matrices(mesh, scipy_path=True)
+        assert same(M1, M0) and same(A1, A0), (problem, J)
+        assert M1.indices.dtype == np.int32 and M1.indptr.dtype == np.int32
+        assert np.array_equal(M1.stk_row_order, M0.stk_row_order)
+    mesh = problem_helper('lshape_jitter', J_space=6, J_time=2)[0]
+    M1, A1 = space_matrices(mesh)
+    M0, A0 = space_matrices(mesh, scipy_path=True)
+    assert np.array_equal(A1.indices, A0.indices) and np.array_equal(M1.indices, M0.indices)
+    assert np.array_equal(A1.indptr, A0.indptr)
+    assert np.max(np.abs(M1.data - M0.data) / np.abs(M0.data)) < 1e-15
+    assert np.max(np.abs(A1.data - A0.data)) < 1e-15 * np.abs(A0.data).max()
+    assert abs(A1 - A1.T).max() < 1e-13
+    for threads in ('1', '3'):
+        monkeypatch.setenv('STK_HOST_THREADS', threads)
+        Mt, At = space_matrices(mesh)
+        assert same(Mt, M1) and same(At, A1), threads
+
+
 def test_numbering_gives_shallow_gauss_seidel_schedules():
     """The build-owned numbering (source/mesh.py) orders the new vertices of a
     level by edge class with the hypotenuse class last: the sequential sweep of
