@@ -275,7 +275,10 @@ def main():
                                                        J_space=args.J_space,
                                                        J_time=args.J_time)
     A_t, L_t, M_t, G_t, u0_t = time_matrices(mesh_time)
-    M_x, A_x = space_matrices(mesh_space)
+    # (the SciPy form of the assembly: the same matrices bit for bit on these meshes,
+    # and libstk -- with the HIP runtime it links -- stays unloaded until the CPU
+    # baseline's process pool has forked and finished)
+    M_x, A_x = space_matrices(mesh_space, scipy_path=True)
     N, M = A_t.shape[0], M_x.shape[0]
 
     # CPU baseline first: nothing has touched the GPU yet, so its process pool
