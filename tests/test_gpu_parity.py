@@ -991,7 +991,9 @@ def test_restricted_residual_variants_agree(stk):
     product R A (stk_mg_level.ell_ra): same V-cycle up to rounding."""
     import heateq_mpi as hm
     for problem, J_space in (('square', 5), ('lshape', 4)):
-        h = hm.HeatEquationMPI(J_space=J_space, J_time=3, problem=problem)
+        # (arithmetic='fast': its plans follow the process-wide key; the default
+        # arithmetic pins the two-step form per plan)
+        h = hm.HeatEquationMPI(J_space=J_space, J_time=3, problem=problem, arithmetic='fast')
         x = _vec(h.dofs_distr, np.random.RandomState(12).rand(h.N, h.M))
         res = []
         try:

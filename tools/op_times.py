@@ -26,6 +26,7 @@ ap.add_argument('--coarse-rows', type=int, default=4096)
 ap.add_argument('--coarse-pairs', type=int, default=0)
 ap.add_argument('--fuse-restrict', type=int, default=1)
 ap.add_argument('--zero-start', type=int, default=1)
+ap.add_argument('--arithmetic', default='accurate', help="HeatEquationMPI's arithmetic mode (accurate = the default, fast, reference)")
 ap.add_argument('--tune', default='', help='extra stk_set_tuning keys: key=value,...')
 args = ap.parse_args()
 from source import _lib  # noqa: E402
@@ -38,7 +39,8 @@ _lib.check(_lib.lib().stk_set_tuning(b'mg_zero_start', args.zero_start))
 for kv in filter(None, args.tune.split(',')):
     k, v = kv.split('=')
     _lib.check(_lib.lib().stk_set_tuning(k.encode(), int(v)))
-h = hm.HeatEquationMPI(J_space=args.J_space, J_time=args.J_time, problem=args.problem)
+h = hm.HeatEquationMPI(J_space=args.J_space, J_time=args.J_time, problem=args.problem, arithmetic=args.arithmetic)
+print('arithmetic=%s' % args.arithmetic)
 dd = h.dofs_distr
 x = KronVectorMPI(dd, seeded_slab(dd.t_begin, dd.t_end, h.M))
 y = x.copy()
