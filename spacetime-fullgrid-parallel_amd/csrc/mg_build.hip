@@ -12,11 +12,19 @@
 // planner (source/multigrid.py) builds the same plan with NumPy / SciPy; tests
 // compare V-cycles from the two.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <future>
 #include <map>
+#include <mutex>
 #include <numeric>
 #include <queue>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "stk_common.h"
@@ -82,15 +90,15 @@ Csr transpose(const Csr &a)
 // traverses them in.  (R A) P formed this way is bit for bit SciPy's `R @ A @ P`,
 // i.e. the reference's Galerkin matrix (multigrid.py:142-145), the Python
 // planner's, and stk_csr_galerkin's.
-Csr matmul(const Csr &a, const Csr &b, bool emit_sorted = true)
+// Rows [r0, r1) of the product; rows are independent, so the blocks of several
+// threads concatenate to the product formed by one.
+static void matmul_rows(const Csr &a, const Csr &b, bool emit_sorted, int r0, int r1, std::vector<int32_t> &counts,
+                        std::vector<int32_t> &idx, std::vector<double> &val)
 {
-    Csr c;
-    c.rows = a.rows;
-    c.cols = b.cols;
-    c.ptr.assign(a.rows + 1, 0);
     std::vector<double> acc(b.cols, 0.0);
     std::vector<int32_t> mark(b.cols, -1), list;
-    for (int i = 0; i < a.rows; ++i) {
+    counts.assign(r1 - r0, 0);
+    for (int i = r0; i < r1; ++i) {
         list.clear();
         for (int e = a.ptr[i]; e < a.ptr[i + 1]; ++e) {
             const int k = a.idx[e];
@@ -110,13 +118,55 @@ Csr matmul(const Csr &a, const Csr &b, bool emit_sorted = true)
             std::sort(list.begin(), list.end());
         else
             std::reverse(list.begin(), list.end());
+        const size_t before = idx.size();
         for (int j : list) {
             if (acc[j] == 0.0) continue;
-            c.idx.push_back(j);
-            c.val.push_back(acc[j]);
+            idx.push_back(j);
+            val.push_back(acc[j]);
         }
-        c.ptr[i + 1] = (int32_t)c.idx.size();
+        counts[i - r0] = (int32_t)(idx.size() - before);
     }
+}
+
+int host_threads()
+{
+    int T = (int)std::thread::hardware_concurrency();
+    if (const char *env = getenv("STK_HOST_THREADS")) T = atoi(env);
+    return std::max(1, std::min(T, 32));
+}
+
+Csr matmul(const Csr &a, const Csr &b, bool emit_sorted = true)
+{
+    Csr c;
+    c.rows = a.rows;
+    c.cols = b.cols;
+    c.ptr.assign(a.rows + 1, 0);
+    const int T = a.rows < 8192 ? 1 : host_threads();
+    // blocks of rows with equal shares of a's entries
+    std::vector<int> cut(T + 1, a.rows);
+    cut[0] = 0;
+    for (int k = 1; k < T; ++k)
+        cut[k] = (int)(std::lower_bound(a.ptr.begin(), a.ptr.end(), (int32_t)((int64_t)a.ptr[a.rows] * k / T)) - a.ptr.begin());
+    for (int k = 1; k <= T; ++k) cut[k] = std::min(a.rows, std::max(cut[k], cut[k - 1]));
+    std::vector<std::vector<int32_t>> counts(T), idx(T);
+    std::vector<std::vector<double>> val(T);
+    {
+        std::vector<std::thread> pool;
+        for (int k = 1; k < T; ++k)
+            pool.emplace_back([&, k] { matmul_rows(a, b, emit_sorted, cut[k], cut[k + 1], counts[k], idx[k], val[k]); });
+        matmul_rows(a, b, emit_sorted, cut[0], cut[1], counts[0], idx[0], val[0]);
+        for (auto &th : pool) th.join();
+    }
+    size_t total = 0;
+    for (int k = 0; k < T; ++k) total += idx[k].size();
+    c.idx.reserve(total);
+    c.val.reserve(total);
+    for (int k = 0; k < T; ++k) {
+        for (int i = cut[k]; i < cut[k + 1]; ++i) c.ptr[i + 1] = counts[k][i - cut[k]];
+        c.idx.insert(c.idx.end(), idx[k].begin(), idx[k].end());
+        c.val.insert(c.val.end(), val[k].begin(), val[k].end());
+    }
+    for (int i = 0; i < a.rows; ++i) c.ptr[i + 1] += c.ptr[i];
     return c;
 }
 
@@ -193,20 +243,31 @@ std::vector<int32_t> tile_order(const double *coords, int dim, int n, int rows_p
     for (int k = 0; k < dim; ++k) vol *= std::max(hi[k] - lo[k], 1e-30);
     const bool tiled = n > rows_per_tile;
     const double side = std::pow(vol / std::max(1.0, n / (double)rows_per_tile), 1.0 / dim);
-    auto tile = [&](int i, int k) {
-        return tiled ? (int64_t)std::floor((coords[(size_t)i * dim + k] - lo[k]) / side) : (int64_t)0;
+    // sort keys formed once: the tile (slowest axis first), then the coordinates
+    struct Key {
+        int64_t tile[3];
+        double c[3];
+        int32_t id;
     };
-    std::sort(order.begin(), order.end(), [&](int a, int b) {
-        for (int k = dim - 1; k >= 0; --k) {
-            const int64_t ta = tile(a, k), tb = tile(b, k);
-            if (ta != tb) return ta < tb;
+    std::vector<Key> keys(n);
+    for (int i = 0; i < n; ++i) {
+        Key &q = keys[i];
+        q.id = i;
+        for (int k = 0; k < 3; ++k) q.tile[k] = 0, q.c[k] = 0.0;
+        for (int k = 0; k < dim; ++k) {
+            const double v = coords[(size_t)i * dim + (dim - 1 - k)];  // slowest axis first
+            q.c[k] = v;
+            q.tile[k] = tiled ? (int64_t)std::floor((v - lo[dim - 1 - k]) / side) : (int64_t)0;
         }
-        for (int k = dim - 1; k >= 0; --k) {
-            const double ca = coords[(size_t)a * dim + k], cb = coords[(size_t)b * dim + k];
-            if (ca != cb) return ca < cb;
-        }
-        return a < b;
+    }
+    std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
+        for (int k = 0; k < 3; ++k)
+            if (a.tile[k] != b.tile[k]) return a.tile[k] < b.tile[k];
+        for (int k = 0; k < 3; ++k)
+            if (a.c[k] != b.c[k]) return a.c[k] < b.c[k];
+        return a.id < b.id;
     });
+    for (int i = 0; i < n; ++i) order[i] = keys[i].id;
     return order;
 }
 
@@ -271,7 +332,8 @@ std::vector<int32_t> coupling_bands(const double *coords, int dim, const Union &
 // ---- the builder -------------------------------------------------------------
 struct Builder {
     std::vector<void *> dev;  // every device allocation (adopted by the plan)
-    bool failed = false;
+    std::atomic<bool> failed{false};
+    std::mutex mu;  // the pieces of a level are built by several host threads
 
     template <typename T>
     const T *up(const std::vector<T> &h)
@@ -286,7 +348,10 @@ struct Builder {
             failed = true;
             return nullptr;
         }
-        dev.push_back(d);
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            dev.push_back(d);
+        }
         return d;
     }
 };
@@ -408,6 +473,17 @@ extern "C" int stk_mg_create_from_csr(int32_t n_levels, const stk_csr_host *A_fi
                 "stk_mg_create_from_csr: coefficients cms need the second matrix");
     STK_REQUIRE(!coords_host || (dim >= 1 && dim <= 3), "stk_mg_create_from_csr: dim=%d not in 1..3", dim);
     const int J = n_levels - 1;
+    // STK_PLAN_TIMING=1: seconds per stage of the planner on stderr
+    static const bool timing = getenv("STK_PLAN_TIMING") != nullptr;
+    std::map<std::string, double> spent;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t_last = now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto t = now();
+        spent[what] += std::chrono::duration<double>(t - t_last).count();
+        t_last = t;
+    };
     // ---- Galerkin hierarchies, coarse to fine (multigrid.py:142-145) -------------
     std::vector<Csr> A(n_levels), Mm(M_fine ? n_levels : 0), P(J), R(J);
     A[J] = from_host(*A_fine);
@@ -417,18 +493,35 @@ extern "C" int stk_mg_create_from_csr(int32_t n_levels, const stk_csr_host *A_fi
         sort_rows(Mm[J]);
     }
     for (int j = J - 1; j >= 0; --j) {
-        STK_REQUIRE(P_host[j].n_rows == A[j + 1].rows, "stk_mg_create_from_csr: P[%d] has %d rows, level %d has %d", j,
-                    P_host[j].n_rows, j + 1, A[j + 1].rows);
+        const int fine_rows = j + 1 == J ? A_fine->n_rows : P_host[j + 1].n_cols;
+        STK_REQUIRE(P_host[j].n_rows == fine_rows, "stk_mg_create_from_csr: P[%d] has %d rows, level %d has %d", j,
+                    P_host[j].n_rows, j + 1, fine_rows);
         P[j] = from_host(P_host[j]);
         sort_rows(P[j]);
         R[j] = transpose(P[j]);
-        A[j] = matmul(matmul(R[j], A[j + 1], /*emit_sorted=*/false), P[j]);
-        drop_roundoff(A[j]);
-        if (M_fine) {
-            Mm[j] = matmul(matmul(R[j], Mm[j + 1], false), P[j]);
-            drop_roundoff(Mm[j]);
-        }
     }
+    lap("copy in, sort rows");
+    // The chain of Galerkin products runs beside the plan of the finest level, which
+    // needs nothing of it.  Worker threads work on the caller's device.
+    int device = 0;
+    (void)hipGetDevice(&device);
+    std::thread chain([&] {
+        for (int j = J - 1; j >= 0; --j) {
+            A[j] = matmul(matmul(R[j], A[j + 1], /*emit_sorted=*/false), P[j]);
+            drop_roundoff(A[j]);
+            if (M_fine) {
+                Mm[j] = matmul(matmul(R[j], Mm[j + 1], false), P[j]);
+                drop_roundoff(Mm[j]);
+            }
+        }
+    });
+    struct Joiner {  // no return path leaves the thread running
+        std::thread &t;
+        ~Joiner()
+        {
+            if (t.joinable()) t.join();
+        }
+    } chain_guard{chain};
     Builder B;
     std::vector<stk_mg_level> lv(n_levels);
     std::memset(lv.data(), 0, sizeof(stk_mg_level) * n_levels);
@@ -439,7 +532,14 @@ extern "C" int stk_mg_create_from_csr(int32_t n_levels, const stk_csr_host *A_fi
         std::vector<stk_ell_rows> fwd0;
     };
     std::vector<Keep> keep(n_levels);
-    for (int j = 0; j <= J; ++j) {
+    // processing order of a level = of the first n dofs (levels are nested); formed once per size
+    std::map<int, std::vector<int32_t>> tile_orders;
+    auto tile_of = [&](int n) -> const std::vector<int32_t> & {
+        auto it = tile_orders.find(n);
+        if (it == tile_orders.end()) it = tile_orders.emplace(n, tile_order(coords_host, dim, n)).first;
+        return it->second;
+    };
+    auto build_level = [&](int j) -> int {
         const Union u = make_union(A[j], M_fine ? &Mm[j] : nullptr);
         const int n = u.n;
         stk_mg_level &L = lv[j];
@@ -456,14 +556,46 @@ extern "C" int stk_mg_create_from_csr(int32_t n_levels, const stk_csr_host *A_fi
         L.vals_a = B.up(u.va);
         L.vals_m = M_fine ? B.up(u.vm) : nullptr;
         L.diag = B.up(diag);
-        if (j == 0) continue;
+        lap("union pattern, CSR upload");
+        if (j == 0) return 0;
         // processing order (mesh tiles if coordinates are known) and bands
-        const std::vector<int32_t> tile = tile_order(coords_host, dim, n);
+        const std::vector<int32_t> &tile = tile_of(n);
+        const std::vector<int32_t> &tile_c = tile_of(P[j - 1].cols);
+        // the transfer operators and the products R A need neither the union pattern
+        // nor the schedules: two tasks beside the rest of the level
+        std::future<bool> transfers = std::async(std::launch::async, [&, j]() -> bool {
+            (void)hipSetDevice(device);
+            const Union up_ = union_of(P[j - 1]), ur = union_of(R[j - 1]);
+            L.p_indptr = B.up(up_.ptr);
+            L.p_indices = B.up(up_.idx);
+            L.p_vals = B.up(up_.va);
+            L.r_indptr = B.up(ur.ptr);
+            L.r_indices = B.up(ur.idx);
+            L.r_vals = B.up(ur.va);
+            bool ok = ell_rows(B, up_, tile, false, 0, nullptr, nullptr, &K.p);
+            return ell_rows(B, ur, tile_c, false, 0, nullptr, nullptr, &K.r) && ok;
+        });
+        // restricted residual in one step: d = (R A) u - R f
+        std::future<bool> products = std::async(std::launch::async, [&, j]() -> bool {
+            (void)hipSetDevice(device);
+            Csr ra = matmul(R[j - 1], A[j]);
+            drop_roundoff(ra);
+            Csr rm;
+            if (M_fine) {
+                rm = matmul(R[j - 1], Mm[j]);
+                drop_roundoff(rm);
+            }
+            const Union ura = make_union(ra, M_fine ? &rm : nullptr);
+            return ell_rows(B, ura, tile_c, false, 0, nullptr, nullptr, &K.ra);
+        });
         std::vector<int64_t> rank(n);
         for (int p = 0; p < n; ++p) rank[tile[p]] = p;
+        lap("tile order");
         const std::vector<int32_t> band = coupling_bands(coords_host, dim, u);
+        lap("bands");
         auto key = [&](int i) { return (band.empty() ? (int64_t)0 : (int64_t)band[i] * n) + rank[i]; };
         bool ells_ok = ell_rows(B, u, tile, false, 0, nullptr, nullptr, &K.a);
+        lap("ELL copy of the level matrix");
         std::vector<std::vector<int32_t>> fwd_groups;
         for (int bw = 0; bw < 2; ++bw) {
             // depth in the dependency DAG of the sweep in dof order (row i waits for
@@ -492,6 +624,7 @@ extern "C" int stk_mg_create_from_csr(int32_t n_levels, const stk_csr_host *A_fi
                 rows.insert(rows.end(), g.begin(), g.end());
                 ptr.push_back((int32_t)rows.size());
             }
+            lap("sweep schedules");
             // ELL copy: each group band by band, tile order inside a band
             std::vector<int32_t> listed, trow;
             for (auto &g : groups) {
@@ -500,8 +633,10 @@ extern "C" int stk_mg_create_from_csr(int32_t n_levels, const stk_csr_host *A_fi
             }
             if (!band.empty())
                 for (int i : listed) trow.push_back(band[i]);
+            lap("sweep orders");
             stk_ell_rows *dst = bw ? &K.bwd : &K.fwd;
             ells_ok = ell_rows(B, u, listed, true, 0, nullptr, nullptr, dst) && ells_ok;
+            lap("ELL copies of the sweeps");
             if (bw) {
                 K.bwd_ptr = ptr;
                 K.bwd_trow = trow;
@@ -517,18 +652,10 @@ extern "C" int stk_mg_create_from_csr(int32_t n_levels, const stk_csr_host *A_fi
         }
         L.fwd_ptr_host = K.fwd_ptr.data();
         L.bwd_ptr_host = K.bwd_ptr.data();
-        // transfers
-        const Union up_ = union_of(P[j - 1]), ur = union_of(R[j - 1]);
-        L.p_indptr = B.up(up_.ptr);
-        L.p_indices = B.up(up_.idx);
-        L.p_vals = B.up(up_.va);
-        L.r_indptr = B.up(ur.ptr);
-        L.r_indices = B.up(ur.idx);
-        L.r_vals = B.up(ur.va);
-        const std::vector<int32_t> tile_c = tile_order(coords_host, dim, ur.n);
-        ells_ok = ell_rows(B, up_, tile, false, 0, nullptr, nullptr, &K.p) && ells_ok;
-        ells_ok = ell_rows(B, ur, tile_c, false, 0, nullptr, nullptr, &K.r) && ells_ok;
-        if (!ells_ok) continue;
+        ells_ok = transfers.get() && ells_ok;
+        const bool ra_ok = products.get();
+        lap("waiting for transfers and R A products");
+        if (!ells_ok) return 0;
         L.ell_a = &K.a;
         L.ell_fwd = &K.fwd;
         L.ell_bwd = &K.bwd;
@@ -541,18 +668,7 @@ extern "C" int stk_mg_create_from_csr(int32_t n_levels, const stk_csr_host *A_fi
             L.fwd_tile_row_host = K.fwd_trow.data();
             L.bwd_tile_row_host = K.bwd_trow.data();
         }
-        // restricted residual in one step: d = (R A) u - R f
-        {
-            Csr ra = matmul(R[j - 1], A[j]);
-            drop_roundoff(ra);
-            Csr rm;
-            if (M_fine) {
-                rm = matmul(R[j - 1], Mm[j]);
-                drop_roundoff(rm);
-            }
-            const Union ura = make_union(ra, M_fine ? &rm : nullptr);
-            if (ell_rows(B, ura, tile_c, false, 0, nullptr, nullptr, &K.ra)) L.ell_ra = &K.ra;
-        }
+        if (ra_ok) L.ell_ra = &K.ra;
         // first sweep from u = 0: per forward group, only the entries towards earlier groups
         {
             bool nonempty = !fwd_groups.empty();
@@ -584,10 +700,10 @@ extern "C" int stk_mg_create_from_csr(int32_t n_levels, const stk_csr_host *A_fi
                 const int safe = -1;
                 K.fwd0.resize(fwd_groups.size());
                 bool ok0 = true;
+                // (has_m must follow the plan, also for an empty value array)
+                if (M_fine && f.vm.size() != f.idx.size()) f.vm.assign(f.idx.size(), 0.0);
                 for (size_t g = 0; g < fwd_groups.size(); ++g) {
-                    Union fg = f;  // (has_m must follow the plan, also for an empty value array)
-                    if (M_fine && fg.vm.size() != fg.idx.size()) fg.vm.assign(fg.idx.size(), 0.0);
-                    ok0 = ell_rows(B, fg, fwd_groups[g], false, safe, &da, M_fine ? &dm : nullptr, &K.fwd0[g]) && ok0;
+                    ok0 = ell_rows(B, f, fwd_groups[g], false, safe, &da, M_fine ? &dm : nullptr, &K.fwd0[g]) && ok0;
                     if (M_fine && K.fwd0[g].vm == nullptr) {  // group without entries: still needs a vm array
                         std::vector<double> z((size_t)K.fwd0[g].n_pos * K.fwd0[g].K, 0.0);
                         K.fwd0[g].vm = B.up(z);
@@ -595,6 +711,18 @@ extern "C" int stk_mg_create_from_csr(int32_t n_levels, const stk_csr_host *A_fi
                 }
                 if (ok0) L.ell_fwd0 = K.fwd0.data();
             }
+        }
+        lap("zero-start copies");
+        return 0;
+    };
+    {
+        int rc = build_level(J);
+        chain.join();
+        lap("waiting for the Galerkin products");
+        for (int j = J - 1; j >= 0 && rc == 0; --j) rc = build_level(j);
+        if (rc) {
+            for (void *d : B.dev) (void)hipFree(d);
+            return rc;
         }
     }
     // ---- exact coarse inverses: kind 0 = A_0 alone, kind 1 + k = ca*A_0 + cms[k]*M_0 --
@@ -630,5 +758,12 @@ extern "C" int stk_mg_create_from_csr(int32_t n_levels, const stk_csr_host *A_fi
     }
     stk_mg_adopt(mg, B.dev.data(), (int)B.dev.size());
     *out = mg;
+    lap("coarse inverses, stk_mg_create");
+    if (timing) {
+        double total = 0.0;
+        for (auto &kv : spent) total += kv.second;
+        fprintf(stderr, "stk_mg_create_from_csr: %.3f s\n", total);
+        for (auto &kv : spent) fprintf(stderr, "   %-36s %.3f s\n", kv.first.c_str(), kv.second);
+    }
     return 0;
 }
