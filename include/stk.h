@@ -641,7 +641,15 @@ int stk_mg_smooth(stk_mg *mg, void *stream, int32_t level, int32_t n_loc,
  * coarsest matrices: kind 0 = A_0, kind 1 + k = ca*A_0 + cms[k]*M_0.
  * coords (optional, HOST): coordinates of the finest-level dofs, row-major
  * (n x dim), level l = the first n_l of them -- only used for cache-friendly row
- * orders and bands; NULL = index order / breadth-first bands. */
+ * orders and bands; NULL = index order / breadth-first bands.
+ * The Gauss-Seidel copies follow the tuning key "mg_gs_diag_free" AS IT STANDS WHEN
+ * THE PLAN IS BUILT: 1 (default) = diagonal-free rows, u_i = (f_i - sum_{j != i}
+ * a_ij u_j) / a_ii; 0 = the diagonal among the slots and the reference's update
+ * u_i += (f_i - row_i u) / a_ii (multigrid.py:89-97).  Key 0 together with
+ * stk_mg_set_option(plan, "fuse_restrict", 0) is the arithmetic the mirrored
+ * driver runs by default (r.Pr histories within 1e-10 of the CPU path).
+ * The host work runs on the threads of the library (STK_HOST_THREADS overrides
+ * their number); STK_PLAN_TIMING=1 prints the seconds per stage on stderr. */
 typedef struct {
     int32_t n_rows, n_cols;
     const int32_t *indptr, *indices;

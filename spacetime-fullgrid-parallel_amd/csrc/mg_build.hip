@@ -358,6 +358,18 @@ struct Builder {
 
 static const int ROW_SLOTS[] = {2, 4, 5, 6, 7, 9, 12, 16, 20};
 
+}  // namespace
+
+// Tuning key "mg_gs_diag_free" (read when a plan is built by stk_mg_create_from_csr):
+// 1 (default): the Gauss-Seidel copies hold the off-diagonal entries only and a row is
+// updated as u_i = (f_i - sum_{j != i} a_ij u_j) / a_ii; 0: the diagonal stays among the
+// slots and the update is the reference's u_i += (f_i - row_i u) / a_ii
+// (multigrid.py:89-97) -- with stk_mg_set_option(plan, "fuse_restrict", 0) the
+// arithmetic of HeatEquationMPI(arithmetic='accurate'), DESIGN.md section 5.
+int g_mg_gs_diag_free = 1;
+
+namespace {
+
 // sliced-ELL copy of the rows `order` of a union pattern (source/linop.py
 // EllRowsMatrix): K = smallest slot count that holds the longest listed row,
 // unused slots: column pad_col (pad_col < 0: the row's first listed column, or the
@@ -556,6 +568,11 @@ extern "C" int stk_mg_create_from_csr(int32_t n_levels, const stk_csr_host *A_fi
         L.vals_a = B.up(u.va);
         L.vals_m = M_fine ? B.up(u.vm) : nullptr;
         L.diag = B.up(diag);
+        std::vector<double> dia_a_of_row(n), dia_m_of_row(M_fine ? n : 0);
+        for (int i = 0; i < n; ++i) {
+            dia_a_of_row[i] = u.va[diag[i]];
+            if (M_fine) dia_m_of_row[i] = u.vm[diag[i]];
+        }
         lap("union pattern, CSR upload");
         if (j == 0) return 0;
         // processing order (mesh tiles if coordinates are known) and bands
@@ -635,7 +652,10 @@ extern "C" int stk_mg_create_from_csr(int32_t n_levels, const stk_csr_host *A_fi
                 for (int i : listed) trow.push_back(band[i]);
             lap("sweep orders");
             stk_ell_rows *dst = bw ? &K.bwd : &K.fwd;
-            ells_ok = ell_rows(B, u, listed, true, 0, nullptr, nullptr, dst) && ells_ok;
+            if (g_mg_gs_diag_free)
+                ells_ok = ell_rows(B, u, listed, true, 0, nullptr, nullptr, dst) && ells_ok;
+            else
+                ells_ok = ell_rows(B, u, listed, false, 0, &dia_a_of_row, M_fine ? &dia_m_of_row : nullptr, dst) && ells_ok;
             lap("ELL copies of the sweeps");
             if (bw) {
                 K.bwd_ptr = ptr;
@@ -690,11 +710,7 @@ extern "C" int stk_mg_create_from_csr(int32_t n_levels, const stk_csr_host *A_fi
                         }
                     f.ptr[i + 1] = (int32_t)f.idx.size();
                 }
-                std::vector<double> da(n), dm(M_fine ? n : 0);
-                for (int i = 0; i < n; ++i) {
-                    da[i] = u.va[diag[i]];
-                    if (M_fine) dm[i] = u.vm[diag[i]];
-                }
+                const std::vector<double> &da = dia_a_of_row, &dm = dia_m_of_row;
                 // unused slots repeat the row's first kept column (a row of an earlier
                 // group, written before this row in every order of the sweeps)
                 const int safe = -1;

@@ -2048,6 +2048,33 @@ def test_multigrid_plan_from_csr_through_ctypes_only(stk):
                 # accumulation order in both; the coarsest level's dense inverse comes
                 # from LAPACK in one and from Gauss-Jordan in the other)
                 stk.check(lib.stk_mg_destroy(plan))
+                # --- the same plan with the default arithmetic of HeatEquationMPI
+                # ('accurate'): Gauss-Seidel rows with their diagonal (plan-time key
+                # "mg_gs_diag_free" = 0) and the restricted residual as R (A u - f)
+                from source import multigrid as mgmod
+                stk.check(lib.stk_set_tuning(b'mg_gs_diag_free', 0))
+                try:
+                    plan = ctypes.c_void_p()
+                    stk.check(lib.stk_mg_create_from_csr(
+                        len(P_mats) + 1, ctypes.byref(a_h), None, P_arr,
+                        coords.ctypes.data if with_coords else None, coords.shape[1],
+                        3, 2, 1.0, 0, None, ld, ctypes.byref(plan)))
+                finally:
+                    stk.check(lib.stk_set_tuning(b'mg_gs_diag_free', 1))
+                stk.check(lib.stk_mg_set_option(plan, b'fuse_restrict', 0))
+                u2 = torch.empty_like(f)
+                stk.check(lib.stk_mg_apply(plan, stk.stream(), n_loc, ld, 1.0, None,
+                                           None, stk.ptr(f), stk.ptr(u2)))
+                got2 = u2[:, :n_loc].cpu().numpy()
+                assert relerr(got2, want) < 1e-12, (problem, with_coords)
+                assert not np.array_equal(got2, got)  # another arithmetic did run
+                mgmod.GS_DIAG_FREE = False
+                try:
+                    py2 = MultiGrid(A_x, hier, smoothsteps=3, vcycles=2, fuse_restrict=False) @ F
+                finally:
+                    mgmod.GS_DIAG_FREE = True
+                assert relerr(got2, py2) < 1e-13, (problem, with_coords)
+                stk.check(lib.stk_mg_destroy(plan))
                 # --- a family: C_j = (2^j M + 0.3 A)^-1, per-slice coefficients
                 cms = np.array([1.0, 2.0, 4.0])
                 plan = ctypes.c_void_p()
