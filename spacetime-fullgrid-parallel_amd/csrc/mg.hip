@@ -132,6 +132,8 @@ struct stk_mg {
     // -1: follow the process-wide tuning key "mg_fuse_restrict"; 0 / 1: this plan's
     // own choice (stk_mg_set_option; 0 is part of the reference-arithmetic mode)
     int fuse_restrict = -1;
+    // levels on which the fused form may be used (the others take the two steps)
+    int fuse_min_level = 0, fuse_max_level = 1 << 30;
     int strip_pct = 100;  // this plan's strips as a percentage of the tuning key "mg_strip_mb"
     // recorded V-cycle applications (see g_mg_graph)
     struct Recorded {
@@ -335,7 +337,8 @@ static int mgm(stk_mg *mg, hipStream_t st, int j, int n_loc, int ld, double ca, 
     double *r_j = mg->r[j], *d_c = mg->f[j - 1], *u_c = mg->u[j - 1];
     const EllLevel &E = mg->ell[j];
     const bool even = ell_slab_ok(L.n, ld);
-    const bool fuse_restrict = mg->fuse_restrict >= 0 ? mg->fuse_restrict != 0 : g_mg_fuse_restrict != 0;
+    const bool fuse_restrict = (mg->fuse_restrict >= 0 ? mg->fuse_restrict != 0 : g_mg_fuse_restrict != 0) &&
+                               j >= mg->fuse_min_level && j <= mg->fuse_max_level;
     if (fuse_restrict && E.has_ra && E.has_r && even) {
         // d_c = R (A_j u_j - f_j) = (R A_j) u_j - R f_j: the fine residual is never written
         rc = stk_rows_ell_launch(st, 0, &E.r, 0, E.r.n_pos, n_loc, ld, L.n, C.n, 1.0, nullptr, f_j, 1.0, 0.0, nullptr,
@@ -516,12 +519,20 @@ extern "C" int stk_mg_set_option(stk_mg *mg, const char *key, int32_t value)
         mg->fuse_restrict = value < 0 ? -1 : (value != 0);
         return 0;
     }
+    if (std::strcmp(key, "fuse_restrict_min_level") == 0) {
+        mg->fuse_min_level = value;
+        return 0;
+    }
+    if (std::strcmp(key, "fuse_restrict_max_level") == 0) {
+        mg->fuse_max_level = value;
+        return 0;
+    }
     if (std::strcmp(key, "strip_pct") == 0) {
         STK_REQUIRE(value >= 1 && value <= 10000, "stk_mg_set_option: strip_pct=%d not in 1..10000", value);
         mg->strip_pct = value;
         return 0;
     }
-    stk_set_error("stk_mg_set_option: unknown key '%s' (fuse_restrict, strip_pct)", key);
+    stk_set_error("stk_mg_set_option: unknown key '%s' (fuse_restrict, fuse_restrict_min_level, fuse_restrict_max_level, strip_pct)", key);
     return 2;
 }
 

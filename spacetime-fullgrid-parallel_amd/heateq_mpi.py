@@ -174,15 +174,16 @@ class HeatEquationMPI:
     arithmetic='accurate' (default) keeps the fast structure (two multigrid applies
     per S on two streams, one batched V-cycle for P) with the reference's
     arithmetic in the two places that own the gap to the CPU path's r.Pr history
-    (DESIGN.md section 5): Gauss-Seidel rows with their diagonal and the update
-    u_i += (f_i - row_i u) / a_ii (multigrid.py:89-97), and the restricted residual
-    as R (A u - f) (multigrid.py:174-175).  Every entry of the history within 1e-10
-    of the CPU path -- the bound BASELINE.json's north star states -- (measured
-    <= 5e-11 at configs 1-4).
+    (DESIGN.md section 5), on the level that owns it -- the finest: Gauss-Seidel
+    rows with their diagonal and the update u_i += (f_i - row_i u) / a_ii
+    (multigrid.py:89-97), and the restricted residual as R (A u - f)
+    (multigrid.py:174-175).  Every entry of the history within 1e-10 of the CPU
+    path -- the bound BASELINE.json's north star states -- (measured <= 5.3e-11
+    at configs 1-4).
 
     arithmetic='fast': diagonal-free Gauss-Seidel rows u_i = (f_i - sum_{j != i}) / a_ii
-    and the restricted residual as (R A) u - R f from the precomputed product: 13 %
-    less solve time, iteration counts unchanged, history entries within 4.6e-10.
+    and the restricted residual as (R A) u - R f from the precomputed product on every
+    level: 11 % less solve time, iteration counts unchanged, history entries within 4.6e-10.
 
     arithmetic='reference' = schur='reference' + family='reference' + Gauss-Seidel
     rows with their diagonal (u_i += (f_i - row_i u) / a_ii, multigrid.py:89-97) +
@@ -262,9 +263,13 @@ class HeatEquationMPI:
         self.hierarchy = hierarchy
         from source import multigrid as _mg
         gs_form = _mg.GS_DIAG_FREE
-        if arithmetic in ('reference', 'accurate'):
+        if arithmetic == 'reference':
             _mg.GS_DIAG_FREE = False
-        unfused = False if arithmetic == 'accurate' else None  # restricted residual as R (A u - f)
+        elif arithmetic == 'accurate':
+            # the reference's forms where they matter: the FINEST level owns the gap of
+            # the fast mode (profiles/r03_history_by_level.log); below it the fast forms
+            # leave every r.Pr within 1e-10 of the CPU path
+            _mg.GS_DIAG_FREE_LEVELS = lambda level, finest: level < finest
         if precond == 'multigrid' and family == 'reference':
             # one hierarchy per wavelet level from the assembled matrix
             # (reference heateq_mpi.py:147-153)
@@ -289,13 +294,17 @@ class HeatEquationMPI:
                     pool.submit(on_dev(lambda: EllMatrices.shared(
                         [self.M_x, self.A_x]).packed_for(n_steps)))
                 kinv = pool.submit(on_dev(MultiGrid), self.A_x, hierarchy,
-                                   smoothsteps=smoothsteps, vcycles=vcycles,
-                                   fuse_restrict=unfused)
+                                   smoothsteps=smoothsteps, vcycles=vcycles)
                 family = pool.submit(
                     on_dev(MultiGridFamily), self.A_x, self.M_x, hierarchy, ca=alpha,
                     cms=[2**j for j in range(self.J_time + 1)],
-                    smoothsteps=smoothsteps, vcycles=vcycles, fuse_restrict=unfused)
+                    smoothsteps=smoothsteps, vcycles=vcycles)
                 self.Kinv_x, self.C_family = kinv.result(), family.result()
+            if arithmetic == 'accurate':
+                # restricted residual as R (A u - f) (multigrid.py:174-175) on the finest
+                # level, (R A) u - R f below it
+                for plans in (self.Kinv_x._dev, self.C_family._dev):
+                    plans.set_option('fuse_restrict_max_level', hierarchy.J - 1)
             # strips of the strip-wise smoothing (csrc/mg.hip), measured at config 3
             # (profiles/r03_strip_sizes_two_streams.log): K's applies run two at a time
             # inside S and share the caches, the family's applies run alone
@@ -310,6 +319,7 @@ class HeatEquationMPI:
                 for j in range(self.J_time + 1)
             ]
         _mg.GS_DIAG_FREE = gs_form
+        _mg.GS_DIAG_FREE_LEVELS = None
         self.u0_x = u0_x.result()
         early.shutdown()
         mark('multigrid plans, Kronecker plan, load vector')
@@ -370,7 +380,7 @@ def main(argv=None):
                                ('arithmetic', str, 'accurate',
                                 'accurate: Gauss-Seidel and restricted residual in the '
                                 'reference\'s arithmetic (r.Pr history within 1e-10 of the CPU '
-                                'path); fast: both regrouped (13 %% less solve time, history '
+                                'path); fast: both regrouped on every level (11 %% less solve time, history '
                                 'within 4.6e-10); reference: every regrouping of the build off '
                                 '(2.3x slower than fast)')])
     comm, rank, size = driver.start(args)

@@ -208,6 +208,9 @@ def coupling_bands(coords, indptr, indices):
 # update u_i += (f_i - row_i u) / a_ii (reference multigrid.py:89-97) -- part of
 # the "reference arithmetic" mode (heateq_mpi.HeatEquationMPI(arithmetic='reference')).
 GS_DIAG_FREE = True
+# Levels whose Gauss-Seidel copies follow GS_DIAG_FREE when it is set; the others
+# get the full rows.  None = every level; a callable (level, finest) -> bool.
+GS_DIAG_FREE_LEVELS = None
 
 
 class _DeviceHierarchy:
@@ -301,7 +304,8 @@ class _DeviceHierarchy:
                 groups = [r_[np.argsort(key[r_], kind='stable')] for r_ in groups]
                 listed = (np.concatenate(groups) if n else
                           np.zeros(0, dtype=np.int64))
-                if GS_DIAG_FREE:
+                if GS_DIAG_FREE and (GS_DIAG_FREE_LEVELS is None
+                                     or GS_DIAG_FREE_LEVELS(j, self.J)):
                     ells[name] = EllRowsMatrix(indptr, indices, vals[0], vm,
                                                listed, diag=True)
                 else:
