@@ -44,7 +44,7 @@ __global__ __launch_bounds__(GBS) void gs_group_kernel(int64_t total, const int3
                                                        const double *__restrict__ vm,
                                                        const double *__restrict__ cm,
                                                        const int32_t *__restrict__ diag,
-                                                       const double *__restrict__ f, double *u)
+                                                       const double *__restrict__ f, double *u, int diag_free)
 {
     const int64_t stride = (int64_t)gridDim.x * GBS;
     for (int64_t idx = (int64_t)blockIdx.x * GBS + threadIdx.x; idx < total; idx += stride) {
@@ -56,10 +56,11 @@ __global__ __launch_bounds__(GBS) void gs_group_kernel(int64_t total, const int3
         const double c = (vm != nullptr) ? cm[t] : 0.0;
         double ax = 0.0;
         const int ed = diag[i];
-        // batches of independent gathers (clamped past the row end), the
-        // off-diagonal entries summed in CSR order like the sequential sweep:
-        // u_i = (f_i - sum_{j != i} a_ij u_j) / a_ii, as the diagonal-free ELL
-        // copies of the row engine (stk_ell_rows.diag_free)
+        // batches of independent gathers (clamped past the row end), the entries
+        // summed in CSR order like the sequential sweep, in the form of the plan's
+        // ELL copies (stk_ell_rows.diag_free): u_i = (f_i - sum_{j != i} a_ij u_j) / a_ii,
+        // or with the diagonal in the sum and u_i += (f_i - row_i u) / a_ii
+        // (reference multigrid.py:89-97)
         for (int eb = e0; eb < e1; eb += 8) {
             double uv[8], av[8];
 #pragma unroll
@@ -70,11 +71,11 @@ __global__ __launch_bounds__(GBS) void gs_group_kernel(int64_t total, const int3
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q)
-                if (eb + q < e1 && eb + q != ed) ax = fma(av[q], uv[q], ax);
+                if (eb + q < e1 && (!diag_free || eb + q != ed)) ax = fma(av[q], uv[q], ax);
         }
         const double d = (vm != nullptr) ? fma(c, vm[ed], ca * va[ed]) : ca * va[ed];
         const size_t o = (size_t)i * ld + t;
-        u[o] = (1.0 / d) * (f[o] - ax);
+        u[o] = (diag_free ? 0.0 : u[o]) + (1.0 / d) * (f[o] - ax);
     }
 }
 
@@ -292,7 +293,7 @@ static int smooth_level(stk_mg *mg, hipStream_t st, int level, int n_loc, int ld
             const int64_t total = (int64_t)nr * n_loc;
             hipLaunchKernelGGL(gs_group_kernel, dim3(stk_flat_grid(total, GBS)), dim3(GBS), 0, st, total,
                                rows + ptr[g], n_loc, ld, L.indptr, L.indices, L.vals_a, ca,
-                               cm ? L.vals_m : nullptr, cm, L.diag, f, u);
+                               cm ? L.vals_m : nullptr, cm, L.diag, f, u, E.has_gs ? E.fwd.diag_free : 1);
             STK_LAUNCH_CHECK();
         }
     }

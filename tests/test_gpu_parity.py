@@ -1005,6 +1005,58 @@ def test_restricted_residual_variants_agree(stk):
         assert relerr(res[1][0], res[0][0]) < 1e-13
         assert relerr(res[1][1], res[0][1]) < 1e-13
         assert not np.array_equal(res[1][0], res[0][0])  # the fused path did run
+        # the per-level window of the fused form (what the default arithmetic uses to
+        # keep the two-step form on the finest level only): an empty window is the
+        # two-step form, the full one the fused form, bit for bit
+        J = h.hierarchy.J
+        plans = (h.Kinv_x._dev, h.C_family._dev)
+        try:
+            for lo, hi, same_as in ((0, -1, 0), (0, 1 << 30, 1), (0, J - 1, None)):
+                for dev in plans:
+                    dev.set_option('fuse_restrict_min_level', lo)
+                    dev.set_option('fuse_restrict_max_level', hi)
+                got = _np(h.P @ x)
+                if same_as is not None:
+                    assert np.array_equal(got, res[same_as][0]), (lo, hi)
+                else:  # fused below the finest level only (at this size those levels run
+                    # inside the fused coarse launch, which always takes the two steps)
+                    assert relerr(got, res[0][0]) < 1e-13
+                    assert not np.array_equal(got, res[1][0])
+        finally:
+            for dev in plans:
+                dev.set_option('fuse_restrict_min_level', 0)
+                dev.set_option('fuse_restrict_max_level', 1 << 30)
+    # Gauss-Seidel row forms by level (multigrid.GS_DIAG_FREE_LEVELS): "no level
+    # diagonal-free" is the plan GS_DIAG_FREE = False builds
+    from source import multigrid as mgmod
+    from source.assembly import space_matrices
+    from source.multigrid import MeshHierarchy, MultiGrid
+    from source.problem import problem_helper
+    mesh = problem_helper('square', J_space=4, J_time=2)[0]
+    A_x = space_matrices(mesh)[1]
+    hier = MeshHierarchy(mesh)
+    F = np.random.RandomState(3).rand(A_x.shape[0], 6)
+    out = {}
+    try:
+        for name, flag, levels in (('free', True, None), ('full', False, None),
+                                   ('none free', True, lambda j, Jf: False),
+                                   ('free below the finest', True, lambda j, Jf: j < Jf)):
+            mgmod.GS_DIAG_FREE, mgmod.GS_DIAG_FREE_LEVELS = flag, levels
+            mg = MultiGrid(A_x, hier, smoothsteps=3, vcycles=2)
+            out[name] = mg @ F
+            # an odd number of columns takes the CSR kernels (mg.hip gs_group_kernel,
+            # two-step restricted residual, no fused coarse launch): the same row form
+            out[name + ', csr'] = mg @ F[:, :5]
+            assert relerr(out[name + ', csr'], out[name][:, :5]) < 1e-13, name
+    finally:
+        mgmod.GS_DIAG_FREE, mgmod.GS_DIAG_FREE_LEVELS = True, None
+    assert np.array_equal(out['none free'], out['full'])
+    assert not np.array_equal(out['free'], out['full'])
+    assert not np.array_equal(out['free below the finest'], out['full'])
+    assert not np.array_equal(out['free below the finest'], out['free'])
+    assert relerr(out['free below the finest'], out['full']) < 1e-13
+    assert np.array_equal(out['none free, csr'], out['full, csr'])
+    assert not np.array_equal(out['free, csr'], out['full, csr'])
 
 
 def _lib_dev(a):
