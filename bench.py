@@ -370,7 +370,7 @@ def main():
 
     # ---- secondary figure: PCG iterations per second --------------------------
     # in the library's default arithmetic ('accurate': every r.Pr within 1e-10 of the
-    # CPU path) and in the 'fast' one (11 % less time, entries within 4.6e-10)
+    # CPU path) and in the 'fast' one (4 % less time, entries within 4.6e-10)
     def timed_solve(arithmetic):
         import heateq_mpi as hm
         from source.linalg import PCG

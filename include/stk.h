@@ -596,6 +596,10 @@ typedef struct {
      * passes. */
     int32_t n_tile_rows;
     const int32_t *fwd_tile_row_host, *bwd_tile_row_host;
+    /* Optional (NULL if absent): ell_fwd / ell_bwd once more in the OTHER row form
+     * (stk_ell_rows.diag_free), same rows in the same order: what the sweeps the
+     * plan options "fast_until_cycle" / "fast_parts" name run on. */
+    const stk_ell_rows *ell_fwd_alt, *ell_bwd_alt;
 } stk_mg_level;
 
 typedef struct stk_mg stk_mg;
@@ -616,7 +620,17 @@ int stk_mg_destroy(stk_mg *mg);
  * strip-wise smoothing of THIS plan as a percentage of the tuning key
  * "mg_strip_mb" (results do not depend on it): plans whose applies run two at a
  * time share the caches and want smaller strips, a plan that runs alone larger
- * ones. */
+ * ones.
+ * Where the reference's forms are used (the history's gap to the CPU path is owned
+ * by the LAST V-cycle's restricted residual and post-smoothing on the FINEST level:
+ * DESIGN.md section 5): "fuse_restrict_min_level" / "_max_level" (default 0 / no
+ * bound): the fused form only on levels inside the window, the two steps outside;
+ * "fast_until_cycle" (default 0): the V-cycles with a smaller index take the fast
+ * forms throughout -- the alternative sweep copies of levels that have them
+ * (stk_mg_level.ell_fwd_alt / ell_bwd_alt), the fused restricted residual on every
+ * level; "fast_parts": in the later V-cycles bit 0 lets the pre-smoothing and bit 1
+ * the restricted residual take the fast forms as well (the post-smoothing never
+ * does). */
 int stk_mg_set_option(stk_mg *plan, const char *key, int32_t value);
 /* u = MG(f): `vcycles` V-cycles from u = 0.  cm/kind: per-time-slice mass
  * coefficient and coarse-inverse index (device, n_loc) or NULL. */

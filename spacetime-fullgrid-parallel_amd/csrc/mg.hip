@@ -106,8 +106,9 @@ int g_mg_fuse_coarse = 1;       // 0 disables the fused coarse sub-V-cycle
 int g_mg_coarse_max_rows = 4096;  // levels up to this many rows may be fused (larger ones fill the GPU by themselves)
 
 struct EllLevel {
-    bool has_a = false, has_gs = false, has_p = false, has_r = false, has_ra = false;
+    bool has_a = false, has_gs = false, has_p = false, has_r = false, has_ra = false, has_alt = false;
     stk_ell_rows a, fwd, bwd, p, r, ra;
+    stk_ell_rows fwd_alt, bwd_alt;  // the sweeps' copies in the other row form (early V-cycles)
     std::vector<stk_ell_rows> fwd0;  // per forward group: entries towards earlier groups only
     std::vector<int32_t> fwd_pos, bwd_pos;
     // strip-wise sweeps: tile row of every position, and per strip count S the
@@ -135,6 +136,13 @@ struct stk_mg {
     int fuse_restrict = -1;
     // levels on which the fused form may be used (the others take the two steps)
     int fuse_min_level = 0, fuse_max_level = 1 << 30;
+    // V-cycles with index < fast_until_cycle run the fast forms: the alternative
+    // copies of the sweeps where a level has them, the fused restricted residual
+    // on every level
+    int fast_until_cycle = 0;
+    // ... and in the later V-cycles: bit 0 = the pre-smoothing, bit 1 = the restricted
+    // residual also take the fast forms (the post-smoothing never does)
+    int fast_parts = 0;
     int strip_pct = 100;  // this plan's strips as a percentage of the tuning key "mg_strip_mb"
     // recorded V-cycle applications (see g_mg_graph)
     struct Recorded {
@@ -248,12 +256,13 @@ int g_mg_graph_replays = 0;  // graph launches so far (tests read it through stk
 extern int g_stk_tuning_epoch;  // kron.hip: bumped by every stk_set_tuning
 
 static int smooth_level(stk_mg *mg, hipStream_t st, int level, int n_loc, int ld, double ca, const double *cm,
-                        int its, bool backward, const double *f, double *u, bool zero_start = false)
+                        int its, bool backward, const double *f, double *u, bool zero_start = false, int cycle = 1 << 30)
 {
     const stk_mg_level &L = mg->lv[level];
     const EllLevel &E = mg->ell[level];
     if (E.has_gs && ell_slab_ok(L.n, ld)) {
-        const stk_ell_rows &e = backward ? E.bwd : E.fwd;
+        const bool alt = E.has_alt && cycle < mg->fast_until_cycle;
+        const stk_ell_rows &e = alt ? (backward ? E.bwd_alt : E.fwd_alt) : (backward ? E.bwd : E.fwd);
         const std::vector<int32_t> &pos = backward ? E.bwd_pos : E.fwd_pos;
         const int ng = (int)pos.size() - 1;
         const bool zs = zero_start && !backward && its >= 1;
@@ -303,7 +312,7 @@ static int smooth_level(stk_mg *mg, hipStream_t st, int level, int n_loc, int ld
 // multigrid.py:168-182
 // u_zero: u_j is zero by definition but its memory has NOT been written.
 static int mgm(stk_mg *mg, hipStream_t st, int j, int n_loc, int ld, double ca, const double *cm,
-               const int32_t *kind, const double *f_j, double *u_j, bool u_zero)
+               const int32_t *kind, const double *f_j, double *u_j, bool u_zero, int cycle)
 {
     const stk_mg_level &L = mg->lv[j];
     if (g_mg_fuse_coarse && mg->coarse && j == mg->Lc && (ld & 1) == 0 && f_j == mg->f[j] && u_j == mg->u[j]) {
@@ -332,14 +341,16 @@ static int mgm(stk_mg *mg, hipStream_t st, int j, int n_loc, int ld, double ca, 
         STK_LAUNCH_CHECK();
         return 0;
     }
-    int rc = smooth_level(mg, st, j, n_loc, ld, ca, cm, mg->smoothsteps, false, f_j, u_j, zero_start);
+    int rc = smooth_level(mg, st, j, n_loc, ld, ca, cm, mg->smoothsteps, false, f_j, u_j, zero_start,
+                          (mg->fast_parts & 1) ? -1 : cycle);
     if (rc) return rc;
     const stk_mg_level &C = mg->lv[j - 1];
     double *r_j = mg->r[j], *d_c = mg->f[j - 1], *u_c = mg->u[j - 1];
     const EllLevel &E = mg->ell[j];
     const bool even = ell_slab_ok(L.n, ld);
     const bool fuse_restrict = (mg->fuse_restrict >= 0 ? mg->fuse_restrict != 0 : g_mg_fuse_restrict != 0) &&
-                               j >= mg->fuse_min_level && j <= mg->fuse_max_level;
+                               ((j >= mg->fuse_min_level && j <= mg->fuse_max_level) || cycle < mg->fast_until_cycle ||
+                                (mg->fast_parts & 2));
     if (fuse_restrict && E.has_ra && E.has_r && even) {
         // d_c = R (A_j u_j - f_j) = (R A_j) u_j - R f_j: the fine residual is never written
         rc = stk_rows_ell_launch(st, 0, &E.r, 0, E.r.n_pos, n_loc, ld, L.n, C.n, 1.0, nullptr, f_j, 1.0, 0.0, nullptr,
@@ -365,7 +376,7 @@ static int mgm(stk_mg *mg, hipStream_t st, int j, int n_loc, int ld, double ca, 
                               1.0, 0.0, nullptr, d_c);
         if (rc) return rc;
     }
-    rc = mgm(mg, st, j - 1, n_loc, ld, ca, cm, kind, d_c, u_c, /*u_zero=*/true);
+    rc = mgm(mg, st, j - 1, n_loc, ld, ca, cm, kind, d_c, u_c, /*u_zero=*/true, cycle);
     if (rc) return rc;
     // u_j -= P u_c
     if (E.has_p && even)
@@ -375,7 +386,7 @@ static int mgm(stk_mg *mg, hipStream_t st, int j, int n_loc, int ld, double ca, 
         rc = stk_csr_spmm(st, L.n, n_loc, ld, L.p_indptr, L.p_indices, L.p_vals, 1.0, nullptr, nullptr, u_c, -1.0,
                           1.0, u_j, u_j);
     if (rc) return rc;
-    return smooth_level(mg, st, j, n_loc, ld, ca, cm, mg->smoothsteps, true, f_j, u_j);
+    return smooth_level(mg, st, j, n_loc, ld, ca, cm, mg->smoothsteps, true, f_j, u_j, false, cycle);
 }
 
 extern "C" int stk_mg_create(int32_t n_levels, const stk_mg_level *levels, int32_t smoothsteps, int32_t vcycles,
@@ -409,6 +420,12 @@ extern "C" int stk_mg_create(int32_t n_levels, const stk_mg_level *levels, int32
             E.bwd_pos.assign(L.bwd_pos_host, L.bwd_pos_host + L.n_bwd + 1);
             E.has_gs = true;
         }
+        if (E.has_gs && L.ell_fwd_alt && L.ell_bwd_alt && L.ell_fwd_alt->n_pos == E.fwd.n_pos &&
+            L.ell_bwd_alt->n_pos == E.bwd.n_pos) {
+            E.fwd_alt = *L.ell_fwd_alt;
+            E.bwd_alt = *L.ell_bwd_alt;
+            E.has_alt = true;
+        }
         if (E.has_gs && L.n_tile_rows > 1 && L.fwd_tile_row_host && L.bwd_tile_row_host) {
             E.fwd_trow.assign(L.fwd_tile_row_host, L.fwd_tile_row_host + E.fwd.n_pos);
             E.bwd_trow.assign(L.bwd_tile_row_host, L.bwd_tile_row_host + E.bwd.n_pos);
@@ -416,6 +433,7 @@ extern "C" int stk_mg_create(int32_t n_levels, const stk_mg_level *levels, int32
         }
         mg->lv[j].ell_a = mg->lv[j].ell_fwd = mg->lv[j].ell_bwd = mg->lv[j].ell_p = mg->lv[j].ell_r = nullptr;
         mg->lv[j].ell_ra = mg->lv[j].ell_fwd0 = nullptr;
+        mg->lv[j].ell_fwd_alt = mg->lv[j].ell_bwd_alt = nullptr;
     }
     mg->u.assign(n_levels, nullptr);
     mg->f.assign(n_levels, nullptr);
@@ -516,6 +534,10 @@ extern "C" int stk_mg_destroy(stk_mg *mg)
 extern "C" int stk_mg_set_option(stk_mg *mg, const char *key, int32_t value)
 {
     STK_REQUIRE(mg && key, "stk_mg_set_option: null pointer");
+    // recorded V-cycles (tuning key mg_graph) were captured under the old options
+    for (auto &r : mg->recorded)
+        if (r.exec) (void)hipGraphExecDestroy(r.exec);
+    mg->recorded.clear();
     if (std::strcmp(key, "fuse_restrict") == 0) {
         mg->fuse_restrict = value < 0 ? -1 : (value != 0);
         return 0;
@@ -528,12 +550,20 @@ extern "C" int stk_mg_set_option(stk_mg *mg, const char *key, int32_t value)
         mg->fuse_max_level = value;
         return 0;
     }
+    if (std::strcmp(key, "fast_until_cycle") == 0) {
+        mg->fast_until_cycle = value;
+        return 0;
+    }
+    if (std::strcmp(key, "fast_parts") == 0) {
+        mg->fast_parts = value;
+        return 0;
+    }
     if (std::strcmp(key, "strip_pct") == 0) {
         STK_REQUIRE(value >= 1 && value <= 10000, "stk_mg_set_option: strip_pct=%d not in 1..10000", value);
         mg->strip_pct = value;
         return 0;
     }
-    stk_set_error("stk_mg_set_option: unknown key '%s' (fuse_restrict, fuse_restrict_min_level, fuse_restrict_max_level, strip_pct)", key);
+    stk_set_error("stk_mg_set_option: unknown key '%s' (fuse_restrict, fuse_restrict_min_level, fuse_restrict_max_level, fast_until_cycle, fast_parts, strip_pct)", key);
     return 2;
 }
 
@@ -542,7 +572,7 @@ static int run_vcycles(stk_mg *mg, hipStream_t st, int32_t n_loc, int32_t ld, do
 {
     const int J = (int)mg->lv.size() - 1;
     for (int v = 0; v < mg->vcycles; ++v) {
-        int rc = mgm(mg, st, J, n_loc, ld, ca, cm, kind, f, u, /*u_zero=*/v == 0);  // multigrid.py:187
+        int rc = mgm(mg, st, J, n_loc, ld, ca, cm, kind, f, u, /*u_zero=*/v == 0, v);  // multigrid.py:187
         if (rc) return rc;
     }
     return 0;

@@ -174,16 +174,17 @@ class HeatEquationMPI:
     arithmetic='accurate' (default) keeps the fast structure (two multigrid applies
     per S on two streams, one batched V-cycle for P) with the reference's
     arithmetic in the two places that own the gap to the CPU path's r.Pr history
-    (DESIGN.md section 5), on the level that owns it -- the finest: Gauss-Seidel
-    rows with their diagonal and the update u_i += (f_i - row_i u) / a_ii
-    (multigrid.py:89-97), and the restricted residual as R (A u - f)
-    (multigrid.py:174-175).  Every entry of the history within 1e-10 of the CPU
-    path -- the bound BASELINE.json's north star states -- (measured <= 5.3e-11
-    at configs 1-4).
+    (DESIGN.md section 5), where they own it -- the last V-cycle of a multigrid
+    application on the finest level: the restricted residual as R (A u - f)
+    (multigrid.py:174-175) and the post-smoothing on Gauss-Seidel rows with their
+    diagonal, u_i += (f_i - row_i u) / a_ii (multigrid.py:89-97).  Every entry of
+    the history within 1e-10 of the CPU path -- the bound BASELINE.json's north
+    star states -- (measured <= 4.3e-11 at configs 1-4) for 4 % more solve time
+    than the fast mode.
 
     arithmetic='fast': diagonal-free Gauss-Seidel rows u_i = (f_i - sum_{j != i}) / a_ii
     and the restricted residual as (R A) u - R f from the precomputed product on every
-    level: 11 % less solve time, iteration counts unchanged, history entries within 4.6e-10.
+    level and in every V-cycle: 4 % less solve time, iteration counts unchanged, history entries within 4.6e-10.
 
     arithmetic='reference' = schur='reference' + family='reference' + Gauss-Seidel
     rows with their diagonal (u_i += (f_i - row_i u) / a_ii, multigrid.py:89-97) +
@@ -266,10 +267,13 @@ class HeatEquationMPI:
         if arithmetic == 'reference':
             _mg.GS_DIAG_FREE = False
         elif arithmetic == 'accurate':
-            # the reference's forms where they matter: the FINEST level owns the gap of
-            # the fast mode (profiles/r03_history_by_level.log); below it the fast forms
-            # leave every r.Pr within 1e-10 of the CPU path
+            # the reference's forms where they matter: the gap of the fast mode is owned
+            # by the FINEST level (profiles/r03_history_by_level.log) and there by the
+            # LAST V-cycle's restricted residual and post-smoothing
+            # (profiles/r03_history_by_cycle.log) -- what comes earlier is damped by
+            # what follows it.  The finest level gets both row forms.
             _mg.GS_DIAG_FREE_LEVELS = lambda level, finest: level < finest
+            _mg.GS_ALT_COPIES = True
         if precond == 'multigrid' and family == 'reference':
             # one hierarchy per wavelet level from the assembled matrix
             # (reference heateq_mpi.py:147-153)
@@ -305,6 +309,8 @@ class HeatEquationMPI:
                 # level, (R A) u - R f below it
                 for plans in (self.Kinv_x._dev, self.C_family._dev):
                     plans.set_option('fuse_restrict_max_level', hierarchy.J - 1)
+                    plans.set_option('fast_until_cycle', vcycles - 1)  # all but the last V-cycle
+                    plans.set_option('fast_parts', 1)  # and the last one's pre-smoothing
             # strips of the strip-wise smoothing (csrc/mg.hip), measured at config 3
             # (profiles/r03_strip_sizes_two_streams.log): K's applies run two at a time
             # inside S and share the caches, the family's applies run alone
@@ -320,6 +326,7 @@ class HeatEquationMPI:
             ]
         _mg.GS_DIAG_FREE = gs_form
         _mg.GS_DIAG_FREE_LEVELS = None
+        _mg.GS_ALT_COPIES = False
         self.u0_x = u0_x.result()
         early.shutdown()
         mark('multigrid plans, Kronecker plan, load vector')
@@ -380,7 +387,7 @@ def main(argv=None):
                                ('arithmetic', str, 'accurate',
                                 'accurate: Gauss-Seidel and restricted residual in the '
                                 'reference\'s arithmetic (r.Pr history within 1e-10 of the CPU '
-                                'path); fast: both regrouped on every level (11 %% less solve time, history '
+                                'path); fast: both regrouped everywhere (4 %% less solve time, history '
                                 'within 4.6e-10); reference: every regrouping of the build off '
                                 '(2.3x slower than fast)')])
     comm, rank, size = driver.start(args)

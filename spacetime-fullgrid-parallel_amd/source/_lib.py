@@ -82,7 +82,9 @@ class MGLevel(ctypes.Structure):
                 ('ell_ra', ctypes.POINTER(EllRows)),
                 ('ell_fwd0', ctypes.POINTER(EllRows)),
                 ('n_tile_rows', c_i32), ('fwd_tile_row_host', c_p),
-                ('bwd_tile_row_host', c_p)]
+                ('bwd_tile_row_host', c_p),
+                ('ell_fwd_alt', ctypes.POINTER(EllRows)),
+                ('ell_bwd_alt', ctypes.POINTER(EllRows))]
 
 
 _PROTOTYPES = {

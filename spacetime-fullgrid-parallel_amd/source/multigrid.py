@@ -211,6 +211,10 @@ GS_DIAG_FREE = True
 # Levels whose Gauss-Seidel copies follow GS_DIAG_FREE when it is set; the others
 # get the full rows.  None = every level; a callable (level, finest) -> bool.
 GS_DIAG_FREE_LEVELS = None
+# True: a level that gets the full rows also gets the diagonal-free copies as its
+# ALTERNATIVE form (stk_mg_level.ell_fwd_alt / ell_bwd_alt): the plan option
+# "fast_until_cycle" then runs the first V-cycles of an application on them.
+GS_ALT_COPIES = False
 
 
 class _DeviceHierarchy:
@@ -311,6 +315,9 @@ class _DeviceHierarchy:
                 else:
                     ells[name] = EllRowsMatrix(indptr, indices, vals[0], vm, listed,
                                                dia_values=True)
+                    if GS_DIAG_FREE and GS_ALT_COPIES:
+                        ells[name + '_alt'] = EllRowsMatrix(indptr, indices, vals[0], vm,
+                                                            listed, diag=True)
                 if band is not None:
                     # band of every ELL position (ascending inside a group):
                     # lets the plan run the sweeps strip by strip (mg.hip)
