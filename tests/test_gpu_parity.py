@@ -1059,6 +1059,50 @@ def test_restricted_residual_variants_agree(stk):
     assert not np.array_equal(out['free, csr'], out['full, csr'])
 
 
+def test_reference_forms_only_where_the_gap_is_owned(stk):
+    """The default arithmetic keeps the reference's forms for the last V-cycle's
+    restricted residual and post-smoothing on the finest level (plan options
+    fast_until_cycle / fast_parts, the alternative sweep copies of
+    stk_mg_level.ell_fwd_alt / ell_bwd_alt).  With every V-cycle declared fast the
+    plan reproduces arithmetic='fast' bit for bit; with none, the plan that has
+    the reference's forms on the whole finest level; the default lies between."""
+    import heateq_mpi as hm
+    from source import multigrid as mgmod
+    for problem, J_space in (('square', 6), ('lshape', 5)):
+        fast = hm.HeatEquationMPI(J_space=J_space, J_time=3, problem=problem, arithmetic='fast')
+        x = _vec(fast.dofs_distr, np.random.RandomState(21).rand(fast.N, fast.M))
+        want_fast = (_np(fast.P @ x), _np(fast.S @ x))
+        del fast
+        # the reference's forms on the whole finest level, no alternative copies
+        mgmod.GS_DIAG_FREE_LEVELS = lambda level, finest: level < finest
+        try:
+            whole = hm.HeatEquationMPI(J_space=J_space, J_time=3, problem=problem, arithmetic='fast')
+        finally:
+            mgmod.GS_DIAG_FREE_LEVELS = None
+        for dev in (whole.Kinv_x._dev, whole.C_family._dev):
+            dev.set_option('fuse_restrict_max_level', whole.hierarchy.J - 1)
+        want_whole = (_np(whole.P @ x), _np(whole.S @ x))
+        del whole
+        h = hm.HeatEquationMPI(J_space=J_space, J_time=3, problem=problem)  # arithmetic='accurate'
+        plans = (h.Kinv_x._dev, h.C_family._dev)
+        default = (_np(h.P @ x), _np(h.S @ x))
+
+        def run(until, parts):
+            for dev in plans:
+                dev.set_option('fast_until_cycle', until)
+                dev.set_option('fast_parts', parts)
+            return _np(h.P @ x), _np(h.S @ x)
+
+        all_fast, none_fast = run(2, 0), run(0, 0)
+        for k in range(2):
+            assert np.array_equal(all_fast[k], want_fast[k]), (problem, k)
+            assert np.array_equal(none_fast[k], want_whole[k]), (problem, k)
+            assert not np.array_equal(default[k], want_fast[k]) and not np.array_equal(default[k], want_whole[k])
+            assert relerr(default[k], want_whole[k]) < 1e-13
+        again = run(1, 1)  # the default's options
+        assert np.array_equal(again[0], default[0]) and np.array_equal(again[1], default[1])
+
+
 def _lib_dev(a):
     from source import _lib
     return _lib.to_dev(np.ascontiguousarray(a))
