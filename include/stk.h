@@ -659,9 +659,13 @@ int stk_mg_smooth(stk_mg *mg, void *stream, int32_t level, int32_t n_loc,
  * The Gauss-Seidel copies follow the tuning key "mg_gs_diag_free" AS IT STANDS WHEN
  * THE PLAN IS BUILT: 1 (default) = diagonal-free rows, u_i = (f_i - sum_{j != i}
  * a_ij u_j) / a_ii; 0 = the diagonal among the slots and the reference's update
- * u_i += (f_i - row_i u) / a_ii (multigrid.py:89-97).  Key 0 together with
- * stk_mg_set_option(plan, "fuse_restrict", 0) is the arithmetic the mirrored
- * driver runs by default (r.Pr histories within 1e-10 of the CPU path).
+ * u_i += (f_i - row_i u) / a_ii (multigrid.py:89-97); 2 = the latter on the finest
+ * level, which also gets the diagonal-free copies as its alternative form, the
+ * former below.  Key 2 together with stk_mg_set_option(plan,
+ * "fuse_restrict_max_level", n_levels - 2), ("fast_until_cycle", vcycles - 1) and
+ * ("fast_parts", 1) is the arithmetic the mirrored driver runs by default (r.Pr
+ * histories within 1e-10 of the CPU path for 4 % of the solve); key 0 with
+ * ("fuse_restrict", 0) has the reference's forms everywhere.
  * The host work runs on the threads of the library (STK_HOST_THREADS overrides
  * their number); STK_PLAN_TIMING=1 prints the seconds per stage on stderr. */
 typedef struct {

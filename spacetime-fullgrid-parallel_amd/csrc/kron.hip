@@ -453,7 +453,7 @@ extern "C" int stk_set_tuning(const char *key, int32_t value)
         return 0;
     }
     if (std::strcmp(key, "mg_gs_diag_free") == 0) {
-        g_mg_gs_diag_free = value != 0;
+        g_mg_gs_diag_free = value;
         return 0;
     }
     if (std::strcmp(key, "mg_fuse_restrict") == 0) {

@@ -364,8 +364,11 @@ static const int ROW_SLOTS[] = {2, 4, 5, 6, 7, 9, 12, 16, 20};
 // 1 (default): the Gauss-Seidel copies hold the off-diagonal entries only and a row is
 // updated as u_i = (f_i - sum_{j != i} a_ij u_j) / a_ii; 0: the diagonal stays among the
 // slots and the update is the reference's u_i += (f_i - row_i u) / a_ii
-// (multigrid.py:89-97) -- with stk_mg_set_option(plan, "fuse_restrict", 0) the
-// arithmetic of HeatEquationMPI(arithmetic='accurate'), DESIGN.md section 5.
+// (multigrid.py:89-97); 2: the latter on the finest level, which also gets the
+// diagonal-free copies as its alternative form (stk_mg_level.ell_fwd_alt / ell_bwd_alt),
+// the former below -- with stk_mg_set_option(plan, "fuse_restrict_max_level", finest - 1),
+// ("fast_until_cycle", vcycles - 1) and ("fast_parts", 1) the arithmetic of
+// HeatEquationMPI(arithmetic='accurate'), DESIGN.md section 5.
 int g_mg_gs_diag_free = 1;
 
 namespace {
@@ -540,7 +543,7 @@ extern "C" int stk_mg_create_from_csr(int32_t n_levels, const stk_csr_host *A_fi
     // host arrays the level structs point into while stk_mg_create copies them
     struct Keep {
         std::vector<int32_t> fwd_ptr, bwd_ptr, fwd_trow, bwd_trow;
-        stk_ell_rows a, fwd, bwd, p, r, ra;
+        stk_ell_rows a, fwd, bwd, p, r, ra, fwd_alt, bwd_alt;
         std::vector<stk_ell_rows> fwd0;
     };
     std::vector<Keep> keep(n_levels);
@@ -652,10 +655,19 @@ extern "C" int stk_mg_create_from_csr(int32_t n_levels, const stk_csr_host *A_fi
                 for (int i : listed) trow.push_back(band[i]);
             lap("sweep orders");
             stk_ell_rows *dst = bw ? &K.bwd : &K.fwd;
-            if (g_mg_gs_diag_free)
+            // row form of this level's sweeps: diagonal-free (key 1, and the levels below
+            // the finest with key 2) or with the diagonal (key 0; the finest level with
+            // key 2, which also gets the diagonal-free copies as its alternative form)
+            const bool full_rows = g_mg_gs_diag_free == 0 || (g_mg_gs_diag_free == 2 && j == J);
+            if (!full_rows) {
                 ells_ok = ell_rows(B, u, listed, true, 0, nullptr, nullptr, dst) && ells_ok;
-            else
+            } else {
                 ells_ok = ell_rows(B, u, listed, false, 0, &dia_a_of_row, M_fine ? &dia_m_of_row : nullptr, dst) && ells_ok;
+                if (g_mg_gs_diag_free == 2) {
+                    stk_ell_rows *alt = bw ? &K.bwd_alt : &K.fwd_alt;
+                    if (ell_rows(B, u, listed, true, 0, nullptr, nullptr, alt)) (bw ? L.ell_bwd_alt : L.ell_fwd_alt) = alt;
+                }
+            }
             lap("ELL copies of the sweeps");
             if (bw) {
                 K.bwd_ptr = ptr;

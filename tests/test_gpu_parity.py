@@ -2171,6 +2171,33 @@ def test_multigrid_plan_from_csr_through_ctypes_only(stk):
                     mgmod.GS_DIAG_FREE = True
                 assert relerr(got2, py2) < 1e-13, (problem, with_coords)
                 stk.check(lib.stk_mg_destroy(plan))
+                # --- and with those forms only where the history's gap is owned: key 2
+                # (finest level: rows with their diagonal + the diagonal-free copies as
+                # the alternative form) and the plan options of the default arithmetic
+                stk.check(lib.stk_set_tuning(b'mg_gs_diag_free', 2))
+                try:
+                    plan = ctypes.c_void_p()
+                    stk.check(lib.stk_mg_create_from_csr(
+                        len(P_mats) + 1, ctypes.byref(a_h), None, P_arr,
+                        coords.ctypes.data if with_coords else None, coords.shape[1],
+                        3, 2, 1.0, 0, None, ld, ctypes.byref(plan)))
+                finally:
+                    stk.check(lib.stk_set_tuning(b'mg_gs_diag_free', 1))
+                for key, value in ((b'fuse_restrict_max_level', len(P_mats) - 1),
+                                   (b'fast_until_cycle', 1), (b'fast_parts', 1)):
+                    stk.check(lib.stk_mg_set_option(plan, key, value))
+                u3 = torch.empty_like(f)
+                stk.check(lib.stk_mg_apply(plan, stk.stream(), n_loc, ld, 1.0, None,
+                                           None, stk.ptr(f), stk.ptr(u3)))
+                got3 = u3[:, :n_loc].cpu().numpy()
+                assert relerr(got3, want) < 1e-12, (problem, with_coords)
+                assert not np.array_equal(got3, got) and not np.array_equal(got3, got2)
+                # every V-cycle declared fast: the diagonal-free plan's result, bit for bit
+                stk.check(lib.stk_mg_set_option(plan, b'fast_until_cycle', 2))
+                stk.check(lib.stk_mg_apply(plan, stk.stream(), n_loc, ld, 1.0, None,
+                                           None, stk.ptr(f), stk.ptr(u3)))
+                assert np.array_equal(u3[:, :n_loc].cpu().numpy(), got), (problem, with_coords)
+                stk.check(lib.stk_mg_destroy(plan))
                 # --- a family: C_j = (2^j M + 0.3 A)^-1, per-slice coefficients
                 cms = np.array([1.0, 2.0, 4.0])
                 plan = ctypes.c_void_p()
