@@ -118,34 +118,16 @@ __global__ __launch_bounds__(BS, (K >= 12 || RP > 1) ? 4 : 6) void kron_pack_ker
     double *s_w = s_dict + (DICT ? a.n_codes * RP * NT : R * K * RP * NT);
 
     const int tid = threadIdx.x;
-    int r = tid / W;
-    int p = tid - r * W;
-    // EXPERIMENT (tools/kron_ab.py --split): the split slab --
-    // an M x ld main block with ld = n_loc - 1 steps per row (512-byte rows at 65 steps)
-    // and the last step of every row as a 16-byte pair in a tail block behind it.  With
-    // flag bit 3 the lanes of a slot row are its ld / 2 main pairs, a power-of-two run
-    // (a wave = two whole rows), and the tail pairs of all slot rows follow in lanes of
-    // their own.
-    const bool split = !GHOST && a.ld == a.n_loc - 1;
-    if (split && (a.flags & 8)) {
-        const int PM = a.ld / 2;
-        if (tid < R * PM) {
-            r = tid / PM;
-            p = tid - r * PM;
-        } else {
-            r = tid - R * PM;
-            p = PM;
-        }
-    }
+    const int r = tid / W;
+    const int p = tid - r * W;
     const bool in_row = r < R;
     const bool ghost_lane = GHOST && p == a.P;
     const int t0 = 2 * p;  // own lanes: first time step of the pair
     const bool has1 = t0 + 1 < a.n_loc;
     // what distinguishes the lanes of a row: where their 16 bytes of a column start
-    const bool tail_lane = split && t0 >= a.ld;
-    const size_t off_lane = ghost_lane ? 0 : tail_lane ? (size_t)a.M * a.ld * 8 : (size_t)t0 * 8;
-    const char *base_lane = reinterpret_cast<const char *>(ghost_lane ? a.gh : a.x) + off_lane;
-    const uint32_t stride_lane = (ghost_lane || tail_lane) ? 16u : (uint32_t)a.ld * 8u;
+    const char *base_lane = ghost_lane ? reinterpret_cast<const char *>(a.gh)
+                                       : reinterpret_cast<const char *>(a.x) + (size_t)t0 * 8;
+    const uint32_t stride_lane = ghost_lane ? 16u : (uint32_t)a.ld * 8u;
     const uint32_t col_mask = (1u << a.col_bits) - 1u;
     // where a lane leaves its two sums in s_w (index q = t + 1)
     const int wq0 = ghost_lane ? 0 : t0 + 1;
@@ -386,8 +368,8 @@ __global__ __launch_bounds__(BS, (K >= 12 || RP > 1) ? 4 : 6) void kron_pack_ker
             for (int j = 0; j < RP; ++j) {
                 if (RP > 1 && yrow[j] < 0) continue;  // a slot row that serves one matrix row only
                 if (!has1) y1[j] = 0.0;              // padding slot stays zero
-                double2 *dst = reinterpret_cast<double2 *>(reinterpret_cast<char *>(a.y) + off_lane +
-                                                           (size_t)(uint32_t)yrow[j] * stride_lane);
+                double2 *dst = reinterpret_cast<double2 *>(
+                    reinterpret_cast<char *>(a.y) + (size_t)(uint32_t)yrow[j] * ((size_t)a.ld * 8) + (size_t)t0 * 8);
                 if (a.beta != 0.0) {
                     const double2 old = *dst;
                     y0[j] = fma(a.beta, old.x, y0[j]);
@@ -729,10 +711,8 @@ extern "C" int stk_kron_pack_apply(void *stream, const stk_pack_pattern *pat, in
                 "stk_kron_pack_apply: col_bits=%d cannot address %d columns", pat->col_bits, pat->M);
     STK_REQUIRE(pat->vals || (pat->n_codes >= 1 && (int64_t)pat->n_codes <= ((int64_t)1 << (32 - pat->col_bits))),
                 "stk_kron_pack_apply: %d codes do not fit %d bits", pat->n_codes, 32 - pat->col_bits);
-    STK_REQUIRE(n_loc > 0 && (ld >= n_loc || (ld == n_loc - 1 && ld >= 2 && !ghosts)) && (ld & 1) == 0,
-                "stk_kron_pack_apply: bad sizes n_loc=%d ld=%d (ld must be even; n_loc - 1 = the split slab of "
-                "tools/kron_ab.py --split)",
-                n_loc, ld);
+    STK_REQUIRE(n_loc > 0 && ld >= n_loc && (ld & 1) == 0,
+                "stk_kron_pack_apply: bad sizes n_loc=%d ld=%d (ld must be even)", n_loc, ld);
     STK_REQUIRE(n_terms >= 1 && n_terms <= 3, "stk_kron_pack_apply: n_terms=%d not in 1..3", n_terms);
     STK_REQUIRE((n_loc + 1) / 2 + 2 <= 512, "stk_kron_pack_apply: n_loc=%d too large", n_loc);
     STK_REQUIRE(x != y, "stk_kron_pack_apply: input aliases output");

@@ -26,9 +26,6 @@ ap.add_argument('--problem', default='square')
 ap.add_argument('--n_loc', type=int, default=65)
 ap.add_argument('--ghosts', type=int, default=0)
 ap.add_argument('--ld', type=int, default=0, help='row stride in doubles (0: n_loc rounded up to even)')
-ap.add_argument('--split', type=int, default=0,
-                help='1: also time the split slab (M x (n_loc-1) main block + one 16-byte tail pair per row; '
-                     'variants "split" and "split,pack_flags=11" = with the lane remap), checked against the classic one')
 ap.add_argument('--rounds', type=int, default=9)
 ap.add_argument('--reps', type=int, default=20)
 ap.add_argument('--variants', default='plain;pack;pack,pack_flags=1;pack,pack_flags=2;pack,pack_flags=3')
@@ -70,19 +67,10 @@ def run(variant):
         _lib.check(_lib.lib().stk_set_tuning(k.encode(), int(v)))
     if parts[0] == 'plain':
         return lambda: ell.apply([(tri[0], 0, x, lo, hi), (tri[1], 1, x, lo, hi)], n_loc, ld, 0.0, y)
-    if parts[0] == 'split':
-        return lambda: ell.packed.apply([(tri[0], 0), (tri[1], 1)], xs, None, n_loc, lds, 0.0, ys)
     form = {'pack': ell.packed, 'pack1': forms[1], 'pack2': forms[2]}[parts[0]]
     return lambda: form.apply([(tri[0], 0), (tri[1], 1)], x, gh, n_loc, ld, 0.0, y)
 
 
-if args.split:
-    assert n_loc % 2 == 1 and not args.ld and g is None
-    lds = n_loc - 1
-    xs = torch.zeros(M * (n_loc + 1), dtype=torch.float64, device='cuda')
-    xs[:M * lds].view(M, lds).copy_(x[:, :lds])
-    xs[M * lds:].view(M, 2)[:, 0] = x[:, lds]
-    ys = torch.empty_like(xs)
 forms = {rp: ell.packed_variant(rp) for rp in (1, 2)}
 print('packed forms: default %d row(s) per unit' % ell.packed.rows_per_unit, flush=True)
 y1 = torch.full_like(x, 3.0)
@@ -105,19 +93,6 @@ for rp in (2,):
     assert same
 
 
-if args.split:
-    yc = torch.empty_like(x)
-    ell.packed.apply([(tri[0], 0), (tri[1], 1)], x, None, n_loc, ld, 0.0, yc)
-    for fl in (3, 11):
-        _lib.check(_lib.lib().stk_set_tuning(b'pack_flags', fl))
-        ys.fill_(7.0)
-        ell.packed.apply([(tri[0], 0), (tri[1], 1)], xs, None, n_loc, lds, 0.0, ys)
-        torch.cuda.synchronize()
-        same = (torch.equal(ys[:M * lds].view(M, lds), yc[:, :lds])
-                and torch.equal(ys[M * lds:].view(M, 2), yc[:, lds:lds + 2]))
-        print('split slab (pack_flags=%d) bit-identical with the classic layout: %s' % (fl, same), flush=True)
-        assert same
-    _lib.check(_lib.lib().stk_set_tuning(b'pack_flags', 3))
 variants = args.variants.split(';')
 times = {v: [] for v in variants}
 for rnd in range(args.rounds):
