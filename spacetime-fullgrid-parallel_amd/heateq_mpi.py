@@ -262,29 +262,23 @@ class HeatEquationMPI:
         hierarchy = hierarchy.result()
         mark('wavelets, prolongations')
         self.hierarchy = hierarchy
-        from source import multigrid as _mg
-        gs_form = _mg.GS_DIAG_FREE
-        if arithmetic == 'reference':
-            _mg.GS_DIAG_FREE = False
-        elif arithmetic == 'accurate':
-            # the reference's forms where they matter: the gap of the fast mode is owned
-            # by the FINEST level (profiles/r03_history_by_level.log) and there by the
-            # LAST V-cycle's restricted residual and post-smoothing
-            # (profiles/r03_history_by_cycle.log) -- what comes earlier is damped by
-            # what follows it.  The finest level gets both row forms.
-            _mg.GS_DIAG_FREE_LEVELS = lambda level, finest: level < finest
-            _mg.GS_ALT_COPIES = True
+        # Row form of the Gauss-Seidel copies.  'owned': the reference's forms where they
+        # matter -- the gap of the fast mode is owned by the FINEST level
+        # (profiles/r03_history_by_level.log) and there by the LAST V-cycle's restricted
+        # residual and post-smoothing (profiles/r03_history_by_cycle.log); what comes
+        # earlier is damped by what follows it.  The finest level gets both row forms.
+        gs_rows = {'reference': 'full', 'accurate': 'owned', 'fast': None}[arithmetic]
         if precond == 'multigrid' and family == 'reference':
             # one hierarchy per wavelet level from the assembled matrix
             # (reference heateq_mpi.py:147-153)
             fuse = False if arithmetic == 'reference' else None
             self.Kinv_x = MultiGrid(self.A_x, hierarchy, smoothsteps=smoothsteps,
-                                    vcycles=vcycles, fuse_restrict=fuse)
+                                    vcycles=vcycles, fuse_restrict=fuse, gs_rows=gs_rows)
             self.C_family = None
             self.C_j = [
                 MultiGrid(2**j * self.M_x + alpha * self.A_x, hierarchy,
                           smoothsteps=smoothsteps, vcycles=vcycles,
-                          fuse_restrict=fuse)
+                          fuse_restrict=fuse, gs_rows=gs_rows)
                 for j in range(self.J_time + 1)
             ]
         elif precond == 'multigrid':
@@ -298,11 +292,11 @@ class HeatEquationMPI:
                     pool.submit(on_dev(lambda: EllMatrices.shared(
                         [self.M_x, self.A_x]).packed_for(n_steps)))
                 kinv = pool.submit(on_dev(MultiGrid), self.A_x, hierarchy,
-                                   smoothsteps=smoothsteps, vcycles=vcycles)
+                                   smoothsteps=smoothsteps, vcycles=vcycles, gs_rows=gs_rows)
                 family = pool.submit(
                     on_dev(MultiGridFamily), self.A_x, self.M_x, hierarchy, ca=alpha,
                     cms=[2**j for j in range(self.J_time + 1)],
-                    smoothsteps=smoothsteps, vcycles=vcycles)
+                    smoothsteps=smoothsteps, vcycles=vcycles, gs_rows=gs_rows)
                 self.Kinv_x, self.C_family = kinv.result(), family.result()
             if arithmetic == 'accurate':
                 # restricted residual as R (A u - f) (multigrid.py:174-175) on the finest
@@ -324,9 +318,6 @@ class HeatEquationMPI:
                 InvLinOp(2**j * self.M_x + alpha * self.A_x)
                 for j in range(self.J_time + 1)
             ]
-        _mg.GS_DIAG_FREE = gs_form
-        _mg.GS_DIAG_FREE_LEVELS = None
-        _mg.GS_ALT_COPIES = False
         self.u0_x = u0_x.result()
         early.shutdown()
         mark('multigrid plans, Kronecker plan, load vector')

@@ -220,7 +220,14 @@ GS_ALT_COPIES = False
 class _DeviceHierarchy:
     """Everything one libstk multigrid plan needs, resident on the device."""
     def __init__(self, mat_a, mat_m, hierarchy, smoothsteps, vcycles,
-                 coarse_mats):
+                 coarse_mats, gs_rows=None):
+        # row form of the Gauss-Seidel copies: 'free' (diagonal-free on every level),
+        # 'full' (the reference's form on every level), 'owned' (the reference's form
+        # on the finest level, which also gets the diagonal-free copies as its
+        # alternative form; diagonal-free below -- what HeatEquationMPI's default
+        # arithmetic runs on), None: the module switches GS_DIAG_FREE* above
+        assert gs_rows in (None, 'free', 'full', 'owned')
+        self.gs_rows = gs_rows
         self.J = hierarchy.J
         self.smoothsteps, self.vcycles = smoothsteps, vcycles
         self.has_m = mat_m is not None
@@ -253,6 +260,18 @@ class _DeviceHierarchy:
         self.twin = None  # a second plan on the same matrices with workspaces of its own
         self.twin_ld = 0
         self.options = {}  # stk_mg_set_option keys of this hierarchy's plans
+
+    def _row_form(self, j):
+        """(rows with their diagonal?, diagonal-free copies beside them?) of level j."""
+        if self.gs_rows == 'free':
+            return False, False
+        if self.gs_rows == 'full':
+            return True, False
+        if self.gs_rows == 'owned':
+            return j == self.J, j == self.J
+        free = GS_DIAG_FREE and (GS_DIAG_FREE_LEVELS is None
+                                 or GS_DIAG_FREE_LEVELS(j, self.J))
+        return not free, (not free) and GS_DIAG_FREE and GS_ALT_COPIES
 
     def _fill_level(self, j, hierarchy):
         L = self.levels[j]
@@ -308,14 +327,14 @@ class _DeviceHierarchy:
                 groups = [r_[np.argsort(key[r_], kind='stable')] for r_ in groups]
                 listed = (np.concatenate(groups) if n else
                           np.zeros(0, dtype=np.int64))
-                if GS_DIAG_FREE and (GS_DIAG_FREE_LEVELS is None
-                                     or GS_DIAG_FREE_LEVELS(j, self.J)):
+                full_rows, alt_copies = self._row_form(j)
+                if not full_rows:
                     ells[name] = EllRowsMatrix(indptr, indices, vals[0], vm,
                                                listed, diag=True)
                 else:
                     ells[name] = EllRowsMatrix(indptr, indices, vals[0], vm, listed,
                                                dia_values=True)
-                    if GS_DIAG_FREE and GS_ALT_COPIES:
+                    if alt_copies:
                         ells[name + '_alt'] = EllRowsMatrix(indptr, indices, vals[0], vm,
                                                             listed, diag=True)
                 if band is not None:
@@ -465,14 +484,14 @@ class MultiGrid(SpaceOp):
     member = None
 
     def __init__(self, mat, hierarchy, smoothsteps=2, vcycles=1,
-                 fuse_restrict=None):
+                 fuse_restrict=None, gs_rows=None):
         self.num_applies = 0
         self.time_applies = 0
         self.hierarchy = hierarchy
         self.smoothsteps = smoothsteps
         self.vcycles = vcycles
         self._dev = _DeviceHierarchy(mat, None, hierarchy, smoothsteps,
-                                     vcycles, lambda a0, m0: [a0])
+                                     vcycles, lambda a0, m0: [a0], gs_rows=gs_rows)
         if fuse_restrict is not None:
             # False: the restricted residual as the reference forms it,
             # R (A u - f) (multigrid.py:174-175); see stk_mg_set_option
@@ -532,7 +551,7 @@ class MultiGridFamily:
     BlockDiagMPI recognises members of one family and runs all time slices in
     one batched V-cycle."""
     def __init__(self, mat_a, mat_m, hierarchy, ca, cms, smoothsteps=2,
-                 vcycles=1, fuse_restrict=None):
+                 vcycles=1, fuse_restrict=None, gs_rows=None):
         self.ca = float(ca)
         self.cms = [float(c) for c in cms]
         self.hierarchy = hierarchy
@@ -542,7 +561,7 @@ class MultiGridFamily:
             return [a0] + [self.ca * a0 + c * m0 for c in self.cms]
 
         self._dev = _DeviceHierarchy(mat_a, mat_m, hierarchy, smoothsteps,
-                                     vcycles, coarse)
+                                     vcycles, coarse, gs_rows=gs_rows)
         if fuse_restrict is not None:
             self._dev.set_option('fuse_restrict', bool(fuse_restrict))
         self.shape = self._dev.shape
