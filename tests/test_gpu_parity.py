@@ -1059,6 +1059,32 @@ def test_restricted_residual_variants_agree(stk):
     assert not np.array_equal(out['free, csr'], out['full, csr'])
 
 
+def test_solve_is_reproducible_run_to_run(stk):
+    """No kernel of the path uses atomics or an order that depends on scheduling
+    (two-stage dot products, one writer per output element), S runs two V-cycle
+    chains on two HIP streams and the set-up builds its plans in worker threads:
+    two solves of two separately built operators give the same bits, and so do
+    repeated applies."""
+    import heateq_mpi as hm
+    from source.linalg import PCG
+    runs = []
+    for rep in range(2):
+        h = hm.HeatEquationMPI(J_space=6, J_time=4, problem='square')
+        x = _vec(h.dofs_distr, np.random.RandomState(77).rand(h.N, h.M))
+        applies = [(_np(h.S @ x), _np(h.P @ x), _np(h.WT_S_W @ x)) for _ in range(3)]
+        for k in range(3):
+            assert np.array_equal(applies[1][k], applies[0][k]) and np.array_equal(applies[2][k], applies[0][k])
+        hist = []
+        w, it = PCG(h.WT_S_W, h.P, h.rhs, history=hist)
+        runs.append((it, np.asarray(hist), _np(w), applies[0]))
+        del h
+    assert runs[0][0] == runs[1][0]
+    assert np.array_equal(runs[0][1], runs[1][1])
+    assert np.array_equal(runs[0][2], runs[1][2])
+    for k in range(3):
+        assert np.array_equal(runs[0][3][k], runs[1][3][k])
+
+
 def test_reference_forms_only_where_the_gap_is_owned(stk):
     """The default arithmetic keeps the reference's forms for the last V-cycle's
     restricted residual and post-smoothing on the finest level (plan options
