@@ -226,42 +226,7 @@ __global__ __launch_bounds__(BS, (K >= 12 || RP > 1) ? 4 : 6) void kron_pack_ker
 #pragma unroll
             for (int k = 0; k < NT; ++k) acc0[j][k] = acc1[j][k] = 0.0;
 
-        if constexpr (RP >= 3) {
-            // EXPERIMENT (tools/kron_ab.py, variant pack4): three or four rows per slot row
-            // lost to their registers (K gathered pairs in flight); here the K gathers
-            // are issued in two batches, so that at most (K + 1) / 2 pairs are held at a
-            // time.  The slots of a row are accumulated in the same ascending order.
-            if (active) {
-                constexpr int NB = 1, KB = (K + NB - 1) / NB;
-                int ro = r * KS;
-#pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    asm volatile("" : "+v"(ro));
-                    const uint32_t *so = s_slot + ro + b * KB;
-                    double2 xv[KB];
-                    uint32_t sl[KB];
-#pragma unroll
-                    for (int u = 0; u < KB; ++u)
-                        if (b * KB + u < K) {
-                            sl[u] = so[u];
-                            xv[u] = load2(base_lane + (size_t)(sl[u] & col_mask) * stride_lane);
-                        }
-#pragma unroll
-                    for (int u = 0; u < KB; ++u)
-                        if (b * KB + u < K) {
-                            const double *dv = s_dict + (sl[u] >> a.col_bits) * (RP * NT);
-#pragma unroll
-                            for (int j = 0; j < RP; ++j, dv += NT) {
-#pragma unroll
-                                for (int k = 0; k < NT; ++k) {
-                                    acc0[j][k] = fma(dv[k], xv[u].x, acc0[j][k]);
-                                    acc1[j][k] = fma(dv[k], xv[u].y, acc1[j][k]);
-                                }
-                            }
-                        }
-                }
-            }
-        } else if (active) {
+        if (active) {
             int ro = r * KS;
             double2 xv[K];
             {
@@ -604,15 +569,6 @@ int launch_npf(hipStream_t st, const PackArgs<NT> &a, unsigned grid, size_t lds)
             return 0;
         }
     }
-    if constexpr (RP >= 3) {
-        static bool raised = false;
-        if (!raised) {
-            STK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&kron_pack_kernel<NT, K, 1, GHOST, BS, false, RP>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-            raised = true;
-        }
-        STK_REQUIRE(npf <= 1, "stk_kron_pack_apply: four rows per slot row: %d slot words per thread", npf);
-    }
     if (npf <= 1)
         hipLaunchKernelGGL((kron_pack_kernel<NT, K, 1, GHOST, BS, false, RP>), dim3(grid), dim3(BS), lds, st, a);
     else if (npf <= 2)
@@ -639,14 +595,13 @@ int launch(hipStream_t st, PackArgs<NT> a, int K)
                                  (size_t)NT * 3 * (a.n_loc + 2)) +
                sizeof(uint32_t) * ((size_t)R * KS + (size_t)R * RP + 4) + 32;
     };
-    const size_t lds_cap = RP >= 3 ? 78 * 1024 : 64 * 1024;
-    while (a.R > 1 && lds_of(a.R) > lds_cap) --a.R;  // short slabs: many units per group
+    while (a.R > 1 && lds_of(a.R) > 64 * 1024) --a.R;  // short slabs: many units per group
     a.ngroups = (a.n_units + a.R - 1) / a.R;
     a.chunk = (a.ngroups + 7) / 8;
     a.flags = g_pack_flags;
     a.diag = g_pack_diag;
     const size_t lds = lds_of(a.R);
-    STK_REQUIRE(lds <= lds_cap, "stk_kron_pack_apply: %zu bytes of LDS per workgroup (dictionary too large?)", lds);
+    STK_REQUIRE(lds <= 64 * 1024, "stk_kron_pack_apply: %zu bytes of LDS per workgroup (dictionary too large?)", lds);
     const int n_cu = stk_cu_count();
     int per_cu = g_pack_wg_per_cu > 0 ? g_pack_wg_per_cu : ((K >= 12 || RP > 1) ? 2 : 3) * (512 / BS);
     const int by_lds = (int)(160 * 1024 / (lds + 256));
@@ -675,9 +630,6 @@ int launch(hipStream_t st, PackArgs<NT> a, int K)
             STK_PACK_CASE(12)
         }
         stk_set_error("stk_kron_pack_apply: K=%d is not one of 8, 10, 12 (row pairs)", K);
-    } else if constexpr (RP == 4) {
-        if (K == 14 && !ghost) return launch_npf<NT, 14, false, BS, RP>(st, a, grid, lds);
-        stk_set_error("stk_kron_pack_apply: four rows per slot row exist for K = 14 without ghost steps only");
     }
 #undef STK_PACK_CASE
     return 2;
@@ -711,9 +663,6 @@ int dispatch(hipStream_t st, const stk_pack_pattern *pat, int32_t n_loc, int32_t
     }
     a.P = (n_loc + 1) / 2;
     if (pat->rows_per_unit == 2) return launch<NT, 512, 2>(st, a, pat->K);
-    if constexpr (NT == 2) {  // the experiment's instantiation: the metric's two terms
-        if (pat->rows_per_unit == 4) return launch<NT, 512, 4>(st, a, pat->K);
-    }
     // 256-thread workgroups: only where a row still fits comfortably
     if (g_pack_block == 256 && a.P + 1 <= 64) return launch<NT, 256, 1>(st, a, pat->K);
     return launch<NT, 512, 1>(st, a, pat->K);
@@ -752,7 +701,7 @@ extern "C" int stk_kron_pack_apply(void *stream, const stk_pack_pattern *pat, in
         for (int k = 0; k < n_terms; ++k)
             STK_REQUIRE(t[k].mat == k, "stk_kron_pack_apply: with explicit values term %d must name matrix %d", k, k);
     }
-    STK_REQUIRE(pat->rows_per_unit == 1 || pat->rows_per_unit == 2 || (pat->rows_per_unit == 4 && n_terms == 2 && !ghosts),
+    STK_REQUIRE(pat->rows_per_unit == 1 || pat->rows_per_unit == 2,
                 "stk_kron_pack_apply: rows_per_unit=%d is not 1 or 2", pat->rows_per_unit);
     STK_REQUIRE(pat->n_units > 0 && (int64_t)pat->n_units * pat->rows_per_unit >= pat->M &&
                     (pat->rows_per_unit == 1 ? pat->n_units == pat->M : pat->row_ids != nullptr),

@@ -47,8 +47,7 @@ extern "C" int32_t stk_pack_unit_slots(int32_t K, int32_t rp)
 {
     if (rp == 1) return K;
     if (rp == 2) return K == 5 ? 8 : K == 7 ? 10 : K == 9 ? 12 : 0;
-    if (rp == 4 && K == 7) return 14;  // EXPERIMENT: 2 x 2 patches of a P1 mesh (tools/kron_ab.py --order patch2)
-    return 0;  // three / four rows per unit in RUNS (K = 7 -> 13 / 16): measured slower than pairs, not instantiated
+    return 0;  // three / four rows per unit (K = 7 -> 13 / 16): measured slower than pairs, not instantiated
 }
 
 // Row pairs need rows that follow each other in the processing order to share

@@ -31,8 +31,7 @@ ap.add_argument('--reps', type=int, default=20)
 ap.add_argument('--variants', default='plain;pack;pack,pack_flags=1;pack,pack_flags=2;pack,pack_flags=3')
 ap.add_argument('--phases', action='store_true')
 ap.add_argument('--rows-per-tile', default='')
-ap.add_argument('--order', default='patch', help='patch (assembly hint), index (memory order) or patch2 '
-                '(mesh tiles with 2 x 2 blocks of vertices inside: four rows per slot row, variant pack4)')
+ap.add_argument('--order', default='patch', help='patch (assembly hint) or index (memory order)')
 args = ap.parse_args()
 if args.rows_per_tile:
     os.environ['STK_ROWS_PER_TILE'] = args.rows_per_tile
@@ -41,13 +40,6 @@ M_x, A_x = space_matrices(mesh)
 M = M_x.shape[0]
 if args.order == 'index':
     M_x.stk_row_order = A_x.stk_row_order = np.arange(M, dtype=np.int32)
-if args.order == 'patch2':
-    pts = mesh.points[~mesh.boundary]
-    h = np.min(np.diff(np.unique(np.round(pts[:, 0], 12))))
-    ix, iy = np.rint(pts[:, 0] / h).astype(np.int64), np.rint(pts[:, 1] / h).astype(np.int64)
-    side = int(np.sqrt(2048))  # vertices per tile edge, as the default tiles
-    order = np.lexsort((ix & 1, iy & 1, ix >> 1, iy >> 1, ix // side, iy // side)).astype(np.int32)
-    M_x.stk_row_order = A_x.stk_row_order = order
 ell = EllMatrices([M_x, A_x], [M_x])
 n_loc = args.n_loc
 ld = args.ld or (n_loc + (n_loc & 1))
@@ -75,10 +67,7 @@ def run(variant):
         _lib.check(_lib.lib().stk_set_tuning(k.encode(), int(v)))
     if parts[0] == 'plain':
         return lambda: ell.apply([(tri[0], 0, x, lo, hi), (tri[1], 1, x, lo, hi)], n_loc, ld, 0.0, y)
-    if parts[0] == 'pack4':
-        forms.setdefault(4, ell.packed_variant(4))
-        assert forms[4].ok and forms[4].rows_per_unit == 4, 'four rows per slot row not available'
-    form = {'pack': ell.packed, 'pack1': forms[1], 'pack2': forms[2], 'pack4': forms.get(4)}[parts[0]]
+    form = {'pack': ell.packed, 'pack1': forms[1], 'pack2': forms[2]}[parts[0]]
     return lambda: form.apply([(tri[0], 0), (tri[1], 1)], x, gh, n_loc, ld, 0.0, y)
 
 
@@ -90,9 +79,7 @@ if forms[1].ok and forms[1].rows_per_unit == 1:
 else:  # values without a dictionary: the one-row form is the plain one
     print('   no dictionary for these values: one-row form = plain sliced ELL', flush=True)
     ell.apply([(tri[0], 0, x, lo, hi), (tri[1], 1, x, lo, hi)], n_loc, ld, 0.0, y1)
-if 'pack4' in args.variants:
-    forms[4] = ell.packed_variant(4)
-for rp in sorted(k for k in forms if k >= 2):
+for rp in (2,):
     f = forms[rp]
     if f.rows_per_unit != rp:
         print('   %d rows per unit: not available for these matrices' % rp)
