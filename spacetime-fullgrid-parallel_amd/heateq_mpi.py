@@ -156,6 +156,30 @@ class SchurMPI(LinearOperatorMPI):
         return vec_out
 
 
+class _Beside:
+    """fn(*args) in a thread of its own (host work that holds no interpreter lock
+    for long: NumPy on large arrays); result() joins and re-raises.  A daemon
+    thread: nothing to shut down if the caller never gets to result()."""
+    def __init__(self, fn, *args):
+        import threading
+        self._out = self._err = None
+
+        def run():
+            try:
+                self._out = fn(*args)
+            except BaseException as err:  # handed to the caller of result()
+                self._err = err
+
+        self._thread = threading.Thread(target=run, daemon=True)
+        self._thread.start()
+
+    def result(self):
+        self._thread.join()
+        if self._err is not None:
+            raise self._err
+        return self._out
+
+
 class HeatEquationMPI:
     """Creates the operators for solving the heat equation in parallel in time
     (reference heateq_mpi.py:29-201).  Matrices come from the build's own P1
@@ -227,9 +251,8 @@ class HeatEquationMPI:
         # the load vector and the prolongations need the mesh only: beside the
         # assembly, which runs on the host threads of libstk (no GIL held)
         from concurrent.futures import ThreadPoolExecutor
-        early = ThreadPoolExecutor(max_workers=2)
-        u0_x = early.submit(space_load, mesh_space, data['u0'])
-        hierarchy = early.submit(MeshHierarchy, mesh_space)
+        u0_x = _Beside(space_load, mesh_space, data['u0'])
+        hierarchy = _Beside(MeshHierarchy, mesh_space)
         # --- TIME --- (heateq_mpi.py:78-88)
         self.A_t, self.L_t, self.M_t, self.G_t, self.u0_t = time_matrices(
             mesh_time)
@@ -319,7 +342,6 @@ class HeatEquationMPI:
                 for j in range(self.J_time + 1)
             ]
         self.u0_x = u0_x.result()
-        early.shutdown()
         mark('multigrid plans, Kronecker plan, load vector')
         self.CAC_j = [
             CompositeLinOp([self.C_j[j], self.A_x, self.C_j[j]])
