@@ -29,16 +29,19 @@ for p in (REPO, PKG):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+XGMI_LINK_GBS_PER_DIRECTION = 76.8  # xGMI: 7 point-to-point links per GPU, ~153.6 GB/s bidirectional each
 
 
 def seeded_slab(t_begin, t_end, M):
-    """x ~ U[0,1), generated per GLOBAL time row so that every rank count sees
-    the same global vector (protocol of reference heateq_mpi_timing.py:81-83,
-    which seeds 128)."""
-    out = np.empty((t_end - t_begin, M))
-    for t in range(t_begin, t_end):
-        out[t - t_begin] = np.random.RandomState(128 + t).rand(M)
-    return out
+    """Rows [t_begin, t_end) of the reference's timing vector: `np.random.seed(128);
+    np.random.rand(N, M)` drawn GLOBALLY and then sliced (reference
+    heateq_mpi_timing.py:81-83), so that every rank count
+    sees the same global vector.  The generator's stream is row-major: the rows
+    before the slab are drawn and dropped one at a time."""
+    rs = np.random.RandomState(128)
+    for _ in range(t_begin):
+        rs.rand(M)
+    return rs.rand(t_end - t_begin, M)
 
 
 _CPU = {}
@@ -226,17 +229,28 @@ def profiler_preloaded():
             or any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ))
 
 
+EXTERNAL_LAUNCHERS = ('OMPI_COMM_WORLD_SIZE', 'PMI_SIZE', 'PMIX_RANK', 'SLURM_NTASKS')
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: N ranks as child processes
-    of torch.distributed.run on 127.0.0.1, a free port; returns their exit code."""
-    import socket
+    of torch.distributed.run on 127.0.0.1, a free port; returns their exit code.
+    Refused under another launcher (mpirun / srun start N processes themselves:
+    each would start N more) and under a profiler whose preloaded library has
+    already initialised the GPU in this process."""
     import subprocess
-    with socket.socket() as sock:
-        sock.bind(('127.0.0.1', 0))
-        port = sock.getsockname()[1]
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
-           '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    found = [k for k in EXTERNAL_LAUNCHERS if k in os.environ]
+    if found:
+        sys.exit('bench.py --gpus %d: started under another launcher (%s) without RANK / '
+                 'WORLD_SIZE; launch it with torch.distributed.run, one process per GPU'
+                 % (n, ', '.join(found)))
+    if profiler_preloaded():
+        sys.exit('bench.py --gpus %d: a profiler preload has initialised the GPU; put the '
+                 'profiler around torch.distributed.run instead' % n)
+    # --standalone: the launcher binds a free port itself (no probe-then-bind window)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--standalone', '--local-addr',
+           '127.0.0.1', '--nnodes=1', '--nproc-per-node', str(n),
+           os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     env.setdefault('OMP_NUM_THREADS', '4')
@@ -313,9 +327,27 @@ def main():
     n_loc = dd.t_end - dd.t_begin
     my_bytes = fused.algorithmic_bytes(n_loc, M)
 
+    halo = None
+    if size > 1:
+        # first contact with a multi-GPU node: every rank checks that its plans live on
+        # its own device and reports backend / RCCL / peer access on stderr; the halo
+        # form (direct, or routed over 3 / 7 links) is chosen by a probe on real rows
+        # unless STK_HALO_ROUTES pins it
+        from source.mpi_vector import probe_halo_form, startup_report
+        pk = fused.ell.packed_for(n_loc) if getattr(fused, 'use_ell', False) else None
+        startup_report(dd, [x.buf, y.buf] + list(fused.tri) +
+                       ([pk.slots, pk.dict] if pk is not None and pk.ok else []))
+        pinned = os.environ.get('STK_HALO_ROUTES', 'auto')
+        if pinned == 'auto':
+            halo = probe_halo_form(dd)
+        else:
+            halo = {'chosen': int(pinned), 'reason': 'pinned by STK_HALO_ROUTES'}
+    wire_wait = [0.0]
+
     def step():
         x._invalidate()  # forces the halo exchange, as heateq_mpi_timing.py:94
         op._matvec(x, y)
+        wire_wait[0] += op.time_communication
 
     # bring the device to its steady clocks first: a cold GPU runs the first few
     # milliseconds of work measurably slower (the same kernel: 0.40 ms in the
@@ -329,6 +361,7 @@ def main():
         step()
     comm.Barrier()
     torch.cuda.synchronize()
+    wire_wait[0] = 0.0
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(
         enable_timing=True)
     t0 = time.perf_counter()
@@ -354,6 +387,16 @@ def main():
         kernel_ms = ev0.elapsed_time(ev1) / args.steps
     else:
         kernel_ms = dev_ms
+
+    # several ranks: where each rank's step goes -- the host's wait for the wire, and
+    # the device time of the pieces around it, each timed alone (the received rows
+    # are there) -- gathered on rank 0
+    per_rank = None
+    if size > 1:
+        mine = {'rank': rank, 'n_loc': n_loc, 'step_ms': dev_ms, 'kernels_with_cached_halo_ms': kernel_ms,
+                'host_wait_for_wire_ms': wire_wait[0] / args.steps * 1e3}
+        mine.update(fused.phase_times(x, y) or {})
+        per_rank = comm.gather(mine)
 
     import torch.distributed as dist
     red_dev = comm._device() if size > 1 else 'cuda'  # nccl: device, gloo (tests): host
@@ -467,6 +510,28 @@ def main():
         'pcg': solve,
         'pcg_fast': solve_fast,
     }
+    if size > 1:
+        # what the wire allows: x is invalidated every step (the reference's timing
+        # protocol), so each step moves one time row of 8 M bytes to and from each
+        # neighbour over ONE xGMI link (7 links x ~153 GB/s bidirectional per GPU,
+        # ~77 GB/s per direction); routed over k links, a piece of 1 / k of the row
+        # travels in each of two phases
+        link = XGMI_LINK_GBS_PER_DIRECTION
+        k = max(1, int(halo['chosen']))
+        wire_ms = 8.0 * M / (link * 1e9) * 1e3 * (1.0 if k == 1 else 2.0 / k)
+        out['multi_gpu'] = {
+            'halo_form': halo,
+            'per_rank': per_rank,
+            'wire_bound': {
+                'bytes_per_neighbour_per_step': 8 * M,
+                'xgmi_GBs_per_link_and_direction': link,
+                'wire_ms_per_step_at_link_rate': wire_ms,
+                'ceiling_GBs': total_bytes / (wire_ms * 1e-3) / 1e9,
+                'note': 'the micro-benchmark invalidates x every step (heateq_mpi_timing.py:94): '
+                        'a step cannot be shorter than the wire time of one time row per '
+                        'neighbour, whatever the kernels do; the solve exchanges one row per S apply',
+            },
+        }
     if cpu is not None:
         out['cpu_baseline'] = cpu
     print(json.dumps(out))

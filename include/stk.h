@@ -416,6 +416,24 @@ int stk_kron_pack_ghost_apply(void *stream, const stk_pack_pattern *pattern_host
                               const stk_kron_pack_term *terms_host,
                               const double *x_lo, const double *x_hi, double *y);
 
+/* The same packed stream with an input slab PER TERM: y = beta*y + sum_k (T_k kron
+ * X_k) xs[k] -- the last stage of the Schur complement S = B^T K B + G of
+ * heateq_mpi.py:166-181 once K is applied to two right-hand sides instead of four
+ * times: (I kron M_x) v1 + (I kron A_x) v2 + (G_t kron M_x) x, i.e. three
+ * TridiagKronMatMPI / IdentityKronMatMPI applies and the sum of SumMPI._matvec
+ * (mpi_kron.py:77-90, 135-150, 214-219) in one pass.  The terms take turns on the
+ * slot words of a row (K gathers from xs[k], then term k's sums); a lane skips the
+ * turn of a term whose time factor never multiplies its pair of time steps (G_t
+ * has the single entry (0, 0)), so a term costs the traffic of the time steps it
+ * reads.  No ghost time steps: a term whose factor couples to the neighbour
+ * ranks' rows takes stk_kron_pack_apply.  The pattern must have a dictionary;
+ * xs_host: n_terms device pointers (host array), 2 or 3 terms.  Every row's sums
+ * are those of stk_kron_pack_apply, term by term. */
+int stk_kron_pack_apply_multi(void *stream, const stk_pack_pattern *pattern_host,
+                              int32_t n_loc, int32_t ld, int32_t n_terms,
+                              const stk_kron_pack_term *terms_host,
+                              const double *const *xs_host, double beta, double *y);
+
 /* ---- plan construction from CSR (no Python needed) ---------------------------
  * Everything the three forms above stream is derived here, on the host side of
  * the library, from the CSR matrices a caller of the reference holds

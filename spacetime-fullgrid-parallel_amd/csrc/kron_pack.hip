@@ -52,6 +52,16 @@
 //    registers and handed over through LDS like the slot words.  36 bytes per slot instead of 20 in the one-row plain form
 //    (kron_ell.hip), but 10 gathers for two rows instead of 14; accumulation order
 //    and results are those of the plain form, bit for bit.
+//  * INPUTS PER TERM (MULTI = true, stk_kron_pack_apply_multi): term k gathers from
+//    a slab of its own, xk[k] -- the last stage of the regrouped Schur complement,
+//    (I kron M_x) v1 + (I kron A_x) v2 + (G_t kron M_x) x (reference
+//    heateq_mpi.py:166-181), which the plain form (kron_ell.hip, 20 bytes per slot,
+//    7 gathers per row and term) ran at 0.28 of the HBM peak.  The terms take turns
+//    on the one packed slot stream: K gathers from xk[k], then the sums of term k.
+//    A lane skips the turn of a term whose time factor never multiplies its pair of
+//    time steps (G_t has the one entry (0, 0): only the first lane of a row gathers
+//    x), so a term costs the traffic of the time steps it really reads.  The sums are
+//    accumulated in the order of the one-input form, term by term.
 #include <cstring>
 
 #include "stk_common.h"
@@ -79,6 +89,7 @@ struct PackArgs {
     const double *vals;
     int32_t n_mats;
     int32_t mat[NT];
+    const double *xk[NT];  // MULTI: the input slab of term k
 };
 
 typedef double stk_v2d __attribute__((ext_vector_type(2)));
@@ -101,9 +112,10 @@ __device__ inline unsigned long long stamp()
 // iteration -- publish + barrier, gathers + space factors, exchange + barrier,
 // time stencil + store -- into a.diag[wave][4].  Its outputs are still correct;
 // its run time is not quoted anywhere.
-template <int NT, int K, int NPF, bool GHOST, int BS, bool DIAG, int RP, bool DICT = true>
+template <int NT, int K, int NPF, bool GHOST, int BS, bool DIAG, int RP, bool DICT = true, bool MULTI = false>
 __global__ __launch_bounds__(BS, (K >= 12 || RP > 1) ? 4 : 6) void kron_pack_kernel(const PackArgs<NT> a)
 {
+    static_assert(!MULTI || (!GHOST && !DIAG && DICT), "inputs per term: no ghost lanes, dictionary form");
     constexpr int NPV = DICT ? 1 : 2;  // explicit values prefetched per thread (R is sized for it)
     constexpr int KS = (K + 3) & ~3;  // LDS stride of a row's slots (16-byte vectors)
     extern __shared__ double sm[];
@@ -150,6 +162,29 @@ __global__ __launch_bounds__(BS, (K >= 12 || RP > 1) ? 4 : 6) void kron_pack_ker
             for (int i = tid; i < NT * R * RP; i += BS) {
                 s_w[i * SW] = 0.0;
                 s_w[i * SW + a.n_loc + 1] = 0.0;
+            }
+        }
+    }
+
+    // MULTI: does term k's time factor multiply z_k at this lane's time steps at
+    // all?  z[t] enters the output through sub[t + 1], dia[t] and super[t - 1].
+    bool need[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) need[k] = true;
+    if constexpr (MULTI) {
+        if (a.any_tri) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                if (a.tri[k] == nullptr) continue;
+                const double *c = s_tri + k * 3 * LT;
+                bool used = false;
+                for (int t = t0; t < min(t0 + 2, a.n_loc); ++t) {
+                    used = used || c[LT + t] != 0.0;
+                    if (t + 1 < a.n_loc) used = used || c[t + 1] != 0.0;
+                    if (t >= 1) used = used || c[2 * LT + t - 1] != 0.0;
+                }
+                need[k] = used;
             }
         }
     }
@@ -226,7 +261,46 @@ __global__ __launch_bounds__(BS, (K >= 12 || RP > 1) ? 4 : 6) void kron_pack_ker
 #pragma unroll
             for (int k = 0; k < NT; ++k) acc0[j][k] = acc1[j][k] = 0.0;
 
-        if (active) {
+        if (MULTI && active) {
+            // the terms take turns: K gathers from term k's own slab, then its sums
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                if (!need[k]) continue;
+                const char *base_k = reinterpret_cast<const char *>(a.xk[k]) + (size_t)t0 * 8;
+                int ro = r * KS;
+                double2 xv[K];
+                {
+                    uint32_t sl[KS];
+                    const uint4 *so = reinterpret_cast<const uint4 *>(s_slot + ro);
+#pragma unroll
+                    for (int u = 0; u < KS / 4; ++u) {
+                        const uint4 v = so[u];
+                        sl[4 * u] = v.x, sl[4 * u + 1] = v.y, sl[4 * u + 2] = v.z, sl[4 * u + 3] = v.w;
+                    }
+#pragma unroll
+                    for (int u = 0; u < K; ++u) xv[u] = load2(base_k + (size_t)(sl[u] & col_mask) * stride_lane);
+                }
+                asm volatile("" : "+v"(ro));  // the codes are read again: see below
+                uint32_t sl[KS];
+                const uint4 *so = reinterpret_cast<const uint4 *>(s_slot + ro);
+#pragma unroll
+                for (int u = 0; u < KS / 4; ++u) {
+                    const uint4 v = so[u];
+                    sl[4 * u] = v.x, sl[4 * u + 1] = v.y, sl[4 * u + 2] = v.z, sl[4 * u + 3] = v.w;
+                }
+#pragma unroll
+                for (int u = 0; u < K; ++u) {
+                    const double *dv = s_dict + (sl[u] >> a.col_bits) * (RP * NT) + k;
+#pragma unroll
+                    for (int j = 0; j < RP; ++j, dv += NT) {
+                        const double v = dv[0];
+                        acc0[j][k] = fma(v, xv[u].x, acc0[j][k]);
+                        acc1[j][k] = fma(v, xv[u].y, acc1[j][k]);
+                    }
+                }
+            }
+        }
+        if (!MULTI && active) {
             int ro = r * KS;
             double2 xv[K];
             {
@@ -562,6 +636,21 @@ int launch_npf(hipStream_t st, const PackArgs<NT> &a, unsigned grid, size_t lds)
             return 0;
         }
     }
+    if constexpr (!GHOST && NT >= 2 && BS == 512) {
+        if (a.xk[0] != nullptr) {  // inputs per term (dictionary form only: checked by the entry point)
+            if (npf <= 1)
+                hipLaunchKernelGGL((kron_pack_kernel<NT, K, 1, false, BS, false, RP, true, true>), dim3(grid), dim3(BS),
+                                   lds, st, a);
+            else if (npf <= 2)
+                hipLaunchKernelGGL((kron_pack_kernel<NT, K, 2, false, BS, false, RP, true, true>), dim3(grid), dim3(BS),
+                                   lds, st, a);
+            else
+                hipLaunchKernelGGL((kron_pack_kernel<NT, K, 4, false, BS, false, RP, true, true>), dim3(grid), dim3(BS),
+                                   lds, st, a);
+            STK_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if constexpr (NT == 2 && K == 7 && !GHOST && BS == 512 && RP == 1) {
         if (a.diag != nullptr && npf <= 1) {
             hipLaunchKernelGGL((kron_pack_kernel<NT, K, 1, GHOST, BS, true, RP>), dim3(grid), dim3(BS), lds, st, a);
@@ -637,9 +726,10 @@ int launch(hipStream_t st, PackArgs<NT> a, int K)
 
 template <int NT>
 int dispatch(hipStream_t st, const stk_pack_pattern *pat, int32_t n_loc, int32_t ld, const stk_kron_pack_term *t,
-             const double *x, const double *gh, double beta, double *y)
+             const double *x, const double *gh, double beta, double *y, const double *const *xs = nullptr)
 {
     PackArgs<NT> a;
+    for (int k = 0; k < NT; ++k) a.xk[k] = xs ? xs[k] : nullptr;
     a.slots = pat->slots;
     a.row_ids = pat->row_ids;
     a.x = x;
@@ -664,7 +754,7 @@ int dispatch(hipStream_t st, const stk_pack_pattern *pat, int32_t n_loc, int32_t
     a.P = (n_loc + 1) / 2;
     if (pat->rows_per_unit == 2) return launch<NT, 512, 2>(st, a, pat->K);
     // 256-thread workgroups: only where a row still fits comfortably
-    if (g_pack_block == 256 && a.P + 1 <= 64) return launch<NT, 256, 1>(st, a, pat->K);
+    if (g_pack_block == 256 && a.P + 1 <= 64 && !xs) return launch<NT, 256, 1>(st, a, pat->K);
     return launch<NT, 512, 1>(st, a, pat->K);
 }
 
@@ -727,6 +817,40 @@ extern "C" int stk_kron_pack_apply(void *stream, const stk_pack_pattern *pat, in
         case 2: return dispatch<2>(st, pat, n_loc, ld, t, x, ghosts, beta, y);
         default: return dispatch<3>(st, pat, n_loc, ld, t, x, ghosts, beta, y);
     }
+}
+
+extern "C" int stk_kron_pack_apply_multi(void *stream, const stk_pack_pattern *pat, int32_t n_loc, int32_t ld,
+                                         int32_t n_terms, const stk_kron_pack_term *t, const double *const *xs_host,
+                                         double beta, double *y)
+{
+    const stk_timed timed_(STK_OP_KRON, stream);
+    STK_REQUIRE(pat && t && xs_host && y, "stk_kron_pack_apply_multi: null pointer");
+    STK_REQUIRE(pat->M > 0 && pat->K >= 1 && pat->slots && pat->dict && !pat->vals,
+                "stk_kron_pack_apply_multi: needs a pattern with a dictionary");
+    STK_REQUIRE(pat->rows_per_unit == 1 || pat->rows_per_unit == 2,
+                "stk_kron_pack_apply_multi: rows_per_unit=%d is not 1 or 2", pat->rows_per_unit);
+    STK_REQUIRE(pat->n_units > 0 && (int64_t)pat->n_units * pat->rows_per_unit >= pat->M &&
+                    (pat->rows_per_unit == 1 ? pat->n_units == pat->M : pat->row_ids != nullptr),
+                "stk_kron_pack_apply_multi: %d slot rows of %d matrix rows each do not cover M=%d", pat->n_units,
+                pat->rows_per_unit, pat->M);
+    STK_REQUIRE(pat->col_bits >= 1 && pat->col_bits <= 31 && ((int64_t)1 << pat->col_bits) >= pat->M,
+                "stk_kron_pack_apply_multi: col_bits=%d cannot address %d columns", pat->col_bits, pat->M);
+    STK_REQUIRE(pat->n_codes >= 1 && (int64_t)pat->n_codes <= ((int64_t)1 << (32 - pat->col_bits)),
+                "stk_kron_pack_apply_multi: %d codes do not fit %d bits", pat->n_codes, 32 - pat->col_bits);
+    STK_REQUIRE(n_loc > 0 && ld >= n_loc && (ld & 1) == 0,
+                "stk_kron_pack_apply_multi: bad sizes n_loc=%d ld=%d (ld must be even)", n_loc, ld);
+    STK_REQUIRE(n_terms >= 2 && n_terms <= 3, "stk_kron_pack_apply_multi: n_terms=%d not 2 or 3", n_terms);
+    STK_REQUIRE((n_loc + 1) / 2 + 2 <= 512, "stk_kron_pack_apply_multi: n_loc=%d too large", n_loc);
+    for (int k = 0; k < n_terms; ++k) {
+        STK_REQUIRE(t[k].mat >= 0 && t[k].mat < pat->n_mats, "stk_kron_pack_apply_multi: term %d names matrix %d of %d",
+                    k, t[k].mat, pat->n_mats);
+        STK_REQUIRE(xs_host[k] && xs_host[k] != y && ((uintptr_t)xs_host[k] & 15) == 0,
+                    "stk_kron_pack_apply_multi: input %d missing, aliasing the output or not 16-byte aligned", k);
+    }
+    STK_REQUIRE(((uintptr_t)y & 15) == 0, "stk_kron_pack_apply_multi: y must be 16-byte aligned");
+    hipStream_t st = stk_stream(stream);
+    if (n_terms == 2) return dispatch<2>(st, pat, n_loc, ld, t, xs_host[0], nullptr, beta, y, xs_host);
+    return dispatch<3>(st, pat, n_loc, ld, t, xs_host[0], nullptr, beta, y, xs_host);
 }
 
 extern "C" int stk_interleave_ghosts(void *stream, int32_t M, const double *lo, const double *hi, double *ghosts)

@@ -318,7 +318,8 @@ static int mgm(stk_mg *mg, hipStream_t st, int j, int n_loc, int ld, double ca, 
     if (g_mg_fuse_coarse && mg->coarse && j == mg->Lc && (ld & 1) == 0 && f_j == mg->f[j] && u_j == mg->u[j]) {
         // (the job list starts from zero itself when its vectors live in LDS;
         // the global-memory variant reads u)
-        if (u_zero) STK_HIP(hipMemsetAsync(u_j, 0, sizeof(double) * (size_t)L.n * ld, st));
+        if (u_zero && !stk_coarse_plan_in_lds(mg->coarse))
+            STK_HIP(hipMemsetAsync(u_j, 0, sizeof(double) * (size_t)L.n * ld, st));
         return stk_coarse_plan_run(mg->coarse, st, n_loc, ld, ca, cm, kind, mg->coarse_inv);
     }
     const bool zero_start = u_zero && j >= 1 && can_zero_start(mg, j, ld);

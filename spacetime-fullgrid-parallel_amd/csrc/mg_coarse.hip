@@ -473,6 +473,14 @@ stk_coarse_plan *stk_coarse_plan_build(const stk_coarse_level *lv, int Lc, int s
     return p;
 }
 
+// Does the job list run with its level vectors in LDS?  That variant starts the cut
+// level's u from zero itself and writes every entry of it at the end: the caller
+// need not zero it in memory.
+bool stk_coarse_plan_in_lds(const stk_coarse_plan *p)
+{
+    return g_mg_coarse_lds && g_mg_coarse_pairs <= 1 && sizeof(double) * (size_t)p->lds_rows <= 144 * 1024;
+}
+
 int stk_coarse_plan_run(const stk_coarse_plan *p, hipStream_t st, int n_loc, int ld, double ca, const double *cm,
                         const int32_t *kind, const double *coarse_inv)
 {
@@ -498,7 +506,7 @@ int stk_coarse_plan_run(const stk_coarse_plan *p, hipStream_t st, int n_loc, int
     // else single time steps (half the arena)
     const size_t lds_pair = sizeof(double2) * (size_t)p->lds_rows, lds_one = sizeof(double) * (size_t)p->lds_rows;
     const size_t lds_max = 144 * 1024;
-    if (g_mg_coarse_lds && g_mg_coarse_pairs <= 1 && lds_one <= lds_max) {
+    if (stk_coarse_plan_in_lds(p)) {
         static bool attr_set = false;
         if (!attr_set) {
             STK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mg_coarse_lds_kernel<true, true>),

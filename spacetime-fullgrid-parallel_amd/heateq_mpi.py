@@ -49,6 +49,7 @@ class SchurMPI(LinearOperatorMPI):
     applies are independent: they run side by side on two HIP streams
     (MultiGrid.apply_pair; two_streams = False: one after the other)."""
     two_streams = True
+    pack_last_stage = True  # False: the last stage in the plain sliced-ELL form (kron_ell.hip)
 
     def __init__(self, dofs_distr, A_t, L_t, M_t, G_t, M_x, A_x, Kinv_x):
         super().__init__(dofs_distr)
@@ -149,9 +150,17 @@ class SchurMPI(LinearOperatorMPI):
             self.ell.apply([self._spec(self.tLT, 0, vec_in),
                             self._spec(self.tM, 1, vec_in)], n_loc, ld, 0.0, u)
             v2 = self.Kinv_x.apply(u, n_loc=n_loc)
-        self.ell.apply([(None, 0, v1, None, None), (None, 1, v2, None, None),
-                        self._spec(self.tG, 0, vec_in)], n_loc, ld, 0.0,
-                       vec_out.buf)
+        g_lo, g_hi = self._couples[id(self.tG)]
+        if (self.pack_last_stage and packed.ok and not packed.explicit
+                and not ((g_lo or g_hi) and self.dofs_distr.size > 1)):
+            # the three inputs through the packed slot stream, one turn per term;
+            # G_t's turn only in the lanes of the time steps it multiplies
+            packed.apply_multi([(None, 0, v1), (None, 1, v2), (self.tG, 0, x)],
+                               n_loc, ld, 0.0, vec_out.buf)
+        else:
+            self.ell.apply([(None, 0, v1, None, None), (None, 1, v2, None, None),
+                            self._spec(self.tG, 0, vec_in)], n_loc, ld, 0.0,
+                           vec_out.buf)
         vec_out.communicated_bdr = False
         return vec_out
 
@@ -236,6 +245,8 @@ class HeatEquationMPI:
         mark = lambda label: self.setup_timeline.append((label, MPI.Wtime() - start_time))
         comm = MPI.COMM_WORLD if comm is None else comm
         assert arithmetic in ('fast', 'accurate', 'reference')
+        assert family in ('batched', 'reference'), family
+        assert schur in ('fused', 'reference'), schur
         if arithmetic == 'reference':
             schur = family = 'reference'
         self.arithmetic = arithmetic
@@ -304,6 +315,9 @@ class HeatEquationMPI:
                           fuse_restrict=fuse, gs_rows=gs_rows)
                 for j in range(self.J_time + 1)
             ]
+            if arithmetic == 'accurate':
+                for mg in [self.Kinv_x] + self.C_j:
+                    self._accurate_options(mg._dev, hierarchy.J, vcycles)
         elif precond == 'multigrid':
             # the two hierarchies (A_x alone; 2^j M_x + alpha A_x, all j in one
             # family) are independent host work (SciPy / NumPy release the GIL)
@@ -316,18 +330,14 @@ class HeatEquationMPI:
                         [self.M_x, self.A_x]).packed_for(n_steps)))
                 kinv = pool.submit(on_dev(MultiGrid), self.A_x, hierarchy,
                                    smoothsteps=smoothsteps, vcycles=vcycles, gs_rows=gs_rows)
-                family = pool.submit(
+                members = pool.submit(
                     on_dev(MultiGridFamily), self.A_x, self.M_x, hierarchy, ca=alpha,
                     cms=[2**j for j in range(self.J_time + 1)],
                     smoothsteps=smoothsteps, vcycles=vcycles, gs_rows=gs_rows)
-                self.Kinv_x, self.C_family = kinv.result(), family.result()
+                self.Kinv_x, self.C_family = kinv.result(), members.result()
             if arithmetic == 'accurate':
-                # restricted residual as R (A u - f) (multigrid.py:174-175) on the finest
-                # level, (R A) u - R f below it
                 for plans in (self.Kinv_x._dev, self.C_family._dev):
-                    plans.set_option('fuse_restrict_max_level', hierarchy.J - 1)
-                    plans.set_option('fast_until_cycle', vcycles - 1)  # all but the last V-cycle
-                    plans.set_option('fast_parts', 1)  # and the last one's pre-smoothing
+                    self._accurate_options(plans, hierarchy.J, vcycles)
             # strips of the strip-wise smoothing (csrc/mg.hip), measured at config 3
             # (profiles/r03_strip_sizes_two_streams.log): K's applies run two at a time
             # inside S and share the caches, the family's applies run alone
@@ -386,6 +396,16 @@ class HeatEquationMPI:
         mark('operators and right-hand side')
         self.setup_time = MPI.Wtime() - start_time
         self.mem_after_mpi = mem()
+
+    @staticmethod
+    def _accurate_options(plans, J, vcycles):
+        """The plan options of arithmetic='accurate' (gs_rows='owned' plans): the
+        restricted residual as R (A u - f) (reference multigrid.py:174-175) on the
+        finest level, (R A) u - R f below it; the fast forms in all but the last
+        V-cycle and in the last one's pre-smoothing."""
+        plans.set_option('fuse_restrict_max_level', J - 1)
+        plans.set_option('fast_until_cycle', vcycles - 1)
+        plans.set_option('fast_parts', 1)
 
     def print_time_per_apply(self):
         for name in driver.OPERATORS:

@@ -335,6 +335,15 @@ class EllRowsMatrix:
             raise _lib.StkError('EllRowsMatrix: a row has %d entries for %d slots'
                                 % (int(ov.item()), self.K))
 
+    @staticmethod
+    def check_all(copies):
+        """check() of several copies with ONE synchronisation (the plan builders
+        call it once per level, after all copies of the level are queued)."""
+        flags = [c._overflow for c in copies if getattr(c, '_overflow', None) is not None]
+        if flags and int(torch.stack(flags).max().item()) != 0:
+            for c in copies:
+                c.check()
+
     def _build_with_numpy(self, indptr, indices, va, vm, order, K, diag, pad_col,
                           want_dia, earlier_group):
         n = len(indptr) - 1
@@ -754,6 +763,17 @@ class PackedEllMatrices:
         _lib.check(_lib.lib().stk_kron_pack_ghost_apply(
             _lib.stream(), ctypes.byref(self._pattern_for(specs)), n_loc, ld, len(specs),
             self._terms(specs), _lib.ptr(x_lo), _lib.ptr(x_hi), _lib.ptr(out)))
+
+    def apply_multi(self, specs, n_loc, ld, beta, out):
+        """y = beta*y + sum over specs (tri, matrix index, x): every term reads a
+        slab of its own, no ghost time steps (stk_kron_pack_apply_multi); the
+        dictionary form only (`explicit` plans keep the plain form)."""
+        assert not self.explicit and 2 <= len(specs) <= 3
+        terms = self._terms([(tri, k) for tri, k, _ in specs])
+        xs = (ctypes.c_void_p * len(specs))(*[_lib.ptr(x) for _, _, x in specs])
+        _lib.check(_lib.lib().stk_kron_pack_apply_multi(
+            _lib.stream(), ctypes.byref(self.pattern), n_loc, ld, len(specs),
+            terms, xs, beta, _lib.ptr(out)))
 
     def apply(self, specs, x, ghosts, n_loc, ld, beta, out):
         """y = beta*y + sum over specs (tri, matrix index) applied to x;

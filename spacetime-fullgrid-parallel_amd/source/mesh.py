@@ -85,16 +85,20 @@ class TriangleMesh:
                 for b in tri:
                     if a != b:
                         nbrs[a].add(b)
-        # process edges grouped by length, then direction: structured meshes get
-        # the natural (horizontal, vertical, diagonal) classes, with the longest
-        # edges (the hypotenuses) in the LAST class.  The stiffness matrix of a
-        # right triangle has no entry across its hypotenuse, so the midpoints of
-        # the two short-edge classes are not coupled by A_x and share one
-        # Gauss-Seidel dependency level: 3 levels for A_x instead of 4.
+        # process edges grouped by length (longest first), then direction:
+        # structured meshes get the natural (diagonal, horizontal, vertical)
+        # classes, with the longest edges (the hypotenuses) in the FIRST class.
+        # The stiffness matrix of a right triangle has no entry across its
+        # hypotenuse, so A_x couples neither two old vertices, nor an old vertex
+        # with a hypotenuse midpoint, nor two short-edge midpoints: {old vertices,
+        # hypotenuse midpoints} and {short-edge midpoints} are a red-black split
+        # that respects the hierarchical prefix, and the dof-order sweep over A_x
+        # has 2 dependency levels (3 with the hypotenuses last, 4 for M_x + A_x
+        # either way).
         d = self.points[edges[:, 1]] - self.points[edges[:, 0]]
         ang = np.round(np.mod(np.arctan2(d[:, 1], d[:, 0]), np.pi), 9)
         length = np.round(np.hypot(d[:, 0], d[:, 1]), 9)
-        order = np.lexsort((np.arange(ne), ang, length))
+        order = np.lexsort((np.arange(ne), ang, -length))
         col = -np.ones(ne, dtype=np.int64)
         for e in order:
             used = {col[n] for n in nbrs[e] if col[n] >= 0}
@@ -174,13 +178,14 @@ class TetMesh:
     numbering; same attributes as TriangleMesh, with ``cells`` (nt, 4).
 
     The new vertices of a level are grouped by the *direction class* of the edge
-    they bisect, shortest edges first, and sorted lexicographically inside a
-    class.  On the Kuhn triangulation of the cube there are 7 classes (3 axes,
-    3 face diagonals, the space diagonal) and no two edges of a tetrahedron share
-    one, so vertices of one class are never adjacent: the dof-order Gauss-Seidel
-    sweep (reference multigrid.py:89-97) has at most 8 dependency levels for the
-    15-point mass matrix and 4 for the stiffness matrix, which on this mesh is
-    the 7-point stencil (axis neighbours only)."""
+    they bisect (face diagonals, axes, space diagonal) and sorted
+    lexicographically inside a class.  On the Kuhn triangulation of the cube
+    there are 7 classes (3 axes, 3 face diagonals, the space diagonal) and no two
+    edges of a tetrahedron share one, so vertices of one class are never
+    adjacent: the dof-order Gauss-Seidel sweep (reference multigrid.py:89-97) has
+    at most 8 dependency levels for the 15-point mass matrix and 2 for the
+    stiffness matrix, which on this mesh is the 7-point stencil (axis neighbours
+    only; see _edge_classes for the order of the classes)."""
     def __init__(self, points, tets, boundary_fn):
         self.points = np.asarray(points, dtype=np.float64)
         self.tets = np.asarray(tets, dtype=np.int64)
@@ -213,7 +218,15 @@ class TetMesh:
         sign = np.sign(u[np.arange(len(u)), first])
         u = u * sign[:, None]
         rel = np.round(length / length.min(), 9)
-        key = np.column_stack([rel, u])
+        # face diagonals (two non-zero components) first, then the axes, then the
+        # space diagonal: the stiffness matrix couples axis neighbours only, i.e.
+        # vertices whose numbers of odd fine-grid coordinates differ by one, so
+        # {old vertices, face-diagonal midpoints} and {axis midpoints,
+        # space-diagonal midpoints} are a red-black split of A_x that respects the
+        # hierarchical prefix (2 dependency levels instead of 4).
+        nnz = (np.abs(u) > 0).sum(axis=1)
+        prio = np.where(nnz == 2, 0, np.where(nnz == 1, 1, 2))
+        key = np.column_stack([prio, rel, u])
         _, cls = np.unique(key, axis=0, return_inverse=True)
         return cls.reshape(-1)
 

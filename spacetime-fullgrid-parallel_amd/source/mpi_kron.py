@@ -531,6 +531,47 @@ class _FusedKronSum:
             _lib.ptr(vec_out.buf)))
         return time_comm
 
+    def phase_times(self, vec_in, vec_out, reps=10):
+        """Device milliseconds of the pieces of one multi-rank apply on the packed
+        path, each timed alone with HIP events on the halo that is already there:
+        the pack of the two boundary rows, the pass over the slab without the ghost
+        steps (what runs beside the exchange), the ghost steps' share afterwards, and
+        the one-pass form with ghost lanes.  None without the packed path or a GPU."""
+        packed = (self.ell.packed_for(vec_in.n_loc)
+                  if self.use_ell and type(self).use_pack else None)
+        if packed is None or not packed.ok or not vec_in.buf.is_cuda:
+            return None
+        if self.dofs_distr.size > 1:
+            vec_in.communicate_bdr()
+        n_loc, ld, M = vec_in.n_loc, vec_in.ld, vec_in.M
+        specs = [(self.tri[k], k) for k in range(self.n_terms)]
+        lo = vec_in.X_lo if self.needs_lo else None
+        hi = vec_in.X_hi if self.needs_hi else None
+        send = torch.empty((2, M), dtype=torch.float64, device=vec_in.buf.device)
+
+        def timed(fn):
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) / reps
+
+        out = {'pack_ms': timed(lambda: _lib.check(_lib.lib().stk_halo_pack(
+            _lib.stream(), M, n_loc, ld, _lib.ptr(vec_in.buf), _lib.ptr(send[0]), 1,
+            _lib.ptr(send[1]), 1))),
+            'pass_without_ghosts_ms': timed(lambda: packed.apply(
+                specs, vec_in.buf, None, n_loc, ld, 0.0, vec_out.buf))}
+        if lo is not None or hi is not None:
+            out['ghost_share_ms'] = timed(lambda: packed.apply_ghost(
+                specs, lo, hi, n_loc, ld, vec_out.buf))
+            ghosts = vec_in.ghost_interleaved()
+            out['one_pass_with_ghost_lanes_ms'] = timed(lambda: packed.apply(
+                specs, vec_in.buf, ghosts, n_loc, ld, 0.0, vec_out.buf))
+        return out
+
     def kernel_name(self, n_loc):
         """Name of the kernel instantiation `apply` launches (for the bench
         line and for matching a PMC record to the build)."""

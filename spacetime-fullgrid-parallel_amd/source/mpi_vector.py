@@ -124,6 +124,98 @@ def halo_route_plan(size, M, routes):
     return plan
 
 
+def probe_halo_form(dofs_distr, candidates=(3, 7), reps=3):
+    """Start-up choice of the halo form (communicate_bdr, reference
+    mpi_vector.py:140-187): one REAL boundary row per neighbour is exchanged
+    directly and routed over k = 3, 7 links (halo_route_plan); a routed form is
+    taken only if every rank received bit for bit what the direct exchange
+    delivered AND the slowest rank's time over `reps` repetitions beats the direct
+    form's.  Otherwise the direct exchange stays.  Collective: every rank must call
+    it; the decision is taken on reduced values, so all ranks agree.  Sets
+    KronVectorMPI.HALO_ROUTES and returns the record
+    {'chosen', 'ms': {k: max-over-ranks ms}, 'identical': {k: bool}, 'reason'}."""
+    import torch.distributed as dist
+    comm, size = dofs_distr.comm, dofs_distr.size
+    rec = {'chosen': 1, 'ms': {}, 'identical': {}, 'reason': ''}
+    if size <= 2:
+        rec['reason'] = 'fewer than 3 ranks: no intermediate rank to route through'
+        KronVectorMPI.HALO_ROUTES = 1
+        return rec
+    rng = np.random.RandomState(4321 + dofs_distr.rank)
+    x = KronVectorMPI(dofs_distr, rng.rand(dofs_distr.t_end - dofs_distr.t_begin, dofs_distr.M))
+
+    def sync():
+        if x.buf.is_cuda:
+            torch.cuda.synchronize()
+
+    def reduce(value, op):
+        t = torch.tensor([value], dtype=torch.float64, device=comm._device())
+        dist.all_reduce(t, op=op, group=comm.group)
+        return float(t.item())
+
+    def run(k):
+        KronVectorMPI.HALO_ROUTES = k
+        x._invalidate()
+        x.communicate_bdr()  # untimed first exchange: buffers, connections
+        sync()
+        got = x.ghost_pair().clone()
+        worst = 0.0
+        for _ in range(reps):
+            x._invalidate()
+            comm.Barrier()
+            t0 = MPI.Wtime()
+            x.communicate_bdr()
+            sync()
+            worst = max(worst, MPI.Wtime() - t0)
+        return got, reduce(worst, dist.ReduceOp.MAX) * 1e3
+
+    saved = KronVectorMPI.HALO_ROUTES
+    try:
+        want, rec['ms'][1] = run(1)
+        for k in candidates:
+            if k > size - 1:
+                continue
+            got, ms = run(k)
+            same = reduce(1.0 if torch.equal(got, want) else 0.0, dist.ReduceOp.MIN) == 1.0
+            rec['ms'][k], rec['identical'][k] = ms, same
+    except Exception:
+        KronVectorMPI.HALO_ROUTES = saved
+        raise
+    good = [k for k, same in rec['identical'].items() if same and rec['ms'][k] < rec['ms'][1]]
+    rec['chosen'] = min(good, key=lambda k: rec['ms'][k]) if good else 1
+    rec['reason'] = ('routed over %d links: identical rows, %.3f ms against %.3f ms direct'
+                     % (rec['chosen'], rec['ms'][rec['chosen']], rec['ms'][1]) if good else
+                     'direct: no routed form was both identical and faster')
+    KronVectorMPI.HALO_ROUTES = rec['chosen']
+    return rec
+
+
+def startup_report(dofs_distr, tensors=()):
+    """First-contact checks of a multi-rank run, on stderr: every rank asserts that
+    the given plan tensors live on ITS device (LOCAL_RANK), and reports the
+    backend, the RCCL version and which peers its GPU can access directly."""
+    import os
+    import sys
+    import torch.distributed as dist
+    comm = dofs_distr.comm
+    dev = _lib.compute_device()
+    for t in tensors:
+        if t is not None and t.is_cuda:
+            assert t.device == dev, 'plan tensor on %s, this rank computes on %s' % (t.device, dev)
+    info = {'rank': comm.rank, 'local_rank': int(os.environ.get('LOCAL_RANK', '0')), 'device': str(dev),
+            'backend': dist.get_backend(comm.group) if comm.distributed else 'none'}
+    if dev.type == 'cuda':
+        assert dev.index == info['local_rank'] % torch.cuda.device_count(), info
+        info['peer_access'] = [bool(p == dev.index or torch.cuda.can_device_access_peer(dev.index, p))
+                               for p in range(torch.cuda.device_count())]
+        try:
+            info['rccl'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as exc:  # no RCCL in this build of PyTorch
+            info['rccl'] = 'unavailable (%s)' % type(exc).__name__
+    print('stk start-up: %s' % info, file=sys.stderr, flush=True)
+    return info
+
+
 _dot_ws = {}
 
 
@@ -413,7 +505,9 @@ class KronVectorMPI:
     # (environment STK_HALO_ROUTES; 1 = the whole row straight to the neighbour).
     # Opt-in: it has only ever run over gloo -- no multi-GPU node was available to
     # measure it or to prove it on RCCL.
-    HALO_ROUTES = int(__import__('os').environ.get('STK_HALO_ROUTES', '1'))
+    # STK_HALO_ROUTES=auto (what bench.py and the driver do on 3 ranks and more when the
+    # variable is unset): probe_halo_form decides at start-up.
+    HALO_ROUTES = int(__import__('os').environ.get('STK_HALO_ROUTES', '1').replace('auto', '1'))
 
     def _routed_halo(self, first, last, callback):
         """communicate_bdr with every row cut into HALO_ROUTES pieces: phase 1 =

@@ -90,8 +90,8 @@ def galerkin_product(R, A, P, cache=None):
         return dev
 
     nc, cap = R.shape[0], (16 if P is not None else 32)
-    dR, dA = up(R, ('R', id(R))), up(A)
-    dP = up(P, ('P', id(P))) if P is not None else (None, None, None)
+    dR, dA = up(R, 'R'), up(A)  # `cache` is per level: the role names the matrix
+    dP = up(P, 'P') if P is not None else (None, None, None)
     dev = dR[0].device
     counts = torch.empty(nc, dtype=torch.int32, device=dev)
     idx = torch.empty((nc, cap), dtype=torch.int32, device=dev)
@@ -363,6 +363,10 @@ class _DeviceHierarchy:
                 host['ells'] = ells
                 self._zero_start_ells(L, host, indptr, indices, vals[0], vm,
                                       diag, fwd_groups)
+                # one read of the device-side overflow flags per level: a listed row
+                # longer than its slots (a Gauss-Seidel copy of a matrix without a
+                # diagonal entry) must not reach the sweeps
+                EllRowsMatrix.check_all(list(ells.values()) + list(host.get('fwd0', ([],))[0]))
         for name, t in dev.items():
             setattr(L, name, _lib.ptr(t))
         self._keep.append((dev, host))

@@ -144,9 +144,9 @@ def main():
                w_norm=np.linalg.norm(w), w_sample=w[::st, ::sx].copy(),
                sample_strides=np.array([st, sx]))
     if not args.no_ops:
-        X = np.empty((o.N, o.M))
-        for t in range(o.N):  # the bench's vector: one seeded row per time step
-            X[t] = np.random.RandomState(128 + t).rand(o.M)
+        # the bench's vector (bench.seeded_slab): the reference's timing vector,
+        # np.random.seed(128); rand(N, M) (heateq_mpi_timing.py:81-83)
+        X = np.random.RandomState(128).rand(o.N, o.M)
         out['SX_sample'] = o.S(X)[::st, ::sx].copy()
         out['PX_sample'] = o.P(X)[::st, ::sx].copy()
         out['WX_sample'] = o.W(X)[::st, ::sx].copy()

@@ -90,6 +90,23 @@ def main():
                     assert got[0][0] == 0 and got[-1][1] == M
                     assert all(x[1] == y[0] for x, y in zip(got, got[1:]))
     v._invalidate()
+    # the start-up probe that chooses the halo form on real rows: collective, every
+    # rank ends with the same choice, a routed form is only ever taken when it
+    # delivered the direct exchange's rows bit for bit and was faster
+    from source.mpi_vector import probe_halo_form, startup_report
+    rec = probe_halo_form(dd)
+    assert rec['chosen'] == KronVectorMPI.HALO_ROUTES
+    assert comm.allreduce(float(rec['chosen'])) == size * rec['chosen']
+    if size <= 2:
+        assert rec['chosen'] == 1 and not rec['identical']
+    else:
+        assert set(rec['identical']) == {k for k in (3, 7) if k <= size - 1}
+        assert all(rec['identical'].values()), rec  # gloo delivers the routed rows intact
+        assert rec['chosen'] == 1 or rec['ms'][rec['chosen']] < rec['ms'][1]
+    KronVectorMPI.HALO_ROUTES = 1
+    info = startup_report(dd, [v.buf])
+    assert info['rank'] == rank and info['backend'] == 'gloo'
+    v._invalidate()
     # a5: arbitrary remote rows, pattern of every wavelet level
     for j in range(1, J + 1):
         S = wavelets.split(J, j).tocoo()

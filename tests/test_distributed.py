@@ -153,6 +153,19 @@ def test_bench_runs_as_the_driver_launches_it(nproc, backend):
     assert rec['pcg']['roofline']['bytes_per_iteration'] > 0
     if nproc > 1:
         assert 'ghost' in rec['roofline']['kernel']
+        # first-contact record of a multi-rank run: where every rank's step goes, the
+        # halo form the start-up probe chose, the ceiling the wire sets, and one
+        # start-up line per rank on stderr
+        mg = rec['multi_gpu']
+        assert [r['rank'] for r in mg['per_rank']] == list(range(nproc))
+        for r in mg['per_rank']:
+            assert r['step_ms'] > 0 and r['host_wait_for_wire_ms'] >= 0 and r['pack_ms'] > 0
+            assert r['pass_without_ghosts_ms'] > 0 and r['ghost_share_ms'] > 0
+        assert mg['halo_form']['chosen'] >= 1 and mg['halo_form']['reason']
+        if nproc > 2:
+            assert mg['halo_form']['identical'] and all(mg['halo_form']['identical'].values())
+        assert mg['wire_bound']['ceiling_GBs'] > 0
+        assert res.stderr.count('stk start-up:') == nproc
 
 
 def test_bench_builds_its_own_launch_line(monkeypatch):
@@ -173,9 +186,21 @@ def test_bench_builds_its_own_launch_line(monkeypatch):
     cmd = seen['cmd']
     assert cmd[:3] == [sys.executable, '-m', 'torch.distributed.run']
     assert cmd[cmd.index('--nproc-per-node') + 1] == '4'
-    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert '--standalone' in cmd and cmd[cmd.index('--local-addr') + 1] == '127.0.0.1'
     assert cmd[-5:] == [os.path.abspath(bench.__file__), '--gpus', '4', '--steps', '3']
     assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    # under another launcher (mpirun sets OMPI_* and no RANK) every process would start
+    # N more: refused, as is a start under a profiler preload
+    monkeypatch.setenv('OMPI_COMM_WORLD_SIZE', '4')
+    with pytest.raises(SystemExit) as exc:
+        bench.spawn_ranks(4)
+    assert 'another launcher' in str(exc.value)
+    monkeypatch.delenv('OMPI_COMM_WORLD_SIZE')
+    monkeypatch.setenv('ROCPROFILER_SOMETHING', '1')
+    monkeypatch.setenv('LD_PRELOAD', '/opt/rocm/lib/librocprofiler-sdk-tool.so')
+    with pytest.raises(SystemExit) as exc:
+        bench.spawn_ranks(4)
+    assert 'profiler' in str(exc.value)
 
 
 @pytest.mark.gpu

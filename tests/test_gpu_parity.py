@@ -610,11 +610,9 @@ def _record_history_dev(tag, hist, ref):
 
 
 def _bench_vector(N, M):
-    """The bench's input: one seeded row per global time step."""
-    X = np.empty((N, M))
-    for t in range(N):
-        X[t] = np.random.RandomState(128 + t).rand(M)
-    return X
+    """The bench's input (bench.seeded_slab): the reference's timing vector,
+    np.random.seed(128); rand(N, M) (heateq_mpi_timing.py:81-83)."""
+    return np.random.RandomState(128).rand(N, M)
 
 
 @pytest.mark.parametrize('arithmetic', ['fast', 'accurate', 'reference'])
@@ -1381,6 +1379,86 @@ def test_kron_pack_row_pairs(stk):
     scattered = sp.csr_matrix(circ(0) + circ(13) + circ(-13) + circ(29) + circ(-29))
     e = EllMatrices([scattered])
     assert e.packed.ok and e.packed.rows_per_unit == 1
+
+
+def test_kron_pack_inputs_per_term(stk):
+    """stk_kron_pack_apply_multi: every term gathers from a slab of its own on the
+    one packed slot stream (the last stage of SchurMPI: (I kron M_x) v1 + (I kron
+    A_x) v2 + (G_t kron M_x) x, reference heateq_mpi.py:166-181).  Bit for bit the
+    plain sliced-ELL form it replaces (stk_kron_ell_apply: same sums per row, terms
+    added in the same order) for the Schur shape, and dense NumPy for random time
+    factors -- among them factors with a single entry, whose term only a few lanes
+    gather; one row and row pairs per slot row; 2 and 3 terms, beta, slab lengths
+    through the lane / group / prefetch instances."""
+    from source.assembly import space_matrices
+    from source.linop import EllMatrices
+    from source.problem import problem_helper
+    rng = np.random.RandomState(77)
+    families = []
+    for problem, J in (('square', 2), ('square', 4), ('lshape', 3)):
+        M_x, A_x = space_matrices(problem_helper(problem, J_space=J, J_time=2)[0])
+        families.append((problem, [M_x, A_x]))
+    for name, mats in families:
+        ell = EllMatrices(mats, [mats[0]])
+        M = ell.M
+        for n_loc in (1, 2, 8, 9, 17, 33, 65, 129):
+            ld = n_loc + (n_loc & 1)
+
+            def slab(a):
+                s_ = torch.zeros((M, ld), dtype=torch.float64, device='cuda')
+                s_[:, :n_loc] = torch.from_numpy(a).cuda()
+                return s_
+
+            for shape in ('schur', 'random2', 'random3', 'single'):
+                nt = 2 if shape == 'random2' else 3
+                Xs = [rng.rand(M, n_loc) for _ in range(nt)]
+                tris, which = [], [int(rng.randint(2)) for _ in range(nt)]
+                if shape == 'schur':
+                    which = [0, 1, 0]
+                    g = np.zeros((3, n_loc))
+                    g[1, 0] = 1.0  # G_t = e_0 e_0^T (reference heateq_mpi.py:86-88)
+                    tris = [None, None, g]
+                elif shape == 'single':
+                    for k in range(nt):  # one entry somewhere in the band
+                        t = np.zeros((3, n_loc))
+                        d, c = int(rng.randint(3)), int(rng.randint(n_loc))
+                        if n_loc > 1:
+                            c = min(max(c, 1 if d == 0 else 0), n_loc - 2 if d == 2 else n_loc - 1)
+                            t[d, c] = 1.5
+                        else:
+                            t[1, 0] = 1.5
+                        tris.append(t)
+                else:
+                    tris = [rng.rand(3, n_loc) if rng.randint(3) else None for _ in range(nt)]
+                beta = float(rng.choice([0.0, 0.5]))
+                y0 = rng.rand(M, n_loc)
+                want = beta * y0
+                for k in range(nt):
+                    Z = mats[which[k]] @ Xs[k]
+                    if tris[k] is not None:
+                        t = tris[k]
+                        T = np.diag(t[1]) + np.diag(t[0, 1:], -1) + np.diag(t[2, :-1], 1)
+                        Z = Z @ T.T
+                    want = want + Z
+                dev_tri = [None if t is None else _lib_dev(t) for t in tris]
+                xs = [slab(X) for X in Xs]
+                y_plain = slab(y0)
+                ell.apply([(dev_tri[k], which[k], xs[k], None, None) for k in range(nt)],
+                          n_loc, ld, beta, y_plain)
+                for rows in (1, 2):
+                    form = ell.packed_variant(rows)
+                    assert form.ok and form.rows_per_unit == rows and not form.explicit
+                    y = slab(y0)
+                    form.apply_multi([(dev_tri[k], which[k], xs[k]) for k in range(nt)],
+                                     n_loc, ld, beta, y)
+                    tag = (name, n_loc, shape, rows)
+                    assert relerr(y[:, :n_loc].cpu().numpy(), want) < 1e-13, tag
+                    if shape == 'schur':
+                        assert torch.equal(y, y_plain), tag
+                    else:
+                        assert float((y - y_plain).abs().max()) <= 1e-13 * float(y_plain.abs().max()), tag
+                    if ld > n_loc:
+                        assert float(y[:, n_loc:].abs().max()) == 0.0
 
 
 def test_kron_pack_explicit_value_pairs(stk):

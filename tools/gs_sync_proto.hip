@@ -11,7 +11,14 @@
 //   mode 2  mode 0 + a stage body the size of an L2-resident Gauss-Seidel stage:
 //           every lane gathers 7 x 16 B (sc1: L1 bypassed, same-XCD producers) from
 //           rows of its XCD's own `region_kb` window, and stores 16 B;
-//   mode 3  mode 2 without any synchronisation (the body alone).
+//   mode 3  mode 2 without any synchronisation (the body alone);
+//   mode 4  (round 4) NO barrier: every workgroup owns a contiguous band of the XCD's
+//           window and a flag of its own; before stage q it waits until its two
+//           neighbour workgroups OF THE SAME XCD have published stage q - 1, runs
+//           the body, publishes stage q.  The stages pipeline along the skew (a
+//           workgroup may be one stage ahead of its neighbour), nobody waits for
+//           the slowest workgroup of the XCD;
+//   mode 5  mode 4 with empty stages: the bare price of the neighbour flags.
 // Every spin is bounded (the kernel gives up, sets a flag and every later wait
 // falls through), so the grid always drains.
 //
@@ -41,7 +48,9 @@ struct Sync {
     uint32_t *bar;      // [8][LINE] monotonic arrival counters
     uint32_t *all;      // [LINE]    one-time whole-grid arrival counter
     uint32_t *gave_up;  // [LINE]
+    uint32_t *wgflag;   // [8][MAXWG][LINE] stage published by workgroup `me` of an XCD
 };
+constexpr int MAXWG = 128;
 
 __device__ __forceinline__ uint32_t load_sc1(const uint32_t *p)
 {
@@ -86,8 +95,19 @@ __global__ __launch_bounds__(BS) void proto_kernel(Sync s, int mode, int steps, 
     const int rows_in_window = region_vec / row_vec;
     double2 acc = make_double2(0.0, 0.0);
     const long long t0 = wall_clock64();
+    uint32_t *my_flag = s.wgflag + ((size_t)xcc * MAXWG + me) * LINE;
     for (int q = 0; q < steps; ++q) {
-        if (mode >= 2) {
+        if (mode >= 4) {
+            // neighbour flags instead of a barrier: stage q may start once both
+            // neighbours have finished stage q - 1 (they then cannot start q + 1
+            // before this workgroup has published q)
+            if (tid == 0 && q > 0) {
+                if (me > 0) wait_ge(my_flag - LINE, (uint32_t)q, s.gave_up);
+                if (me + 1 < n_here) wait_ge(my_flag + LINE, (uint32_t)q, s.gave_up);
+            }
+            __syncthreads();
+        }
+        if (mode == 2 || mode == 3 || mode == 4) {
             for (int rr = r_in_wg; rr < rows_per_wg; rr += BS / lanes_per_row) {
                 // row of this stage: strided by 4 (groups), shifted by the stage
                 const int row = (int)(((me * rows_per_wg + rr) * 4u + (q & 3)) % (uint32_t)rows_in_window);
@@ -115,6 +135,11 @@ __global__ __launch_bounds__(BS) void proto_kernel(Sync s, int mode, int steps, 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         if (mode == 3) continue;
+        if (mode >= 4) {
+            __syncthreads();  // every wave's stores are out (s_waitcnt above)
+            if (tid == 0) __hip_atomic_store(my_flag, (uint32_t)(q + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
         __syncthreads();
         if (tid == 0) {
             if (mode == 1) {
@@ -160,12 +185,17 @@ int main(int argc, char **argv)
     }
     Sync s;
     uint32_t *words;
-    const size_t n_words = (8 + 8 + 1 + 1) * LINE;
+    const size_t n_words = (8 + 8 + 1 + 1 + 8 * MAXWG) * LINE;
     CK(hipMalloc(&words, n_words * 4));
     s.census = words;
     s.bar = words + 8 * LINE;
     s.all = words + 16 * LINE;
     s.gave_up = words + 17 * LINE;
+    s.wgflag = words + 18 * LINE;
+    if (grid / 8 > MAXWG) {
+        fprintf(stderr, "more than %d workgroups per XCD\n", MAXWG);
+        return 2;
+    }
     // a row of a slab that one XCD owns: 8 time steps = 4 pairs (64 bytes)
     const int row_vec = 4;
     const int region_vec = region_kb * 1024 / 16;
@@ -176,9 +206,10 @@ int main(int argc, char **argv)
     CK(hipMalloc(&cycles, sizeof(long long) * grid));
     std::vector<long long> h(grid);
     std::vector<uint32_t> hw(n_words);
-    const char *names[4] = {"XCD barrier, empty stages", "XCD barrier + neighbour XCD flags + release/acquire",
-                            "XCD barrier + L2-window stage body", "stage body alone (no synchronisation)"};
-    for (int mode = 0; mode < 4; ++mode) {
+    const char *names[6] = {"XCD barrier, empty stages", "XCD barrier + neighbour XCD flags + release/acquire",
+                            "XCD barrier + L2-window stage body", "stage body alone (no synchronisation)",
+                            "neighbour-workgroup flags + stage body, no barrier", "neighbour-workgroup flags, empty stages"};
+    for (int mode = 0; mode < 6; ++mode) {
         for (int rep = 0; rep < 2; ++rep) {
             CK(hipMemset(words, 0, n_words * 4));
             hipEvent_t e0, e1;
@@ -199,7 +230,7 @@ int main(int argc, char **argv)
                 printf("mode %d  %-52s %8.3f us per stage (event %8.3f)  gave_up=%u  per-XCD workgroups:", mode,
                        names[mode], (double)mx / clk_khz * 1e3 / steps, ms * 1e3 / steps, hw[17 * LINE]);
                 for (int x = 0; x < 8; ++x) printf(" %u", hw[x * LINE]);
-                if (mode >= 2)
+                if (mode >= 2 && mode <= 4)
                     printf("  lanes/stage/XCD %d, bytes gathered+stored per stage per XCD %.2f MB", rows_per_wg * row_vec * grid / 8,
                            rows_per_wg * row_vec * (grid / 8) * 128.0 / 1e6);
                 printf("\n");
