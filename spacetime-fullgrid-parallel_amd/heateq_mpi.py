@@ -381,6 +381,8 @@ class HeatEquationMPI:
         levels = (self.W.levels if hasattr(self.W, 'levels') else
                   WaveletTransformOp(self.J_time, interleaved=True).levels)
         self.P = BlockDiagMPI(dd, [self.CAC_j[j] for j in levels])
+        if precond == 'multigrid' and family != 'reference' and schur != 'reference':
+            self.P.mid_packed = (self.S.ell, 1)  # A_x in S's packed (M_x, A_x) stream
         self.WT_S_W = CompositeMPI(dd, [self.WT, self.S, self.W])
 
         # -- RHS -- (heateq_mpi.py:188-191)

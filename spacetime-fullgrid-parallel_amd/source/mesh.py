@@ -19,9 +19,18 @@ lexicographically inside a colour.  New vertices of one colour are then never
 adjacent, old vertices are never adjacent to each other in the refined mesh,
 and therefore a Gauss-Seidel sweep in dof order (reference multigrid.py:89-97)
 has a dependency DAG of depth (#colours + 1) -- 4 for the square -- while still
-being exactly the sequential sweep of the reference.
+being exactly the sequential sweep of the reference.  The colour of the
+hypotenuses comes FIRST (round 4): the stiffness matrix has no entry across a
+hypotenuse, which leaves its sweep with 2 dependency levels (a red-black split:
+see _greedy_edge_colouring).
 """
 import numpy as np
+
+# False: the hypotenuse class LAST among a level's new vertices (the numbering of
+# rounds 1-3: 3 dependency levels for A_x).  Only tools/mg_sweep.py flips it, to
+# show what the order does to the smoother; the fixtures under tests/golden hold
+# the default.
+HYPOTENUSE_FIRST = True
 
 
 class IntervalMesh:
@@ -98,7 +107,7 @@ class TriangleMesh:
         d = self.points[edges[:, 1]] - self.points[edges[:, 0]]
         ang = np.round(np.mod(np.arctan2(d[:, 1], d[:, 0]), np.pi), 9)
         length = np.round(np.hypot(d[:, 0], d[:, 1]), 9)
-        order = np.lexsort((np.arange(ne), ang, -length))
+        order = np.lexsort((np.arange(ne), ang, -length if HYPOTENUSE_FIRST else length))
         col = -np.ones(ne, dtype=np.int64)
         for e in order:
             used = {col[n] for n in nbrs[e] if col[n] >= 0}

@@ -217,6 +217,11 @@ class BlockDiagMPI(LinearOperatorMPI):
     cache lines of every row and each streams the matrices once more.  The K
     applies of S gain because they are whole, independent slabs."""
     two_streams = False
+    # (EllMatrices plan, index of the middle matrix in it) or None: the caller may
+    # name the packed plan that holds the middle factor of its C A C blocks
+    # (heateq_mpi.HeatEquationMPI does: A_x is matrix 1 of the (M_x, A_x) plan)
+    mid_packed = None
+    pack_mid = True
 
     def __init__(self, dofs_distr, matrices_space):
         M = matrices_space[0].shape[0]
@@ -287,7 +292,20 @@ class BlockDiagMPI(LinearOperatorMPI):
                 main.wait_stream(side)
             else:
                 t1 = fam.apply(vec_in.buf, n_loc=n_loc, cm=cm, kind=kind)
-                t2 = mid.apply(t1, n_loc=n_loc)
+                packed = None
+                if self.mid_packed is not None and type(self).pack_mid:
+                    packed = self.mid_packed[0].packed_for(n_loc)
+                if packed is not None and packed.ok and packed.rows_per_unit == 2:
+                    # I kron A_x on the packed slot stream S and the metric's operator
+                    # share (4 bytes per slot instead of 12), where that stream serves
+                    # row PAIRS (5 gathers per row, as many as A_x's own rows have; the
+                    # one-row form gathers the union pattern's 7: 0.085 against 0.058 ms
+                    # on 9-step slabs, profiles/r04_b_launches_by_grid_J3_J9.txt)
+                    t2 = torch.empty_like(t1)
+                    packed.apply([(None, self.mid_packed[1])], t1, None, n_loc,
+                                 vec_in.ld, 0.0, t2)
+                else:
+                    t2 = mid.apply(t1, n_loc=n_loc)
                 fam.apply(t2, out=vec_out.buf, n_loc=n_loc, cm=cm, kind=kind)
         else:
             # general case: the time slices of every distinct operator object

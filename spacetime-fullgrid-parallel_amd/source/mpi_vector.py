@@ -246,6 +246,9 @@ class KronVectorMPI:
         self.rank = dofs_distr.rank
         self.n_loc = self.t_end - self.t_begin
         # even leading dimension: time pairs are 16-byte aligned (include/stk.h)
+        # (rows padded to 128 bytes -- ld = 16 for the 9-step slabs of an 8-rank run --
+        # were measured and lose: S 3.05 -> 4.44 ms, P 5.69 -> 7.21 ms,
+        # profiles/r04_b_op_J3_J9_ld16.log; the bytes count, not the alignment)
         self.ld = self.n_loc + (self.n_loc & 1)
         self._pending = None
 

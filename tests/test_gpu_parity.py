@@ -4,8 +4,9 @@ against the CPU oracle.  Needs an MI355X.
 
 Tolerance: the north star asks for 1e-10 relative on residuals; single applies
 are held to 1e-12 here (they differ from the reference only by the order of
-floating-point additions), whole solves to 1e-8 on the iterates and exact
-equality on iteration counts."""
+floating-point additions), whole solves in the default arithmetic to 1e-10 on
+every r.Pr entry and on the iterates, and to exact equality on iteration
+counts; the opt-in arithmetic='fast' to 1e-9 per entry (it measures 4.6e-10)."""
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -441,15 +442,15 @@ def test_direct_preconditioner_matches_reference_golden(stk, g3):
     P = BlockDiagMPI(dd, [CAC[j] for j in W.levels])
     WT_S_W = CompositeMPI(dd, [WT, S, W])
     x = _vec(dd, g3['X'])
-    assert relerr(_np(S @ x), g3['S_direct']) < 1e-9
-    assert relerr(_np(P @ x), g3['P_direct']) < 1e-9
-    assert relerr(_np(WT_S_W @ x), g3['WTSW_direct']) < 1e-9
+    assert relerr(_np(S @ x), g3['S_direct']) < 1e-10
+    assert relerr(_np(P @ x), g3['P_direct']) < 1e-10
+    assert relerr(_np(WT_S_W @ x), g3['WTSW_direct']) < 1e-10
     rr = []
     w, iters = PCG(WT_S_W, P, _vec(dd, g3['rhs']),
                    callback=lambda w, r, k: rr.append(r.dot(r)))
     assert iters == int(g3['pcg_iters_direct'])
     _hist_dev('golden_%d_%d_direct_rr' % (N, M), rr, g3['pcg_rr_direct'], 1e-10)
-    assert relerr(_np(w), g3['pcg_w_direct']) < 1e-9
+    assert relerr(_np(w), g3['pcg_w_direct']) < 1e-10
 
 
 def test_mat_kron_identity_and_original_wavelet_mode(stk):
@@ -505,10 +506,10 @@ def test_midsize_solve_matches_oracle_fixture(stk):
     hist = []
     w, it = PCG(h.WT_S_W, h.P, h.rhs, history=hist)
     assert it == int(g['iters'])
-    assert _record_history_dev('square_J5_J6', hist, g['hist']) < HIST_RTOL
+    assert _record_history_dev('square_J5_J6', hist, g['hist']) < HIST_RTOL_REFERENCE  # the default arithmetic
     wn = _np(w)
     assert abs(np.linalg.norm(wn) - g['w_norm']) < 1e-10 * g['w_norm']
-    assert relerr(wn[::st, ::sx], g['w_sample']) < 1e-9
+    assert relerr(wn[::st, ::sx], g['w_sample']) < 1e-10
 
 
 def test_wide_slab_addressing_matches(stk):
@@ -584,7 +585,7 @@ def test_coarse_subcycle_variants_agree(stk):
 # stores R M P and R A P once and combines them per time slice (exactly the
 # assembled entries on the finest level, one rounding apart on the coarse ones),
 # and the conditioning of the level problems turns that ulp into 1e-11.
-HIST_RTOL = 1e-9              # fast default: twice the largest deviation measured (4.6e-10)
+HIST_RTOL = 1e-9              # arithmetic='fast' (opt-in): twice the largest deviation measured (4.6e-10)
 HIST_RTOL_REFERENCE = 1e-10   # arithmetic='reference' and 'accurate': the north star's bound, per entry
 HIST_RTOL_VS_INITIAL = 1e-10
 
@@ -718,12 +719,14 @@ def test_baseline_configs_full_size_against_oracle(stk, problem, J_space, J_time
     assert all(b < a for a, b in zip(hist, hist[1:]))
     if (problem, J_space, J_time) == ('square', 10, 7):
         # config 5 has an oracle fixture for the HEAD of the trajectory (the first
-        # three r.Pr and the iterate after two iterations; tests/golden/
-        # make_oracle_vectors.py --lean --kmax 3: 21 minutes and 35 GB on the host)
+        # six r.Pr and the iterate after five iterations; tests/golden/
+        # make_oracle_vectors.py --lean --kmax 6 on the host)
         # and for S, P, W of the bench's vector on the fixture's sample
         g = load_golden('o1_pcg_square_J7_J10')
         st, sx = (int(v) for v in g['sample_strides'])
-        _hist_dev('config5_head_fast', hist[:3], g['hist'][:3], 1e-9)
+        head = len(g['hist'])
+        assert head == int(g['kmax']) >= 6
+        _hist_dev('config5_head_accurate', hist[:head], g['hist'], 1e-10)  # the default arithmetic
         del w
         xb = _vec(dd, _bench_vector(N, M))
         assert relerr(_np(h.W @ xb)[::st, ::sx], g['WX_sample']) < 1e-13
@@ -732,11 +735,11 @@ def test_baseline_configs_full_size_against_oracle(stk, problem, J_space, J_time
         del xb, h
         torch.cuda.empty_cache()
         # the reference-arithmetic mode on the same head: 1e-10 per entry, and the
-        # iterate after the oracle's two iterations
+        # iterate after the oracle's iterations
         h = hm.HeatEquationMPI(J_space=J_space, J_time=J_time, problem=problem, arithmetic='reference')
         hist = []
-        w, iters = PCG(h.WT_S_W, h.P, h.rhs, kmax=3, history=hist)
-        assert iters == int(g['iters']) == 2
+        w, iters = PCG(h.WT_S_W, h.P, h.rhs, kmax=head, history=hist)
+        assert iters == int(g['iters']) == head - 1
         _hist_dev('config5_head_reference_arithmetic', hist, g['hist'], 1e-10)
         wn = _np(w)
         assert abs(np.linalg.norm(wn) - g['w_norm']) < 1e-10 * g['w_norm']
@@ -808,7 +811,7 @@ def test_serial_driver_against_oracle(stk, precond):
     wo, iters_o, hist_o = pcg(o.WT_S_W, o.P, o.WT(o.f()))
     assert iters == iters_o
     _hist_dev('serial_driver_%s' % precond, hist, hist_o, 1e-10)
-    assert relerr(w, wo) < 1e-9
+    assert relerr(w, wo) < 1e-10
     # the parallel driver builds the same Schur complement from five terms
     hp = hm.HeatEquationMPI(J_space=J_space, J_time=J_time, precond=precond)
     xv = _vec(hp.dofs_distr, x.reshape(h.N, h.M))

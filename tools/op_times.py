@@ -28,7 +28,7 @@ ap.add_argument('--fuse-restrict', type=int, default=1)
 ap.add_argument('--zero-start', type=int, default=1)
 ap.add_argument('--arithmetic', default='accurate', help="HeatEquationMPI's arithmetic mode (accurate = the default, fast, reference)")
 ap.add_argument('--tune', default='', help='extra stk_set_tuning keys: key=value,...')
-ap.add_argument('--only', default='', help='comma-separated subset of the rows (W,WT,S,P,Kinv,A_x,axpy,dot)')
+ap.add_argument('--only', default='', help='comma-separated subset of the rows (W,WT,S,P,Kinv,A_x,A_x_packed,axpy,dot)')
 ap.add_argument('--wavelettransform', default=None, help="HeatEquationMPI's wavelet mode (composite, original, interleaved)")
 args = ap.parse_args()
 from source import _lib  # noqa: E402
@@ -66,10 +66,13 @@ rows = [('W', lambda: h.W @ x, 2), ('WT', lambda: h.WT @ x, 2), ('S', lambda: h.
         ('P', lambda: h.P @ x, None), ('Kinv', lambda: h.Kinv_x.apply(x.buf, n_loc=x.n_loc), None),
         ('A_x', lambda: h.CAC_j[0].linops[1].apply(x.buf, n_loc=x.n_loc), 2),
         ('axpy', lambda: y.__iadd__(0.5 * x), 3), ('dot', lambda: x.dot(y), 2)]
+if getattr(h.S, 'ell', None) is not None and h.S.ell.packed_for(x.n_loc).ok:
+    pk, out_ = h.S.ell.packed_for(x.n_loc), torch.empty_like(x.buf)
+    rows.insert(6, ('A_x_packed', lambda: pk.apply([(None, 1)], x.buf, None, x.n_loc, x.ld, 0.0, out_), 2))
 only = set(filter(None, args.only.split(',')))
 for name, fn, passes in rows:
     if only and name not in only:
         continue
     ms = timeit(fn)
     extra = '' if passes is None else '  %.0f GB/s (%d vector passes)' % (passes * nb / ms / 1e6, passes)
-    print('%-5s %9.3f ms%s' % (name, ms, extra))
+    print('%-10s %9.3f ms%s' % (name, ms, extra))
