@@ -11,6 +11,18 @@
 //
 // The arithmetic of a job is that of rows_ell.hip (same sliced-ELL matrices,
 // same summation order), so results are identical to the level-by-level path.
+//
+// Round 4, the UNIFORM form (mg_coarse_uniform_kernel): a job costs ~1.5 us whatever
+// its rows (220 us for the 141 jobs of the preconditioner family's sub-V-cycle, 124 us
+// for K's 81) -- two dependent trips to the L2 per job, the descriptor and then the
+// matrix entries of the rows.  All matrices of the job list are therefore copied once,
+// at plan construction, to ONE slot count KU (8 or 12; zero-valued slots appended: an
+// added slot contributes fma(0, x, s) = s, results unchanged bit for bit), the job
+// descriptors travel to LDS when the kernel starts, and every thread fetches the
+// entries of its first row of job n + 1 BEFORE the barrier that ends job n.
+#include <algorithm>
+#include <map>
+#include <tuple>
 #include <vector>
 
 #include "stk_common.h"
@@ -336,10 +348,224 @@ __global__ __launch_bounds__(CBS) void mg_coarse_kernel(const CoarseArgs a)
     }
 }
 
+// ---- the uniform form ---------------------------------------------------------
+struct CJob {  // 48 bytes, copied to LDS
+    int32_t kind, n_rows;
+    int32_t lx, lz, ly;
+    int32_t flags;  // bit 0: level matrix (ca*va + cm*vm), bit 1: diagonal-free Gauss-Seidel rows
+    uint32_t mat_off;  // first row of the job in the uniform arrays
+    int32_t pad;
+    double alpha, beta;
+};
+
+struct UniArgs {
+    const CJob *jobs;
+    const int32_t *idx;    // [rows][KU]
+    const double *va, *vm; // [rows][KU]
+    const double *dia_a, *dia_m;  // [rows]
+    const int32_t *row;    // [rows] output row of every listed row
+};
+
+__global__ void repack_uniform_kernel(int n_rows, int K_src, int KU, const int32_t *__restrict__ idx,
+                                      const double *__restrict__ va, const double *__restrict__ vm,
+                                      const int32_t *__restrict__ row_ids, const double *__restrict__ dia_a,
+                                      const double *__restrict__ dia_m, int pos_begin, uint32_t mat_off, int32_t *o_idx,
+                                      double *o_va, double *o_vm, double *o_da, double *o_dm, int32_t *o_row)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_rows * KU) return;
+    const int r = t / KU, u = t - r * KU;
+    const size_t src = (size_t)(pos_begin + r) * K_src, dst = (size_t)(mat_off + r) * KU + u;
+    // appended slots: the column of slot 0 (read anyway), value zero
+    o_idx[dst] = idx[src + (u < K_src ? u : 0)];
+    o_va[dst] = u < K_src ? va[src + u] : 0.0;
+    if (o_vm) o_vm[dst] = (vm && u < K_src) ? vm[src + u] : 0.0;
+    if (u == 0) {
+        o_row[mat_off + r] = row_ids ? row_ids[pos_begin + r] : pos_begin + r;
+        o_da[mat_off + r] = dia_a ? dia_a[pos_begin + r] : 0.0;
+        if (o_dm) o_dm[mat_off + r] = dia_m ? dia_m[pos_begin + r] : 0.0;
+    }
+}
+
+template <int KU, bool HAS_M, bool PAIR, int UBS>
+__global__ __launch_bounds__(UBS) void mg_coarse_uniform_kernel(const CoarseArgs a, const UniArgs m)
+{
+    typedef TimeElem<PAIR> E;
+    typedef typename E::type V;
+    extern __shared__ double sm_raw[];
+    V *sv = reinterpret_cast<V *>(sm_raw);
+    CJob *s_jobs = reinterpret_cast<CJob *>(sv + a.lds_rows);
+    const int tid = threadIdx.x;
+    const int t0 = (PAIR ? 2 : 1) * (int)blockIdx.x;
+    const bool has1 = PAIR && t0 + 1 < a.n_loc;
+    double cm0 = 0.0, cm1 = 0.0;
+    if (HAS_M) {
+        cm0 = a.cm[t0];
+        if (has1) cm1 = a.cm[t0 + 1];
+    }
+    {
+        const int4 *src = reinterpret_cast<const int4 *>(m.jobs);
+        int4 *dst = reinterpret_cast<int4 *>(s_jobs);
+        for (int i = tid; i < a.n_jobs * (int)(sizeof(CJob) / 16); i += UBS) dst[i] = src[i];
+    }
+    for (int r = tid; r < a.top_n; r += UBS) {
+        const double *p = a.top_f + (size_t)r * a.ld + t0;
+        if constexpr (PAIR)
+            sv[a.top_lf + r] = *reinterpret_cast<const double2 *>(p);
+        else
+            sv[a.top_lf + r] = *p;
+        sv[a.top_lu + r] = E::make(0.0, 0.0);  // MGM starts from zero (multigrid.py:176)
+    }
+    // Entries of one listed row, in registers.  TWO sets take turns: set A serves the
+    // even jobs, set B the odd ones, and a set is refilled for job n + 2 as soon as job
+    // n is through with it -- the entries then have a whole job and two barriers to
+    // arrive (one job ahead they would be needed right behind the barrier: the first
+    // thing a job does is gather at its columns).
+    struct RowRegs {
+        int32_t col[KU];
+        double va[KU], vm[KU];
+        double da, dm;
+        int32_t orow;
+    };
+    auto load_row = [&](const CJob &j, int r, RowRegs &S) {
+        const size_t row = (size_t)j.mat_off + r, e0 = row * KU;
+        const int4 *pi = reinterpret_cast<const int4 *>(m.idx + e0);
+#pragma unroll
+        for (int q = 0; q < KU / 4; ++q) {
+            const int4 v = pi[q];
+            S.col[4 * q] = v.x, S.col[4 * q + 1] = v.y, S.col[4 * q + 2] = v.z, S.col[4 * q + 3] = v.w;
+        }
+        const double2 *pa = reinterpret_cast<const double2 *>(m.va + e0);
+#pragma unroll
+        for (int q = 0; q < KU / 2; ++q) {
+            const double2 v = pa[q];
+            S.va[2 * q] = v.x, S.va[2 * q + 1] = v.y;
+        }
+        if (HAS_M && (j.flags & 1)) {
+            const double2 *pm = reinterpret_cast<const double2 *>(m.vm + e0);
+#pragma unroll
+            for (int q = 0; q < KU / 2; ++q) {
+                const double2 v = pm[q];
+                S.vm[2 * q] = v.x, S.vm[2 * q + 1] = v.y;
+            }
+        }
+        if (j.kind == JOB_GS) {
+            S.da = m.dia_a[row];
+            if (HAS_M && (j.flags & 1)) S.dm = m.dia_m[row];
+        }
+        S.orow = m.row[row];
+    };
+    // the first row of a thread in job jn, if that is a row job
+    auto fetch = [&](int jn, RowRegs &S) {
+        if (jn < a.n_jobs) {
+            const CJob nj = s_jobs[jn];
+            if ((nj.kind == JOB_SPMM || nj.kind == JOB_GS) && tid < nj.n_rows) load_row(nj, tid, S);
+        }
+    };
+    auto row_update = [&](const CJob &j, const RowRegs &S) {
+        const bool use_m = HAS_M && (j.flags & 1);
+        const bool diag_free = (j.flags & 2) != 0;
+        const double ca = (j.flags & 1) ? a.ca : 1.0;
+        const V *vx = sv + j.lx;
+        V xv[KU];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) xv[u] = vx[S.col[u]];
+        V zv = E::make(0.0, 0.0), own = E::make(0.0, 0.0);
+        if (j.kind == JOB_GS) {
+            zv = sv[j.lz + S.orow];
+            if (!diag_free) own = vx[S.orow];
+        } else if (j.beta != 0.0) {
+            zv = sv[j.lz + S.orow];
+        }
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            double v0 = ca * S.va[u], v1 = v0;
+            if (use_m) {
+                v0 = fma(cm0, S.vm[u], v0);
+                if (PAIR) v1 = fma(cm1, S.vm[u], v1);
+            }
+            s0 = fma(v0, E::lo(xv[u]), s0);
+            if (PAIR) s1 = fma(v1, E::hi(xv[u]), s1);
+        }
+        double o0, o1 = 0.0;
+        if (j.kind == JOB_GS) {
+            double d0 = ca * S.da, d1 = d0;
+            if (use_m) {
+                d0 = fma(cm0, S.dm, d0);
+                if (PAIR) d1 = fma(cm1, S.dm, d1);
+            }
+            o0 = E::lo(own) + (1.0 / d0) * (E::lo(zv) - s0);
+            if (PAIR) o1 = E::hi(own) + (1.0 / d1) * (E::hi(zv) - s1);
+        } else {
+            o0 = j.alpha * s0;
+            if (PAIR) o1 = j.alpha * s1;
+            if (j.beta != 0.0) {
+                o0 = fma(j.beta, E::lo(zv), o0);
+                if (PAIR) o1 = fma(j.beta, E::hi(zv), o1);
+            }
+        }
+        if (!has1) o1 = 0.0;  // padding slot stays zero
+        sv[j.ly + S.orow] = E::make(o0, o1);
+    };
+    // One job; S holds this thread's first row of it and is refilled for job jn + 2.
+    // The barrier is LDS-only: __syncthreads() would wait for the loads in flight (its
+    // fence covers global memory, vmcnt(0)), which is why a prefetch in front of it
+    // gains nothing; the jobs exchange data through LDS alone -- global memory is
+    // read-only until the final store of the top level.
+    auto run_job = [&](int jn, RowRegs &S) {
+        const CJob j = s_jobs[jn];
+        if (j.kind == JOB_ZERO) {
+            for (int r = tid; r < j.n_rows; r += UBS) sv[j.ly + r] = E::make(0.0, 0.0);
+        } else if (j.kind == JOB_COARSE) {
+            const int n0 = j.n_rows;
+            for (int i = tid; i < n0; i += UBS) {
+                const double *A0 = a.coarse_inv + (size_t)(a.kind ? a.kind[t0] : 0) * n0 * n0 + (size_t)i * n0;
+                const double *A1 =
+                    a.coarse_inv + (size_t)((a.kind && has1) ? a.kind[t0 + 1] : 0) * n0 * n0 + (size_t)i * n0;
+                double s0 = 0.0, s1 = 0.0;
+                for (int c = 0; c < n0; ++c) {
+                    const V fv = sv[j.lz + c];
+                    s0 = fma(A0[c], E::lo(fv), s0);
+                    if (PAIR) s1 = fma(A1[c], E::hi(fv), s1);
+                }
+                sv[j.ly + i] = E::make(a.coarse_scale * s0, has1 ? a.coarse_scale * s1 : 0.0);
+            }
+        } else {
+            if (tid < j.n_rows) row_update(j, S);
+            for (int r = tid + UBS; r < j.n_rows; r += UBS) {  // further rows: fetched on the spot
+                RowRegs T;
+                load_row(j, r, T);
+                row_update(j, T);
+            }
+        }
+        fetch(jn + 2, S);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    __syncthreads();
+    RowRegs A, B;
+    fetch(0, A);
+    fetch(1, B);
+    for (int jn = 0; jn < a.n_jobs; jn += 2) {
+        run_job(jn, A);
+        if (jn + 1 < a.n_jobs) run_job(jn + 1, B);
+    }
+    for (int r = tid; r < a.top_n; r += UBS) {
+        double *dst = a.top_u + (size_t)r * a.ld + t0;
+        if constexpr (PAIR)
+            *reinterpret_cast<double2 *>(dst) = sv[a.top_lu + r];
+        else
+            *dst = sv[a.top_lu + r];
+    }
+    if (!PAIR && blockIdx.x == 0 && (a.n_loc & 1))
+        for (int r = tid; r < a.top_n; r += UBS) a.top_u[(size_t)r * a.ld + a.n_loc] = 0.0;
+}
+
 }  // namespace
 
 int g_mg_coarse_pairs = 0;  // time pairs per workgroup (0 = default: 1, vectors resident in LDS)
 int g_mg_coarse_lds = 1;    // 0: keep the level vectors in global memory
+int g_mg_coarse_uniform = 1;  // 0: the LDS variant on the levels' own ELL copies (per-job slot counts)
 
 // Host side: the job list of MGM(Lc, u_Lc, f_Lc) and its launcher (used by mg.hip).
 struct stk_coarse_plan {
@@ -350,12 +576,21 @@ struct stk_coarse_plan {
     int lds_rows = 0, top_n = 0, top_lu = 0, top_lf = 0;
     const double *top_f = nullptr;
     double *top_u = nullptr;
+    // the uniform form: every matrix of the job list at KU slots per row (0: none)
+    int KU = 0;
+    bool uni_has_m = false;
+    CJob *dev_cjobs = nullptr;
+    int32_t *u_idx = nullptr, *u_row = nullptr;
+    double *u_va = nullptr, *u_vm = nullptr, *u_da = nullptr, *u_dm = nullptr;
 };
 
 void stk_coarse_plan_free(stk_coarse_plan *p)
 {
     if (!p) return;
     if (p->dev_jobs) (void)hipFree(p->dev_jobs);
+    for (void *q : {(void *)p->dev_cjobs, (void *)p->u_idx, (void *)p->u_row, (void *)p->u_va, (void *)p->u_vm,
+                    (void *)p->u_da, (void *)p->u_dm})
+        if (q) (void)hipFree(q);
     delete p;
 }
 
@@ -382,6 +617,80 @@ static Job rows_job(int kind, const stk_ell_rows &e, int pos_begin, int pos_end,
     j.use_m = level_matrix ? 1 : 0;
     j.lx = j.lz = j.ly = -1;
     return j;
+}
+
+// The uniform copies of the job list's matrices (see the head of the file).  Leaves
+// p->KU = 0 when a row is longer than 12 slots or an allocation fails.
+static void build_uniform(stk_coarse_plan *p)
+{
+    const std::vector<Job> &J = p->host_jobs;
+    int kmax = 0;
+    bool has_m = false;
+    for (const Job &j : J)
+        if (j.kind == JOB_SPMM || j.kind == JOB_GS) {
+            kmax = std::max(kmax, (int)j.K);
+            has_m = has_m || (j.use_m && j.vm != nullptr);
+        }
+    const int KU = kmax <= 8 ? 8 : (kmax <= 12 ? 12 : 0);
+    if (KU == 0 || sizeof(CJob) != 48) return;
+    // one copy per distinct (matrix, position range)
+    std::map<std::tuple<const int32_t *, int, int>, uint32_t> where;
+    std::vector<CJob> cj(J.size());
+    uint32_t total = 0;
+    for (size_t n = 0; n < J.size(); ++n) {
+        const Job &j = J[n];
+        CJob &c = cj[n];
+        c.kind = j.kind;
+        c.lx = j.lx, c.lz = j.lz, c.ly = j.ly;
+        c.flags = (j.use_m ? 1 : 0) | (j.diag_free ? 2 : 0);
+        c.alpha = j.alpha, c.beta = j.beta;
+        c.pad = 0;
+        c.mat_off = 0;
+        if (j.kind == JOB_SPMM || j.kind == JOB_GS) {
+            c.n_rows = j.pos_end - j.pos_begin;
+            const auto key = std::make_tuple(j.idx, (int)j.pos_begin, (int)j.pos_end);
+            auto it = where.find(key);
+            if (it == where.end()) {
+                it = where.emplace(key, total).first;
+                total += (uint32_t)c.n_rows;
+            }
+            c.mat_off = it->second;
+        } else {
+            c.n_rows = j.pos_end;
+        }
+    }
+    if (total == 0) return;
+    bool ok = hipMalloc((void **)&p->u_idx, sizeof(int32_t) * (size_t)total * KU) == hipSuccess &&
+              hipMalloc((void **)&p->u_va, sizeof(double) * (size_t)total * KU) == hipSuccess &&
+              hipMalloc((void **)&p->u_da, sizeof(double) * (size_t)total) == hipSuccess &&
+              hipMalloc((void **)&p->u_row, sizeof(int32_t) * (size_t)total) == hipSuccess &&
+              hipMalloc((void **)&p->dev_cjobs, sizeof(CJob) * cj.size()) == hipSuccess;
+    if (ok && has_m)
+        ok = hipMalloc((void **)&p->u_vm, sizeof(double) * (size_t)total * KU) == hipSuccess &&
+             hipMalloc((void **)&p->u_dm, sizeof(double) * (size_t)total) == hipSuccess;
+    if (ok) ok = hipMemcpy(p->dev_cjobs, cj.data(), sizeof(CJob) * cj.size(), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        std::map<std::tuple<const int32_t *, int, int>, bool> done;
+        for (const Job &j : J) {
+            if (j.kind != JOB_SPMM && j.kind != JOB_GS) continue;
+            const auto key = std::make_tuple(j.idx, (int)j.pos_begin, (int)j.pos_end);
+            if (done[key]) continue;
+            done[key] = true;
+            const int rows = j.pos_end - j.pos_begin;
+            if (rows <= 0) continue;
+            const int threads = rows * KU;
+            hipLaunchKernelGGL(repack_uniform_kernel, dim3((threads + 255) / 256), dim3(256), 0, 0, rows, (int)j.K, KU,
+                               j.idx, j.va, j.vm, j.row_ids, j.dia_a, j.dia_m, (int)j.pos_begin, where[key], p->u_idx,
+                               p->u_va, p->u_vm, p->u_da, p->u_dm, p->u_row);
+        }
+        ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+    }
+    if (!ok) {
+        (void)hipGetLastError();
+        return;  // KU stays 0: the per-job form runs
+    }
+    p->KU = KU;
+    p->uni_has_m = has_m;
 }
 
 stk_coarse_plan *stk_coarse_plan_build(const stk_coarse_level *lv, int Lc, int smoothsteps)
@@ -470,6 +779,7 @@ stk_coarse_plan *stk_coarse_plan_build(const stk_coarse_level *lv, int Lc, int s
         stk_coarse_plan_free(p);
         return nullptr;
     }
+    build_uniform(p);  // optional: the plan works without it
     return p;
 }
 
@@ -479,6 +789,46 @@ stk_coarse_plan *stk_coarse_plan_build(const stk_coarse_level *lv, int Lc, int s
 bool stk_coarse_plan_in_lds(const stk_coarse_plan *p)
 {
     return g_mg_coarse_lds && g_mg_coarse_pairs <= 1 && sizeof(double) * (size_t)p->lds_rows <= 144 * 1024;
+}
+
+template <int KU, bool HAS_M, bool PAIR, int UBS>
+static int launch_uniform_one(dim3 grid, size_t lds, hipStream_t st, const CoarseArgs &a, const UniArgs &m)
+{
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+        STK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mg_coarse_uniform_kernel<KU, HAS_M, PAIR, UBS>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((mg_coarse_uniform_kernel<KU, HAS_M, PAIR, UBS>), grid, dim3(UBS), lds, st, a, m);
+    STK_LAUNCH_CHECK();
+    return 0;
+}
+
+// 1024 threads per time step where the registers allow: a level-5 job is then one or
+// four rows per thread instead of two or eight.
+extern int g_mg_coarse_uniform;
+static int launch_uniform(int KU, bool has_m, bool pair, dim3 grid, size_t lds, hipStream_t st, const CoarseArgs &a,
+                          const UniArgs &m)
+{
+    if (KU == 8) {
+        if (g_mg_coarse_uniform == 2) {  // A/B: 512 threads throughout
+            if (has_m) return pair ? launch_uniform_one<8, true, true, 512>(grid, lds, st, a, m)
+                                   : launch_uniform_one<8, true, false, 512>(grid, lds, st, a, m);
+            return pair ? launch_uniform_one<8, false, true, 512>(grid, lds, st, a, m)
+                        : launch_uniform_one<8, false, false, 512>(grid, lds, st, a, m);
+        }
+        // (with the second value array two register sets of 8 slots do not fit the 128
+        // registers a 1024-thread workgroup leaves a thread)
+        if (has_m) return pair ? launch_uniform_one<8, true, true, 512>(grid, lds, st, a, m)
+                               : launch_uniform_one<8, true, false, 512>(grid, lds, st, a, m);
+        return pair ? launch_uniform_one<8, false, true, 512>(grid, lds, st, a, m)
+                    : launch_uniform_one<8, false, false, 1024>(grid, lds, st, a, m);
+    }
+    if (has_m) return pair ? launch_uniform_one<12, true, true, 512>(grid, lds, st, a, m)
+                           : launch_uniform_one<12, true, false, 512>(grid, lds, st, a, m);
+    return pair ? launch_uniform_one<12, false, true, 512>(grid, lds, st, a, m)
+                : launch_uniform_one<12, false, false, 512>(grid, lds, st, a, m);
 }
 
 int stk_coarse_plan_run(const stk_coarse_plan *p, hipStream_t st, int n_loc, int ld, double ca, const double *cm,
@@ -522,6 +872,18 @@ int stk_coarse_plan_run(const stk_coarse_plan *p, hipStream_t st, int n_loc, int
         const bool pair = lds_pair <= lds_max;
         const dim3 grid(pair ? all_pairs : n_loc);
         const size_t lds = pair ? lds_pair : lds_one;
+        if (g_mg_coarse_uniform && p->KU != 0 && (!cm || p->uni_has_m)) {
+            UniArgs m;
+            m.jobs = p->dev_cjobs;
+            m.idx = p->u_idx;
+            m.va = p->u_va;
+            m.vm = p->u_vm;
+            m.dia_a = p->u_da;
+            m.dia_m = p->u_dm;
+            m.row = p->u_row;
+            const size_t lds_u = lds + sizeof(CJob) * (size_t)p->n_jobs;
+            if (lds_u <= 160 * 1024 - 512) return launch_uniform(p->KU, cm != nullptr, pair, grid, lds_u, st, a, m);
+        }
         if (cm && pair)
             hipLaunchKernelGGL((mg_coarse_lds_kernel<true, true>), grid, dim3(CBS), lds, st, a);
         else if (cm)

@@ -181,6 +181,9 @@ def union_pattern(mats):
             m.sort_indices()
         m.sum_duplicates()
     assert len(mats) <= 30
+    if len(mats) == 1:  # nothing to unite
+        m = mats[0]
+        return m.indptr.astype(np.int32), m.indices.astype(np.int32), [np.asarray(m.data, dtype=np.float64)]
     pat = None
     for k, m in enumerate(mats):
         own = sp.csr_matrix((np.full(m.nnz, float(1 << k)), m.indices, m.indptr),

@@ -220,8 +220,12 @@ class BlockDiagMPI(LinearOperatorMPI):
     # (EllMatrices plan, index of the middle matrix in it) or None: the caller may
     # name the packed plan that holds the middle factor of its C A C blocks
     # (heateq_mpi.HeatEquationMPI does: A_x is matrix 1 of the (M_x, A_x) plan)
+    # MEASURED and left off (profiles/r04_c_op_J6_J9_*.log, r04_b_launches_by_grid_J3_J9.txt):
+    # the one-term packed pass is SLOWER than the row engine's own 5-slot copy of A_x,
+    # 0.374 against 0.301 ms on 65-step slabs (row pairs: 10 gathers per two rows, half
+    # of them for columns only M_x has), 0.085 against 0.058 ms on 9-step slabs.
     mid_packed = None
-    pack_mid = True
+    pack_mid = False
 
     def __init__(self, dofs_distr, matrices_space):
         M = matrices_space[0].shape[0]

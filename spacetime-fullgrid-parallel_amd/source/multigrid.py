@@ -47,6 +47,46 @@ class MeshHierarchy:
         self.P_mats = [sp.csr_matrix(P) for P in P_mats]
         self.R_mats = [P.T.tocsr() for P in self.P_mats]
         self.J = len(self.P_mats)
+        # what several plans on this hierarchy need alike (K's and the preconditioner
+        # family's are built side by side): computed once, by whoever asks first
+        self._shared, self._shared_lock = {}, threading.Lock()
+
+    def shared(self, key, make):
+        """make() once per key for all plans built on this hierarchy (row orders,
+        transfer operators on the device: they depend on the mesh alone)."""
+        with self._shared_lock:
+            slot = self._shared.get(key)
+            if slot is None:
+                slot = self._shared[key] = {'lock': threading.Lock()}
+        with slot['lock']:  # a second asker waits for the first one's result
+            if 'value' not in slot:
+                slot['value'] = make()
+        return slot['value']
+
+    def tile_order(self, n):
+        """Mesh-tile processing order of the first n dofs (index order without
+        coordinates)."""
+        if self.coords is None:
+            return np.arange(n, dtype=np.int32)
+        return self.shared(('tile', n), lambda: tile_order_from_coords(self.coords[:n]))
+
+
+def _tile_order(hierarchy, n):
+    """Processing order of the first n dofs of a hierarchy (any object with P_mats /
+    R_mats / coords; a MeshHierarchy computes every order once for all its plans)."""
+    if hasattr(hierarchy, 'tile_order'):
+        return hierarchy.tile_order(n)
+    coords = getattr(hierarchy, 'coords', None)
+    return np.arange(n, dtype=np.int32) if coords is None else tile_order_from_coords(coords[:n])
+
+
+def _shared(hierarchy, key, make):
+    return hierarchy.shared(key, make) if hasattr(hierarchy, 'shared') else make()
+
+
+def _mat_key(mat):
+    """Identity of a CSR matrix by its arrays (sp.csr_matrix(m) wraps, it does not copy)."""
+    return (mat.indptr.ctypes.data, mat.indices.ctypes.data, mat.data.ctypes.data, mat.nnz)
 
 
 def _drop_roundoff(mat, rel=1e-14):
@@ -166,7 +206,7 @@ def _groups_by_depth(depth, n, backward):
     return ptr, order.astype(np.int32)
 
 
-def coupling_bands(coords, indptr, indices):
+def coupling_bands(coords, indptr, indices, rows_of=None):
     """A band index per row such that two coupled rows always lie in the same
     or in adjacent bands -- the property the strip-wise Gauss-Seidel sweep of
     csrc/mg.hip rests on -- with bands as thin as that allows.  The property is
@@ -178,7 +218,8 @@ def coupling_bands(coords, indptr, indices):
     n = len(indptr) - 1
     if n < 2:
         return None
-    rows_of = np.repeat(np.arange(n), np.diff(indptr))
+    if rows_of is None:
+        rows_of = np.repeat(np.arange(n), np.diff(indptr))
 
     def ok(b):
         return len(indices) == 0 or np.abs(b[rows_of] - b[indices]).max() <= 1
@@ -231,15 +272,24 @@ class _DeviceHierarchy:
         self.J = hierarchy.J
         self.smoothsteps, self.vcycles = smoothsteps, vcycles
         self.has_m = mat_m is not None
-        # Galerkin hierarchies, coarse to fine (reference multigrid.py:142-145)
-        A = [sp.csr_matrix(mat_a)]
-        Mm = [sp.csr_matrix(mat_m)] if self.has_m else None
-        for j in reversed(range(self.J)):
-            R, P = hierarchy.R_mats[j], hierarchy.P_mats[j]
-            held = {}  # device copies of R and P, shared by the two products of the level
-            A.insert(0, _drop_roundoff(galerkin_product(R, A[0], P, held)))
-            if self.has_m:
-                Mm.insert(0, _drop_roundoff(galerkin_product(R, Mm[0], P, held)))
+        # Galerkin hierarchies, coarse to fine (reference multigrid.py:142-145).  The
+        # chain of a matrix is the same whichever plan asks (K's and the family's both
+        # start from A_x): formed once per hierarchy and matrix.
+        def chain(fine):
+            fine = sp.csr_matrix(fine)
+
+            def make():
+                mats = [fine]
+                for j in reversed(range(self.J)):
+                    R, P = hierarchy.R_mats[j], hierarchy.P_mats[j]
+                    held = _shared(hierarchy, ('galerkin_rp', j), dict)  # device copies of R, P
+                    mats.insert(0, _drop_roundoff(galerkin_product(R, mats[0], P, held)))
+                return mats
+
+            return list(_shared(hierarchy, ('galerkin', _mat_key(fine)), make))
+
+        A = chain(mat_a)
+        Mm = chain(mat_m) if self.has_m else None
         self.mats_a, self.mats_m = A, Mm
         self.shape = A[-1].shape
         self._keep = []  # device tensors / host arrays the plan points into
@@ -295,14 +345,11 @@ class _DeviceHierarchy:
         host = {}
         if j > 0:
             # processing order: mesh tiles if coordinates are known
-            if hierarchy.coords is not None:
-                tile = tile_order_from_coords(hierarchy.coords[:n])
-            else:
-                tile = np.arange(n, dtype=np.int32)
+            tile = _tile_order(hierarchy, n)
             rank = np.empty(n, dtype=np.int64)
             rank[tile] = np.arange(n)
             # bands for the strip-wise sweeps: coupled rows at most one band apart
-            band = coupling_bands(hierarchy.coords, indptr, indices)
+            band = coupling_bands(hierarchy.coords, indptr, indices, rows_of)
             key = rank if band is None else band * np.int64(n) + rank
             vm = vals[1] if self.has_m else None
             # transfer operators and the restricted-residual product R A: independent
@@ -380,18 +427,27 @@ class _DeviceHierarchy:
             P = sp.csr_matrix(hierarchy.P_mats[j - 1])
             R = sp.csr_matrix(hierarchy.R_mats[j - 1])
             nc = P.shape[1]
-            if hierarchy.coords is not None:
-                tile_c = tile_order_from_coords(hierarchy.coords[:nc])
+            tile_c = _tile_order(hierarchy, nc)
+
+            def transfer_copies():
+                dev_, ells_ = {}, {}
+                for name, m, order in (('p', P, tile), ('r', R, tile_c)):
+                    m.sort_indices()
+                    dev_[name + '_indptr'] = _lib.to_dev(m.indptr.astype(np.int32))
+                    dev_[name + '_indices'] = _lib.to_dev(m.indices.astype(np.int32))
+                    dev_[name + '_vals'] = _lib.to_dev(m.data.astype(np.float64))
+                    ells_[name] = EllRowsMatrix(m.indptr, m.indices, m.data, None, order)
+                return dev_, ells_
+
+            # P and R and their ELL copies depend on the mesh alone: one set on the
+            # device for all plans of the hierarchy (read-only in every kernel)
+            if hasattr(hierarchy, 'shared'):
+                shared_dev, shared_ells = hierarchy.shared(('transfer', j), transfer_copies)
             else:
-                tile_c = np.arange(nc, dtype=np.int32)
-            dev, ells = {}, {}
-            for name, m, order in (('p', P, tile), ('r', R, tile_c)):
-                m.sort_indices()
-                dev[name + '_indptr'] = _lib.to_dev(m.indptr.astype(np.int32))
-                dev[name + '_indices'] = _lib.to_dev(m.indices.astype(np.int32))
-                dev[name + '_vals'] = _lib.to_dev(m.data.astype(np.float64))
-                ells[name] = EllRowsMatrix(m.indptr, m.indices, m.data, None, order)
-            prods = [_drop_roundoff(galerkin_product(R, m, None)) for m in mats]
+                shared_dev, shared_ells = transfer_copies()
+            dev, ells = dict(shared_dev), dict(shared_ells)
+            prods = [_shared(hierarchy, ('ra', j, _mat_key(m)),
+                             lambda m=m: _drop_roundoff(galerkin_product(R, m, None))) for m in mats]
             ra_ptr, ra_idx, ra_vals = union_pattern(prods)
             out['ra'] = EllRowsMatrix(ra_ptr, ra_idx, ra_vals[0],
                                       ra_vals[1] if self.has_m else None, tile_c)

@@ -541,10 +541,15 @@ def test_wide_slab_addressing_matches(stk):
 def test_coarse_subcycle_variants_agree(stk):
     """The coarse end of the V-cycle runs level by level, as one job-list
     kernel on global workspaces, or as one kernel with all level vectors in LDS
-    (csrc/mg_coarse.hip): same arithmetic in the same order, identical output."""
+    -- on the levels' own ELL copies, or on the uniform copies with the job
+    descriptors in LDS and the next job's rows prefetched, 1024 or 512 threads
+    per time step (csrc/mg_coarse.hip): same arithmetic in the same order,
+    identical output.  The square at J_space = 6 gives a thread several rows of a
+    job; the L-shape has rows of 9 entries (12 slots in the uniform form); the
+    cube's rows are longer than the uniform form takes."""
     import heateq_mpi as hm
     outs = []
-    for problem, J_space in (('square', 5), ('cube', 2)):
+    for problem, J_space in (('square', 5), ('square', 6), ('lshape', 4), ('cube', 2)):
         h = hm.HeatEquationMPI(J_space=J_space, J_time=3, problem=problem)
         X = np.random.RandomState(11).rand(h.N, h.M)
         x = _vec(h.dofs_distr, X)
@@ -554,13 +559,15 @@ def test_coarse_subcycle_variants_agree(stk):
             # residuals through R*A (test_restricted_residual_variants_agree),
             # which the job list does not: compare like with like
             stk.check(stk.lib().stk_set_tuning(b'mg_fuse_restrict', 0))
-            for fuse, lds in ((0, 0), (1, 0), (1, 1)):
+            for fuse, lds, uniform in ((0, 0, 1), (1, 0, 1), (1, 1, 0), (1, 1, 1), (1, 1, 2)):
                 stk.check(stk.lib().stk_set_tuning(b'mg_fuse_coarse', fuse))
                 stk.check(stk.lib().stk_set_tuning(b'mg_coarse_lds', lds))
+                stk.check(stk.lib().stk_set_tuning(b'mg_coarse_uniform', uniform))
                 res.append((_np(h.P @ x), _np(h.S @ x)))
         finally:
             stk.check(stk.lib().stk_set_tuning(b'mg_fuse_coarse', 1))
             stk.check(stk.lib().stk_set_tuning(b'mg_coarse_lds', 1))
+            stk.check(stk.lib().stk_set_tuning(b'mg_coarse_uniform', 1))
             stk.check(stk.lib().stk_set_tuning(b'mg_fuse_restrict', 1))
         for Pv, Sv in res[1:]:
             assert np.array_equal(Pv, res[0][0]) and np.array_equal(Sv, res[0][1])

@@ -9,7 +9,7 @@
 #                             and with 30 iterations, differenced (tools/stats_diff.py)
 #   bench[=args]              bench.py (args with + for spaces)
 #   round                     tools/profile_round.sh <tag>
-#   py=script[,args]          python <script> args (+ for spaces)
+#   py=script[,args]          python <script> args (+ for spaces); pyn=name,script[,args]: log named <tag>_<name>.log
 #   sh=command                any command (+ for spaces)
 set -o pipefail
 tag=$1; shift
@@ -53,6 +53,11 @@ for step in "$@"; do
     py)
       IFS=, read script pargs <<< "$arg"
       log=gpurun_out/${tag}_$(basename ${script%.py}).log
+      timeout -k 10 900 python $script $pargs > $log 2>&1 || { tail -15 $log; exit 1; }
+      tail -25 $log ;;
+    pyn)
+      IFS=, read lname script pargs <<< "$arg"
+      log=gpurun_out/${tag}_${lname}.log
       timeout -k 10 900 python $script $pargs > $log 2>&1 || { tail -15 $log; exit 1; }
       tail -25 $log ;;
     sh)
