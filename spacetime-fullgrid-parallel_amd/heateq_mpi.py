@@ -263,7 +263,9 @@ class HeatEquationMPI:
         # assembly, which runs on the host threads of libstk (no GIL held)
         from concurrent.futures import ThreadPoolExecutor
         u0_x = _Beside(space_load, mesh_space, data['u0'])
-        hierarchy = _Beside(MeshHierarchy, mesh_space)
+        # ... with what every plan on the hierarchy shares (tile orders, candidate
+        # bands, the transfer operators on the device) prepared in the same thread
+        hierarchy = _Beside(_lib.in_device_context(lambda m: MeshHierarchy(m).prepare()), mesh_space)
         # --- TIME --- (heateq_mpi.py:78-88)
         self.A_t, self.L_t, self.M_t, self.G_t, self.u0_t = time_matrices(
             mesh_time)

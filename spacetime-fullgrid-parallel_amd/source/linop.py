@@ -183,7 +183,8 @@ def union_pattern(mats):
     assert len(mats) <= 30
     if len(mats) == 1:  # nothing to unite
         m = mats[0]
-        return m.indptr.astype(np.int32), m.indices.astype(np.int32), [np.asarray(m.data, dtype=np.float64)]
+        return (np.asarray(m.indptr, dtype=np.int32), np.asarray(m.indices, dtype=np.int32),
+                [np.asarray(m.data, dtype=np.float64)])
     pat = None
     for k, m in enumerate(mats):
         own = sp.csr_matrix((np.full(m.nnz, float(1 << k)), m.indices, m.indptr),
@@ -197,7 +198,7 @@ def union_pattern(mats):
         full = np.zeros(pat.nnz)
         full[((owners >> k) & 1) == 1] = m.data
         vals.append(full)
-    return pat.indptr.astype(np.int32), pat.indices.astype(np.int32), vals
+    return np.asarray(pat.indptr, dtype=np.int32), np.asarray(pat.indices, dtype=np.int32), vals
 
 
 def row_order_for(mats, indptr, indices):
@@ -431,12 +432,18 @@ class EllMatrices:
         pos = np.repeat(np.arange(M), counts)
         slot = np.arange(len(indices)) - np.repeat(indptr[:-1], counts)
         main = slot < K
+        # (flat one-dimensional scatters: several times faster than [rows, slots]
+        # index pairs on seven million entries)
+        flat = pos * K + slot
+        whole = bool(main.all())
+        if not whole:
+            flat = flat[main]
         ell_idx = np.repeat(own.astype(np.int32)[:, None], K, axis=1)
-        ell_idx[pos[main], slot[main]] = indices[main]
+        ell_idx.reshape(-1)[flat] = indices if whole else indices[main]
         ell_vals = []
         for v in vals:
             e = np.zeros((M, K))
-            e[pos[main], slot[main]] = v[main]
+            e.reshape(-1)[flat] = v if whole else v[main]
             ell_vals.append(e)
         self.M, self.K = M, K
         self.nnz = len(indices)

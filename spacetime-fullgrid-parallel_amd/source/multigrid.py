@@ -70,6 +70,49 @@ class MeshHierarchy:
             return np.arange(n, dtype=np.int32)
         return self.shared(('tile', n), lambda: tile_order_from_coords(self.coords[:n]))
 
+    def coord_band(self, n):
+        """Slices of the first n dofs along the last coordinate axis (mesh rows of a
+        structured mesh): the candidate bands of coupling_bands."""
+        if self.coords is None:
+            return None
+
+        def make():
+            _, band = np.unique(np.round(np.asarray(self.coords)[:n, -1], 12), return_inverse=True)
+            return band.astype(np.int64)
+
+        return self.shared(('band', n), make)
+
+    def transfer_copies(self, j):
+        """P and R between levels j - 1 and j on the device, as CSR and as ELL copies in
+        tile order: they depend on the mesh alone, one set serves every plan of the
+        hierarchy (read-only in all kernels)."""
+        def make():
+            P = sp.csr_matrix(self.P_mats[j - 1])
+            R = sp.csr_matrix(self.R_mats[j - 1])
+            dev, ells = {}, {}
+            for name, m, order in (('p', P, self.tile_order(P.shape[0])),
+                                   ('r', R, self.tile_order(P.shape[1]))):
+                m.sort_indices()
+                dev[name + '_indptr'] = _lib.to_dev(np.asarray(m.indptr, dtype=np.int32))
+                dev[name + '_indices'] = _lib.to_dev(np.asarray(m.indices, dtype=np.int32))
+                dev[name + '_vals'] = _lib.to_dev(np.asarray(m.data, dtype=np.float64))
+                ells[name] = EllRowsMatrix(m.indptr, m.indices, m.data, None, order)
+            return dev, ells
+
+        return self.shared(('transfer', j), make)
+
+    def prepare(self):
+        """Everything plans share, ahead of time (the driver calls it in the thread
+        that builds the hierarchy, beside the assembly of the matrices)."""
+        sizes = [P.shape[1] for P in self.P_mats] + ([self.P_mats[-1].shape[0]] if self.P_mats else [])
+        for n in sizes:
+            self.tile_order(n)
+            self.coord_band(n)
+        if _lib.compute_device().type == 'cuda':
+            for j in range(1, self.J + 1):
+                self.transfer_copies(j)
+        return self
+
 
 def _tile_order(hierarchy, n):
     """Processing order of the first n dofs of a hierarchy (any object with P_mats /
@@ -123,8 +166,8 @@ def galerkin_product(R, A, P, cache=None):
     def up(m, key=None):
         if cache is not None and key is not None and key in cache:
             return cache[key]
-        dev = (_lib.to_dev(m.indptr.astype(np.int32)), _lib.to_dev(m.indices.astype(np.int32)),
-               _lib.to_dev(m.data.astype(np.float64)))
+        dev = (_lib.to_dev(np.asarray(m.indptr, dtype=np.int32)), _lib.to_dev(np.asarray(m.indices, dtype=np.int32)),
+               _lib.to_dev(np.asarray(m.data, dtype=np.float64)))
         if cache is not None and key is not None:
             cache[key] = dev
         return dev
@@ -206,7 +249,7 @@ def _groups_by_depth(depth, n, backward):
     return ptr, order.astype(np.int32)
 
 
-def coupling_bands(coords, indptr, indices, rows_of=None):
+def coupling_bands(coords, indptr, indices, rows_of=None, coord_band=None):
     """A band index per row such that two coupled rows always lie in the same
     or in adjacent bands -- the property the strip-wise Gauss-Seidel sweep of
     csrc/mg.hip rests on -- with bands as thin as that allows.  The property is
@@ -224,11 +267,18 @@ def coupling_bands(coords, indptr, indices, rows_of=None):
     def ok(b):
         return len(indices) == 0 or np.abs(b[rows_of] - b[indices]).max() <= 1
 
+    verified = False
     if coords is not None:
-        _, band = np.unique(np.round(np.asarray(coords)[:n, -1], 12),
-                            return_inverse=True)
-        band = band.astype(np.int64)
-        while band.max() > 0 and not ok(band):
+        if coord_band is not None:  # the slices along the last axis, computed by the caller
+            band = coord_band.copy()
+        else:
+            _, band = np.unique(np.round(np.asarray(coords)[:n, -1], 12),
+                                return_inverse=True)
+            band = band.astype(np.int64)
+        while band.max() > 0:
+            if ok(band):
+                verified = True
+                break
             band //= 2
     else:
         from scipy.sparse.csgraph import dijkstra
@@ -238,7 +288,7 @@ def coupling_bands(coords, indptr, indices, rows_of=None):
         if not np.isfinite(dist).all():
             return None
         band = dist.astype(np.int64)
-    if band.max() < 1 or not ok(band):
+    if band.max() < 1 or not (verified or ok(band)):
         return None
     return band
 
@@ -349,7 +399,8 @@ class _DeviceHierarchy:
             rank = np.empty(n, dtype=np.int64)
             rank[tile] = np.arange(n)
             # bands for the strip-wise sweeps: coupled rows at most one band apart
-            band = coupling_bands(hierarchy.coords, indptr, indices, rows_of)
+            band = coupling_bands(hierarchy.coords, indptr, indices, rows_of,
+                                  hierarchy.coord_band(n) if hasattr(hierarchy, 'coord_band') else None)
             key = rank if band is None else band * np.int64(n) + rank
             vm = vals[1] if self.has_m else None
             # transfer operators and the restricted-residual product R A: independent
@@ -433,16 +484,16 @@ class _DeviceHierarchy:
                 dev_, ells_ = {}, {}
                 for name, m, order in (('p', P, tile), ('r', R, tile_c)):
                     m.sort_indices()
-                    dev_[name + '_indptr'] = _lib.to_dev(m.indptr.astype(np.int32))
-                    dev_[name + '_indices'] = _lib.to_dev(m.indices.astype(np.int32))
-                    dev_[name + '_vals'] = _lib.to_dev(m.data.astype(np.float64))
+                    dev_[name + '_indptr'] = _lib.to_dev(np.asarray(m.indptr, dtype=np.int32))
+                    dev_[name + '_indices'] = _lib.to_dev(np.asarray(m.indices, dtype=np.int32))
+                    dev_[name + '_vals'] = _lib.to_dev(np.asarray(m.data, dtype=np.float64))
                     ells_[name] = EllRowsMatrix(m.indptr, m.indices, m.data, None, order)
                 return dev_, ells_
 
             # P and R and their ELL copies depend on the mesh alone: one set on the
-            # device for all plans of the hierarchy (read-only in every kernel)
-            if hasattr(hierarchy, 'shared'):
-                shared_dev, shared_ells = hierarchy.shared(('transfer', j), transfer_copies)
+            # device for all plans of a MeshHierarchy
+            if hasattr(hierarchy, 'transfer_copies'):
+                shared_dev, shared_ells = hierarchy.transfer_copies(j)
             else:
                 shared_dev, shared_ells = transfer_copies()
             dev, ells = dict(shared_dev), dict(shared_ells)

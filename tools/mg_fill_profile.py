@@ -23,6 +23,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--J_space', type=int, default=9)
 ap.add_argument('--J_time', type=int, default=6)
 ap.add_argument('--top', type=int, default=30)
+ap.add_argument('--sort', default='cumulative')
 args = ap.parse_args()
 if torch.cuda.is_available():
     torch.zeros(1, device='cuda')
@@ -76,4 +77,4 @@ for name, fn in (('MultiGrid(A_x)', lambda: MultiGrid(A_x, hier, smoothsteps=3, 
     fn()
     pr.disable()
     print('==== %s inline: %.2f s' % (name, time.time() - t), flush=True)
-    pstats.Stats(pr).sort_stats('cumulative').print_stats(args.top)
+    pstats.Stats(pr).sort_stats(args.sort).print_stats(args.top)
