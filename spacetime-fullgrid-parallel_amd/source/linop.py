@@ -96,7 +96,10 @@ class SpaceMatrix(SpaceOp):
             out = torch.empty((self.shape[0], ld),
                               dtype=torch.float64,
                               device=x.device)
-        ell = self._ell_form() if (ld % 2 == 0 and ld > 1) else None
+        # the row engine gives a row one lane per pair of time steps (at most 512 lanes);
+        # longer rows -- the transposed slabs of MatKronIdentityMPI, whose "time" axis is
+        # a rank's share of the space dofs -- take the flat CSR kernel
+        ell = self._ell_form() if (ld % 2 == 0 and ld > 1 and (n_loc + 1) // 2 <= 512) else None
         if ell is not None:
             _lib.check(_lib.lib().stk_ell_spmm(
                 _lib.stream(), ctypes.byref(ell.struct), n_loc, ld,

@@ -20,17 +20,26 @@ adjacent, old vertices are never adjacent to each other in the refined mesh,
 and therefore a Gauss-Seidel sweep in dof order (reference multigrid.py:89-97)
 has a dependency DAG of depth (#colours + 1) -- 4 for the square -- while still
 being exactly the sequential sweep of the reference.  The colour of the
-hypotenuses comes FIRST (round 4): the stiffness matrix has no entry across a
-hypotenuse, which leaves its sweep with 2 dependency levels (a red-black split:
-see _greedy_edge_colouring).
+hypotenuses comes LAST by default: the stiffness matrix has no entry across a
+hypotenuse, so the midpoints of the two short-edge classes share a dependency
+level and its sweep has 3.  HYPOTENUSE_FIRST = True puts that colour first, which
+leaves the sweep with 2 levels (a red-black split) -- cheaper applies, but a
+weaker smoother and a longer solve: measured and not the default (see the flag).
 """
 import numpy as np
 
-# False: the hypotenuse class LAST among a level's new vertices (the numbering of
-# rounds 1-3: 3 dependency levels for A_x).  Only tools/mg_sweep.py flips it, to
-# show what the order does to the smoother; the fixtures under tests/golden hold
-# the default.
-HYPOTENUSE_FIRST = True
+# Where the hypotenuse class goes among a level's new vertices.  False (the default):
+# LAST -- the stiffness matrix sweeps in 3 dependency groups, [old | short-edge
+# midpoints | hypotenuse midpoints].  True: FIRST -- 2 groups, the red-black split
+# [old, hypotenuse midpoints | short-edge midpoints], 5-13 % cheaper applies of S.
+# The sweep runs in dof order (reference multigrid.py:89-97), so this is a choice of
+# SMOOTHER, and the red-black order is the weaker one: kappa(K^-1 A_x) 1.028 against
+# 1.002 at J_space = 9 (profiles/r04_mg_sweep_J9.log), PCG needs 14 iterations instead
+# of 13 at J_time = 6 / J_space = 9 and 12 instead of 9 at J_time = 3, and the time to
+# solution is 5-23 % LONGER on every configuration measured
+# (profiles/r04_numbering_*.log; tools/numbering_ab.py, tools/mg_sweep.py).  The
+# fixtures under tests/golden hold the default.
+HYPOTENUSE_FIRST = False
 
 
 class IntervalMesh:
@@ -94,16 +103,15 @@ class TriangleMesh:
                 for b in tri:
                     if a != b:
                         nbrs[a].add(b)
-        # process edges grouped by length (longest first), then direction:
-        # structured meshes get the natural (diagonal, horizontal, vertical)
-        # classes, with the longest edges (the hypotenuses) in the FIRST class.
-        # The stiffness matrix of a right triangle has no entry across its
-        # hypotenuse, so A_x couples neither two old vertices, nor an old vertex
-        # with a hypotenuse midpoint, nor two short-edge midpoints: {old vertices,
-        # hypotenuse midpoints} and {short-edge midpoints} are a red-black split
-        # that respects the hierarchical prefix, and the dof-order sweep over A_x
-        # has 2 dependency levels (3 with the hypotenuses last, 4 for M_x + A_x
-        # either way).
+        # process edges grouped by length, then direction: structured meshes get the
+        # natural (horizontal, vertical, diagonal) classes.  The stiffness matrix of
+        # a right triangle has no entry across its hypotenuse, so A_x couples neither
+        # two old vertices, nor an old vertex with a hypotenuse midpoint, nor two
+        # short-edge midpoints.  Longest edges LAST (the default): the dof-order sweep
+        # over A_x has 3 dependency levels, [old | short-edge midpoints | hypotenuse
+        # midpoints].  Longest edges FIRST (HYPOTENUSE_FIRST): {old vertices,
+        # hypotenuse midpoints} and {short-edge midpoints} are a red-black split that
+        # respects the hierarchical prefix, 2 levels.  M_x + A_x has 4 either way.
         d = self.points[edges[:, 1]] - self.points[edges[:, 0]]
         ang = np.round(np.mod(np.arctan2(d[:, 1], d[:, 0]), np.pi), 9)
         length = np.round(np.hypot(d[:, 0], d[:, 1]), 9)
@@ -187,14 +195,14 @@ class TetMesh:
     numbering; same attributes as TriangleMesh, with ``cells`` (nt, 4).
 
     The new vertices of a level are grouped by the *direction class* of the edge
-    they bisect (face diagonals, axes, space diagonal) and sorted
-    lexicographically inside a class.  On the Kuhn triangulation of the cube
+    they bisect, shortest edges first (see _edge_classes for the other order), and
+    sorted lexicographically inside a class.  On the Kuhn triangulation of the cube
     there are 7 classes (3 axes, 3 face diagonals, the space diagonal) and no two
     edges of a tetrahedron share one, so vertices of one class are never
     adjacent: the dof-order Gauss-Seidel sweep (reference multigrid.py:89-97) has
-    at most 8 dependency levels for the 15-point mass matrix and 2 for the
+    at most 8 dependency levels for the 15-point mass matrix and 4 for the
     stiffness matrix, which on this mesh is the 7-point stencil (axis neighbours
-    only; see _edge_classes for the order of the classes)."""
+    only)."""
     def __init__(self, points, tets, boundary_fn):
         self.points = np.asarray(points, dtype=np.float64)
         self.tets = np.asarray(tets, dtype=np.int64)
@@ -227,14 +235,15 @@ class TetMesh:
         sign = np.sign(u[np.arange(len(u)), first])
         u = u * sign[:, None]
         rel = np.round(length / length.min(), 9)
-        # face diagonals (two non-zero components) first, then the axes, then the
-        # space diagonal: the stiffness matrix couples axis neighbours only, i.e.
-        # vertices whose numbers of odd fine-grid coordinates differ by one, so
-        # {old vertices, face-diagonal midpoints} and {axis midpoints,
-        # space-diagonal midpoints} are a red-black split of A_x that respects the
-        # hierarchical prefix (2 dependency levels instead of 4).
+        # Default: shortest edges first (axes, face diagonals, space diagonal).  With
+        # HYPOTENUSE_FIRST: face diagonals (two non-zero components) first, then the
+        # axes, then the space diagonal -- the stiffness matrix couples axis
+        # neighbours only, i.e. vertices whose numbers of odd fine-grid coordinates
+        # differ by one, so {old vertices, face-diagonal midpoints} and {axis
+        # midpoints, space-diagonal midpoints} are a red-black split of A_x that
+        # respects the hierarchical prefix (2 dependency levels instead of 4).
         nnz = (np.abs(u) > 0).sum(axis=1)
-        prio = np.where(nnz == 2, 0, np.where(nnz == 1, 1, 2))
+        prio = np.where(nnz == 2, 0, np.where(nnz == 1, 1, 2)) if HYPOTENUSE_FIRST else np.zeros(len(u))
         key = np.column_stack([prio, rel, u])
         _, cls = np.unique(key, axis=0, return_inverse=True)
         return cls.reshape(-1)

@@ -665,6 +665,8 @@ class SparseKronIdentityMPI(LinearOperatorMPI):
 class MatKronIdentityMPI(LinearOperatorMPI):
     """M_t kron I_x for a general (dense) time matrix through an all-to-all
     transpose of the vector (reference mpi_kron.py:225-256)."""
+    single_rank_shortcut = True  # False: the transposes also on one rank (tests)
+
     def __init__(self, dofs_distr, mat_time):
         N, K = mat_time.shape
         assert (N == K)
@@ -676,11 +678,24 @@ class MatKronIdentityMPI(LinearOperatorMPI):
             mat_time.toarray() if scipy.sparse.issparse(mat_time) else
             as_matrix(mat_time))
         self._time_op = SpaceMatrix(scipy.sparse.csr_matrix(dense))
+        self._dense = np.ascontiguousarray(dense, dtype=np.float64)
+        self._dense_dev = None
 
     def _matvec(self, vec_in, vec_out):
         assert (isinstance(vec_in, KronVectorMPI))
         assert (self.N == vec_in.N and self.M == vec_in.M)
         assert (vec_in.buf.shape == vec_out.buf.shape)
+        if self.dofs_distr.size == 1 and vec_in.buf.is_cuda and type(self).single_rank_shortcut:
+            # one rank holds every time row of every space dof already: the transposes
+            # of the reference (mpi_kron.py:246-253) have nothing to exchange, the
+            # dense time factor acts on the contiguous time column of each dof
+            if self._dense_dev is None:
+                self._dense_dev = _lib.to_dev(self._dense)
+            _lib.check(_lib.lib().stk_time_dense_apply(
+                _lib.stream(), vec_in.M, self.N, vec_in.ld, self.N, vec_out.ld,
+                _lib.ptr(self._dense_dev), _lib.ptr(vec_in.buf), _lib.ptr(vec_out.buf)))
+            vec_out.communicated_bdr = False
+            return vec_out
         vec_perm, comm_time = vec_in.permute()
         self.time_communication += comm_time
         # the permuted vector has the time index as its "space" index

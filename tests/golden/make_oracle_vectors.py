@@ -120,6 +120,9 @@ def main():
     ap.add_argument('--kmax', type=int, default=100000)
     ap.add_argument('--no-ops', action='store_true',
                     help='skip the S(X), P(X) samples (memory at the largest sizes)')
+    ap.add_argument('--ops-only', action='store_true',
+                    help='keep the trajectory of the existing fixture and recompute only the '
+                         'S / P / W samples of the bench vector (after a change of that vector)')
     ap.add_argument('--lean', action='store_true',
                     help='chunked S and in-place PCG (the largest configuration, with --kmax 3: '
                          'the first entries of the history only)')
@@ -131,18 +134,28 @@ def main():
     def cb(w, r, k):
         print('  iteration %d  (%.0f s)' % (k, time.time() - t0), flush=True)
 
-    if args.lean:
-        S_lean, T_lean = lean_operators(o)
-        o.S = S_lean
-        w, iters, hist = lean_pcg(T_lean, o.P, o.rhs(), args.kmax)
-    else:
-        w, iters, hist = pcg(o.WT_S_W, o.P, o.rhs(), kmax=args.kmax, callback=cb)
-    print('oracle PCG: %d iterations in %.1f s' % (iters, time.time() - t0))
+    path = os.path.join(HERE, fixture_name(args.problem, args.J_time, args.J_space))
     st, sx = sample_strides(o.N, o.M)
-    out = dict(J_time=args.J_time, J_space=args.J_space, problem=args.problem,
-               iters=iters, kmax=args.kmax, hist=np.array(hist),
-               w_norm=np.linalg.norm(w), w_sample=w[::st, ::sx].copy(),
-               sample_strides=np.array([st, sx]))
+    if args.ops_only:
+        have = np.load(path)
+        out = {k: have[k] for k in have.files}
+        assert (int(out['J_time']), int(out['J_space']), str(out['problem'])) == (
+            args.J_time, args.J_space, args.problem)
+        assert tuple(int(v) for v in out['sample_strides']) == (st, sx)
+        if args.lean:
+            o.S = lean_operators(o)[0]
+    else:
+        if args.lean:
+            S_lean, T_lean = lean_operators(o)
+            o.S = S_lean
+            w, iters, hist = lean_pcg(T_lean, o.P, o.rhs(), args.kmax)
+        else:
+            w, iters, hist = pcg(o.WT_S_W, o.P, o.rhs(), kmax=args.kmax, callback=cb)
+        print('oracle PCG: %d iterations in %.1f s' % (iters, time.time() - t0))
+        out = dict(J_time=args.J_time, J_space=args.J_space, problem=args.problem,
+                   iters=iters, kmax=args.kmax, hist=np.array(hist),
+                   w_norm=np.linalg.norm(w), w_sample=w[::st, ::sx].copy(),
+                   sample_strides=np.array([st, sx]))
     if not args.no_ops:
         # the bench's vector (bench.seeded_slab): the reference's timing vector,
         # np.random.seed(128); rand(N, M) (heateq_mpi_timing.py:81-83)
@@ -150,9 +163,7 @@ def main():
         out['SX_sample'] = o.S(X)[::st, ::sx].copy()
         out['PX_sample'] = o.P(X)[::st, ::sx].copy()
         out['WX_sample'] = o.W(X)[::st, ::sx].copy()
-    np.savez_compressed(
-        os.path.join(HERE, fixture_name(args.problem, args.J_time, args.J_space)),
-        **out)
+    np.savez_compressed(path, **out)
 
 
 if __name__ == '__main__':

@@ -467,6 +467,19 @@ def test_mat_kron_identity_and_original_wavelet_mode(stk):
     x = _vec(dd, X)
     M_I = MatKronIdentityMPI(dd, mat_time)
     assert relerr(_np(M_I @ x), mat_time @ X) < TOL
+    # one rank applies the dense factor to the time columns directly; the reference's
+    # route -- transpose, I kron T on the transposed slab, transpose back -- must give
+    # the same, also when a transposed "time" row (a rank's share of the space dofs) is
+    # longer than the row engine's 1024 time steps (the sizes of the BASELINE configs)
+    MatKronIdentityMPI.single_rank_shortcut = False
+    try:
+        assert relerr(_np(M_I @ x), mat_time @ X) < TOL
+        for M_long in (1024, 1025, 2500):
+            dl = _dd(N, M_long)
+            Xl = np.random.RandomState(5).rand(N, M_long)
+            assert relerr(_np(MatKronIdentityMPI(dl, mat_time) @ _vec(dl, Xl)), mat_time @ Xl) < TOL
+    finally:
+        MatKronIdentityMPI.single_rank_shortcut = True
     I_M = IdentityKronMatMPI(dd, mat_space)
     comp = CompositeMPI(dd, [I_M, M_I])
     want = (np.kron(mat_time, mat_space) @ X.reshape(-1)).reshape(N, M)

@@ -369,28 +369,34 @@ def test_p1_assembler_matches_scipy_path(monkeypatch):
 
 def test_numbering_gives_shallow_gauss_seidel_schedules():
     """The build-owned numbering (source/mesh.py) orders the new vertices of a
-    level by edge class with the hypotenuse class FIRST: the stiffness matrix of a
-    right triangle has no entry across its hypotenuse, so {old vertices, hypotenuse
-    midpoints} and {short-edge midpoints} are a red-black split that respects the
-    hierarchical prefix, and the sequential sweep of the reference
-    (multigrid.py:89-97) has 2 dependency levels of equal size for the 5-point
-    stiffness matrix (3 with the hypotenuses last) and 4 for the 7-point mass
-    matrix; on the cube (face diagonals first) 2 for the 7-point stiffness matrix
-    and at most 8 for the 15-point mass matrix.  Numbering inside a level is free
-    in the reference (mesh.py:21-30)."""
+    level by edge class with the hypotenuse class last: the sequential sweep of
+    the reference (multigrid.py:89-97) then has 3 dependency levels for the
+    5-point stiffness matrix and 4 for the 7-point mass matrix (cube: 4 and at most
+    8).  With mesh.HYPOTENUSE_FIRST the stiffness matrix sweeps in 2 levels of equal
+    size -- {old vertices, hypotenuse midpoints} and {short-edge midpoints} are a
+    red-black split that respects the hierarchical prefix -- which is the cheaper
+    but weaker smoother (measured: profiles/r04_numbering_*.log; not the default).
+    Numbering inside a level is free in the reference (mesh.py:21-30)."""
+    from source import mesh as mesh_mod
     from source.assembly import space_matrices
-    from source.mesh import (construct_2d_lshape_mesh, construct_2d_square_mesh,
-                             construct_3d_cube_mesh)
     from source.multigrid import gauss_seidel_schedule
-    for build, depth_m in ((construct_2d_square_mesh, 4), (construct_2d_lshape_mesh, 4),
-                           (construct_3d_cube_mesh, 8)):
-        M_x, A_x = space_matrices(build(2 if depth_m == 8 else 3)[0], scipy_path=True)
-        for backward in (False, True):
-            ptr = gauss_seidel_schedule(A_x.indptr, A_x.indices, backward)[0]
-            assert len(ptr) - 1 == 2 and abs(int(ptr[1]) - int(ptr[2] - ptr[1])) <= 1, ptr
-            assert len(gauss_seidel_schedule(M_x.indptr, M_x.indices, backward)[0]) - 1 <= depth_m
-            if depth_m == 4:
-                assert len(gauss_seidel_schedule(M_x.indptr, M_x.indices, backward)[0]) - 1 == 4
+    builds = ((mesh_mod.construct_2d_square_mesh, 3, 3, 4), (mesh_mod.construct_2d_lshape_mesh, 3, 3, 4),
+              (mesh_mod.construct_3d_cube_mesh, 2, 4, 8))
+    try:
+        for first in (False, True):
+            mesh_mod.HYPOTENUSE_FIRST = first
+            for build, J, depth_a, depth_m in builds:
+                M_x, A_x = space_matrices(build(J)[0], scipy_path=True)
+                for backward in (False, True):
+                    ptr = gauss_seidel_schedule(A_x.indptr, A_x.indices, backward)[0]
+                    if first:
+                        assert len(ptr) - 1 == 2 and abs(int(ptr[1]) - int(ptr[2] - ptr[1])) <= 1, ptr
+                    else:
+                        assert len(ptr) - 1 == depth_a, (build.__name__, ptr)
+                    got = len(gauss_seidel_schedule(M_x.indptr, M_x.indices, backward)[0]) - 1
+                    assert got == depth_m if depth_m == 4 else got <= depth_m
+    finally:
+        mesh_mod.HYPOTENUSE_FIRST = False
 
 
 def test_c_partition_matches_reference_tables():
