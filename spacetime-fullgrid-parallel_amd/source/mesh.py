@@ -40,6 +40,10 @@ import numpy as np
 # (profiles/r04_numbering_*.log; tools/numbering_ab.py, tools/mg_sweep.py).  The
 # fixtures under tests/golden hold the default.
 HYPOTENUSE_FIRST = False
+# tools/numbering_ab.py --orders: colour c of the coarsest mesh's edges becomes class
+# CLASS_ORDER[c] (None: as coloured; with the default colouring of a three-direction
+# mesh, colour 0 / 1 / 2 = horizontal / vertical / hypotenuse).
+CLASS_ORDER = None
 
 
 class IntervalMesh:
@@ -123,6 +127,8 @@ class TriangleMesh:
             while c in used:
                 c += 1
             col[e] = c
+        if CLASS_ORDER is not None:  # experiments: another order of the colour classes
+            col = np.asarray(CLASS_ORDER, dtype=np.int64)[col]
         return col[te]
 
     # ------------------------------------------------------------------

@@ -27,6 +27,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--J_time', type=int, default=6)
 ap.add_argument('--J_space', type=int, default=9)
 ap.add_argument('--problem', default='square')
+ap.add_argument('--orders', action='store_true',
+                help='all six orders of the three edge classes instead of the two settings of the flag')
 args = ap.parse_args()
 
 
@@ -40,8 +42,15 @@ def timed(fn, n):
     return (time.perf_counter() - t) / n, out
 
 
-for first in (True, False):
+import itertools  # noqa: E402
+
+cases = ([(False, p) for p in itertools.permutations(range(3))] if args.orders
+         else [(True, None), (False, None)])
+for first, perm in cases:
     mesh_mod.HYPOTENUSE_FIRST = first
+    mesh_mod.CLASS_ORDER = perm
+    if perm is not None:
+        print('class order %s:' % (perm,), end=' ')
     h = hm.HeatEquationMPI(J_space=args.J_space, J_time=args.J_time, problem=args.problem)
     x = h.rhs.copy()
     tS, _ = timed(lambda: h.S @ x, 5)
