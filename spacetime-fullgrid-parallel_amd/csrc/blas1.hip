@@ -25,9 +25,13 @@ __global__ __launch_bounds__(BS) void axpbyz_kernel(int64_t n, double a, const d
     } else {
         for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += stride) {
             double2 xv = x2[i], yv = y2[i];
-            z2[i] = make_double2(a * xv.x + b * yv.x, a * xv.y + b * yv.y);
+            // b * y rounded, then ONE fused multiply-add: with a = 1 this is exactly the
+            // two steps `y *= b; y += x` (reference linalg.py:39-40), which lets PCG update
+            // its search direction in one pass without changing a bit (written out so that
+            // it does not depend on how the compiler contracts a * x + b * y)
+            z2[i] = make_double2(fma(a, xv.x, b * yv.x), fma(a, xv.y, b * yv.y));
         }
-        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) z[n - 1] = a * x[n - 1] + b * y[n - 1];
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) z[n - 1] = fma(a, x[n - 1], b * y[n - 1]);
     }
 }
 

@@ -44,7 +44,10 @@ def PCG(T, P, b, w0=None, kmax=100000, eps=1e-6, callback=None, history=None):
         record(rho)
         if rho < threshold:
             break
-        direction *= rho / previous
-        direction += z
+        if hasattr(direction, 'scale_add'):  # KronVectorMPI: the same two roundings, one pass
+            direction.scale_add(rho / previous, z)
+        else:
+            direction *= rho / previous
+            direction += z
         del z
     return w, done

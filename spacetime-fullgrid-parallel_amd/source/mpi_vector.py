@@ -344,6 +344,15 @@ class KronVectorMPI:
         self._axpby(float(other), self.buf, 0.0)
         return self
 
+    def scale_add(self, factor, other):
+        """self = factor * self + other in ONE pass, bit for bit the two steps
+        `self *= factor; self += other` (stk_axpby rounds factor * self before its
+        fused multiply-add with 1.0 * other): PCG's update of the search direction
+        (reference linalg.py:39-40) without the extra read and write of the slab."""
+        self._invalidate()
+        self._axpby(1.0, other.buf, float(factor))
+        return self
+
     def __itruediv__(self, other):
         self._invalidate()
         self._axpby(1.0 / float(other), self.buf, 0.0)

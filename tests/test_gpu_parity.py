@@ -86,6 +86,14 @@ def test_blas1_and_dot(stk):
         x /= 3.0
         X = X / 3.0
         assert relerr(_np(x), X) < 1e-15
+        # PCG's direction update in one pass: bit for bit the two steps of the reference
+        # (linalg.py:39-40), which NumPy performs with the same two roundings
+        p1, p2, zz = x.copy(), x.copy(), _vec(dd, Y)
+        p1 *= 0.37
+        p1 += zz
+        p2.scale_add(0.37, zz)
+        assert torch.equal(p1.buf, p2.buf)
+        assert np.array_equal(_np(p2), _np(x) * 0.37 + Y)
         w = y / 7.0
         assert relerr(_np(w), Y / 7.0) < 1e-15
         w = -y
