@@ -35,7 +35,7 @@ def _run(worker, nproc, extra_env=None, timeout=600):
     return res.stdout
 
 
-@pytest.mark.parametrize('nproc', [2, 3, 5])
+@pytest.mark.parametrize('nproc', [2, 3, 5, 8])
 def test_comm_layer_gloo_cpu(nproc):
     out = _run('mp_comm_worker.py', nproc, {'HIP_VISIBLE_DEVICES': '',
                                             'CUDA_VISIBLE_DEVICES': ''})

@@ -6,9 +6,10 @@ last (3 groups).  The Gauss-Seidel sweep runs in dof order (reference
 multigrid.py:89-97), so the numbering is part of the smoother: fewer groups make
 an apply cheaper, a weaker smoother makes the solve longer.
 
-    python tools/numbering_ab.py [--J_time 6 --J_space 9] [--slab 0]
---slab n: the solve's operators on the FIRST n time steps only is not possible (the
-solve needs all steps); instead S and P are also timed alone."""
+    python tools/numbering_ab.py [--J_time 6 --J_space 9] [--problem square] [--orders]
+
+S and P are timed alone as well; --orders runs all six orders of the three edge classes
+(mesh.CLASS_ORDER) instead of the two settings of the flag."""
 import argparse
 import os
 import sys
