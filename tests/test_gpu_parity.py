@@ -513,6 +513,28 @@ def test_mat_kron_identity_and_original_wavelet_mode(stk):
             assert abs(it - it_ref) <= 1 and relerr(u, u_ref) < 1e-5
 
 
+def test_reference_family_runs_the_default_arithmetic_too(stk):
+    """HeatEquationMPI(family='reference') -- one hierarchy per wavelet level from the
+    assembled 2^j M_x + alpha A_x, as reference heateq_mpi.py:147-153 builds them -- gets
+    the plan options of arithmetic='accurate' like the batched family (it
+    used to run a third, undocumented arithmetic): the r.Pr history of config 1 within
+    1e-10 of the oracle's.  Unknown option strings are refused, not silently mapped."""
+    import heateq_mpi as hm
+    from source.linalg import PCG
+    g = load_golden('o1_pcg_square_J3_J6')
+    h = hm.HeatEquationMPI(J_space=int(g['J_space']), J_time=int(g['J_time']), family='reference')
+    assert h.arithmetic == 'accurate' and h.C_family is None
+    for mg in [h.Kinv_x] + h.C_j:
+        assert mg._dev.options.get('fast_until_cycle') == 1 and mg._dev.options.get('fast_parts') == 1
+    hist = []
+    w, it = PCG(h.WT_S_W, h.P, h.rhs, history=hist)
+    assert it == int(g['iters'])
+    assert _record_history_dev('square_J3_J6_reference_family_accurate', hist, g['hist']) < HIST_RTOL_REFERENCE
+    for bad in (dict(family='batch'), dict(schur='fuse')):
+        with pytest.raises(AssertionError):
+            hm.HeatEquationMPI(J_space=2, J_time=2, **bad)
+
+
 def test_midsize_solve_matches_oracle_fixture(stk):
     """N = 33, M = 16 129: PCG iteration count and r.Pr history against the CPU
     oracle's trajectory (tests/golden/make_oracle_vectors.py)."""
