@@ -114,6 +114,15 @@ def main():
         _FusedKronSum.overlap = True
     if rank == 0:
         assert rel(y_overlap, y_one_pass) < 1e-14 and rel(y_overlap, want_metric) < 1e-12
+    # the mirrored driver end to end on the same ranks (reference heateq_mpi.py:205-312):
+    # its first-contact record -- start-up line per rank, on 3 ranks and more the probe
+    # that chooses the halo form -- and the same solve
+    if os.environ.get('STK_HALO_ROUTES') is None:
+        _, sol_d, its_d, hist_d = hm.main(['--J_time=%d' % J_time, '--J_space=%d' % J_space,
+                                          '--problem=%s' % problem])
+        assert its_d == its and np.allclose(hist_d, hist, rtol=1e-12, atol=0.0)
+        KronVectorMPI.HALO_ROUTES = 1
+    if rank == 0:
         print('mp_gpu_worker ok: size %d, %d PCG iterations' % (size, its))
     comm.Barrier()
 
