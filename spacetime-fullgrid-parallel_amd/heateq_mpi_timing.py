@@ -20,7 +20,8 @@ from source.mpi_vector import KronVectorMPI  # noqa: E402
 
 def main(argv=None):
     args = driver.parse('Time several components of the parallel heat equation.', argv,
-                        extra=[('iters', int, 10, 'number of iterations per operator')])
+                        extra=[('iters', int, 10, 'number of iterations per operator')],
+                        defaults={'wavelettransform': 'original'})  # the reference's default here
     comm, rank, size = driver.start(args)
     heat = HeatEquationMPI(**driver.solver_arguments(args))
     if rank == 0:

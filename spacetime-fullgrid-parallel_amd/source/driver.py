@@ -32,10 +32,13 @@ def device_mb():
     return torch.cuda.memory_allocated() / 1048576 if torch.cuda.is_available() else 0.0
 
 
-def parse(description, argv, extra=()):
+def parse(description, argv, extra=(), defaults=None):
+    """`defaults`: a driver's own defaults where the reference's drivers differ (its
+    timing script takes wavelettransform='original', heateq_mpi_timing.py:35-37, its solve
+    driver 'composite', heateq_mpi.py:225-228)."""
     parser = argparse.ArgumentParser(description=description)
     for flag, kind, default, text in _PROBLEM_OPTIONS + tuple(extra):
-        parser.add_argument('--' + flag, type=kind, default=default, help=text)
+        parser.add_argument('--' + flag, type=kind, default=(defaults or {}).get(flag, default), help=text)
     return parser.parse_args(argv)
 
 

@@ -679,21 +679,27 @@ class MatKronIdentityMPI(LinearOperatorMPI):
             as_matrix(mat_time))
         self._time_op = SpaceMatrix(scipy.sparse.csr_matrix(dense))
         self._dense = np.ascontiguousarray(dense, dtype=np.float64)
-        self._dense_dev = None
+        self._local_csr = None
+        # the one-rank shortcut below runs one thread per output over the entries of its
+        # row: good for rows of a few entries (W: 1.69 against 2.46 ms through the
+        # transposes at config 3), bad when some rows are full (W^T: 5.6 against 2.6 ms)
+        self._max_row_nnz = int((self._dense != 0).sum(axis=1).max()) if self._dense.size else 0
 
     def _matvec(self, vec_in, vec_out):
         assert (isinstance(vec_in, KronVectorMPI))
         assert (self.N == vec_in.N and self.M == vec_in.M)
         assert (vec_in.buf.shape == vec_out.buf.shape)
-        if self.dofs_distr.size == 1 and vec_in.buf.is_cuda and type(self).single_rank_shortcut:
+        if (self.dofs_distr.size == 1 and vec_in.buf.is_cuda and type(self).single_rank_shortcut
+                and self._max_row_nnz <= 16):
             # one rank holds every time row of every space dof already: the transposes
-            # of the reference (mpi_kron.py:246-253) have nothing to exchange, the
-            # dense time factor acts on the contiguous time column of each dof
-            if self._dense_dev is None:
-                self._dense_dev = _lib.to_dev(self._dense)
-            _lib.check(_lib.lib().stk_time_dense_apply(
-                _lib.stream(), vec_in.M, self.N, vec_in.ld, self.N, vec_out.ld,
-                _lib.ptr(self._dense_dev), _lib.ptr(vec_in.buf), _lib.ptr(vec_out.buf)))
+            # of the reference (mpi_kron.py:246-253) have nothing to exchange, the time
+            # factor acts on the contiguous time column of each dof -- through its
+            # non-zero entries (stk_time_csr_apply; the wavelet matrix has N log N of N^2)
+            if self._local_csr is None:
+                rows, cols = np.nonzero(self._dense)
+                self._local_csr = _TimeCSR(self.N, list(rows), list(cols),
+                                           list(self._dense[rows, cols]))
+            self._local_csr.apply(vec_in, None, False, vec_out)
             vec_out.communicated_bdr = False
             return vec_out
         vec_perm, comm_time = vec_in.permute()
