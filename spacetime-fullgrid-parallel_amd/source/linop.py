@@ -184,6 +184,30 @@ def union_pattern(mats):
             m.sort_indices()
         m.sum_duplicates()
     assert len(mats) <= 30
+    # the same large matrices are united more than once during a set-up (the Kronecker
+    # plan of S takes (M_x, A_x), the preconditioner family's finest level (A_x, M_x)):
+    # the last result is kept, keyed by the matrices' arrays, and handed out in the
+    # caller's order
+    keys = [(m.indptr.ctypes.data, m.indices.ctypes.data, m.data.ctypes.data, m.nnz) for m in mats]
+    if len(mats) == 1 or sum(m.nnz for m in mats) <= 1000000:
+        return _union_pattern(mats)
+    ident = frozenset(keys)
+    with _union_lock:
+        slot = _union_slots.get(ident)
+        if slot is None:
+            _union_slots.clear()  # one entry: these arrays are large
+            slot = _union_slots[ident] = {'lock': threading.Lock()}
+    with slot['lock']:  # whoever comes second (the plans are built side by side) waits
+        if 'value' not in slot:
+            slot['value'] = (keys, _union_pattern(mats), mats)  # mats: the keys hold addresses
+    h_keys, (h_ptr, h_idx, h_vals), _ = slot['value']
+    return h_ptr, h_idx, [h_vals[h_keys.index(k)] for k in keys]
+
+
+_union_slots, _union_lock = {}, threading.Lock()
+
+
+def _union_pattern(mats):
     if len(mats) == 1:  # nothing to unite
         m = mats[0]
         return (np.asarray(m.indptr, dtype=np.int32), np.asarray(m.indices, dtype=np.int32),
