@@ -24,6 +24,7 @@ extern int g_plan_pack_rows;                                   // plan.hip
 int stk_rows_ell_set_tuning(const char *key, int32_t value);  // rows_ell.hip
 int stk_wavelet_set_tuning(const char *key, int32_t value);   // wavelet.hip
 extern int g_mg_gs_diag_free;  // mg_build.hip
+extern int g_mg_restrict_one_pass;  // mg.hip
 extern int g_mg_fuse_coarse, g_mg_coarse_max_rows, g_mg_fuse_restrict, g_mg_zero_start, g_mg_strip_mb, g_mg_strips_used, g_mg_strip_width;  // mg.hip
 extern int g_mg_coarse_pairs, g_mg_coarse_lds, g_mg_coarse_uniform;  // mg_coarse.hip
 
@@ -466,6 +467,10 @@ extern "C" int stk_set_tuning(const char *key, int32_t value)
     }
     if (std::strcmp(key, "mg_coarse_lds") == 0) {
         g_mg_coarse_lds = value;
+        return 0;
+    }
+    if (std::strcmp(key, "mg_restrict_one_pass") == 0) {
+        g_mg_restrict_one_pass = value;
         return 0;
     }
     if (std::strcmp(key, "mg_coarse_uniform") == 0) {

@@ -102,11 +102,13 @@ int g_mg_strip_mb = 250;        // strip-wise smoothing: working set (u and f) o
                                 // (measured at J_time=6/J_space=9: 120 -> 250 MB is 4.5 % on S and P, 400 the same)
 int g_mg_zero_start = 1;        // 0: zero u in memory and run the first sweep like the others
 int g_mg_fuse_restrict = 1;     // 0: residual and restriction as two steps
+int g_mg_restrict_one_pass = 1; // 0: (R A) u - R f as two passes of the row engine
 int g_mg_fuse_coarse = 1;       // 0 disables the fused coarse sub-V-cycle
 int g_mg_coarse_max_rows = 4096;  // levels up to this many rows may be fused (larger ones fill the GPU by themselves)
 
 struct EllLevel {
     bool has_a = false, has_gs = false, has_p = false, has_r = false, has_ra = false, has_alt = false;
+    bool ra_rows_as_r = false;  // R A and R list the same rows in the same order (checked at plan creation)
     stk_ell_rows a, fwd, bwd, p, r, ra;
     stk_ell_rows fwd_alt, bwd_alt;  // the sweeps' copies in the other row form (early V-cycles)
     std::vector<stk_ell_rows> fwd0;  // per forward group: entries towards earlier groups only
@@ -353,11 +355,23 @@ static int mgm(stk_mg *mg, hipStream_t st, int j, int n_loc, int ld, double ca, 
                                ((j >= mg->fuse_min_level && j <= mg->fuse_max_level) || cycle < mg->fast_until_cycle ||
                                 (mg->fast_parts & 2));
     if (fuse_restrict && E.has_ra && E.has_r && even) {
-        // d_c = R (A_j u_j - f_j) = (R A_j) u_j - R f_j: the fine residual is never written
-        rc = stk_rows_ell_launch(st, 0, &E.r, 0, E.r.n_pos, n_loc, ld, L.n, C.n, 1.0, nullptr, f_j, 1.0, 0.0, nullptr,
-                                 d_c);
-        if (rc) return rc;
-        rc = stk_rows_ell_launch(st, 0, &E.ra, 0, E.ra.n_pos, n_loc, ld, L.n, C.n, ca, cm, u_j, 1.0, -1.0, d_c, d_c);
+        // d_c = R (A_j u_j - f_j) = (R A_j) u_j - R f_j: the fine residual is never written.
+        // One pass where the two matrices list the same rows (tuning key mg_restrict_one_pass;
+        // the very roundings of the two passes), else d_c = R f_j, then d_c = (R A_j) u_j - d_c.
+        // Key 1 (default): only for matrices with per-slice coefficients (the preconditioner
+        // family: P 5.54 -> 5.39 ms on 9-step slabs, 21.7 -> 21.5 ms on 65); K's plans, which run
+        // two at a time inside S, measure SLOWER with it (S 3.31 -> 3.37 ms, 16.9 -> 17.2 ms:
+        // profiles/r04_restrict_one_pass_ab.log).  Key 2: every plan.
+        rc = (g_mg_restrict_one_pass && E.ra_rows_as_r && (cm != nullptr || g_mg_restrict_one_pass >= 2))
+                 ? stk_rows_ell2_launch(st, &E.ra, &E.r, n_loc, ld, L.n, C.n, ca, cm, u_j, f_j, d_c)
+                 : -1;
+        if (rc == -1) {
+            rc = stk_rows_ell_launch(st, 0, &E.r, 0, E.r.n_pos, n_loc, ld, L.n, C.n, 1.0, nullptr, f_j, 1.0, 0.0,
+                                     nullptr, d_c);
+            if (rc) return rc;
+            rc = stk_rows_ell_launch(st, 0, &E.ra, 0, E.ra.n_pos, n_loc, ld, L.n, C.n, ca, cm, u_j, 1.0, -1.0, d_c,
+                                     d_c);
+        }
         if (rc) return rc;
     } else {
         // r_j = A_j u_j - f_j
@@ -413,6 +427,19 @@ extern "C" int stk_mg_create(int32_t n_levels, const stk_mg_level *levels, int32
         if (L.ell_p) { E.p = *L.ell_p; E.has_p = true; }
         if (L.ell_r) { E.r = *L.ell_r; E.has_r = true; }
         if (L.ell_ra) { E.ra = *L.ell_ra; E.has_ra = true; }
+        if (E.has_ra && E.has_r && E.ra.n_pos == E.r.n_pos && E.ra.n_pos > 0) {
+            // the one-pass restricted residual pairs position p of R A with position p of R
+            if (E.ra.row_ids == E.r.row_ids) {
+                E.ra_rows_as_r = true;
+            } else if (E.ra.row_ids && E.r.row_ids) {
+                std::vector<int32_t> ra_rows(E.ra.n_pos), r_rows(E.r.n_pos);
+                if (hipMemcpy(ra_rows.data(), E.ra.row_ids, sizeof(int32_t) * ra_rows.size(), hipMemcpyDeviceToHost) ==
+                        hipSuccess &&
+                    hipMemcpy(r_rows.data(), E.r.row_ids, sizeof(int32_t) * r_rows.size(), hipMemcpyDeviceToHost) ==
+                        hipSuccess)
+                    E.ra_rows_as_r = ra_rows == r_rows;
+            }
+        }
         if (L.ell_fwd0 && L.n_fwd > 0) E.fwd0.assign(L.ell_fwd0, L.ell_fwd0 + L.n_fwd);
         if (L.ell_fwd && L.ell_bwd && L.fwd_pos_host && L.bwd_pos_host) {
             E.fwd = *L.ell_fwd;

@@ -206,6 +206,171 @@ __global__ __launch_bounds__(BS, K >= 12 ? 4 : 6) void rows_ell_kernel(const Row
     }
 }
 
+// ---- the restricted residual in ONE pass: y = A(t) x - B x2 ------------------------
+// d_c = (R A_j) u_j - R f_j (mg.hip: the fine residual is never formed) took two passes
+// of the engine above -- d_c = R f_j, then d_c = (R A_j) u_j - d_c -- i.e. d_c written,
+// read and written again, and a launch more on every level visit.  Here a row gathers
+// its K entries of the first matrix from x and accumulates s (as the second pass did),
+// then its K2 entries of the second matrix from x2 and accumulates s2 (as the first
+// pass did, values unscaled), and stores fma(-1, s2, s): the very roundings of the two
+// passes.  Same skeleton as rows_ell_kernel; both matrices list the same rows in the
+// same order.
+struct Rows2Args {
+    RowsArgs a;              // first matrix, x, y as in the engine (alpha = 1, beta unused)
+    const int32_t *idx2;     // [n_pos][K2]
+    const double *va2;       // [n_pos][K2]
+    const double *x2;
+    uint32_t x2_bytes;
+};
+
+template <int K, int K2, int NPF, bool HAS_M, bool WIDE>
+__global__ __launch_bounds__(BS, 4) void rows_ell2_kernel(const Rows2Args b)
+{
+    const RowsArgs &a = b.a;
+    constexpr int KS = (K + 3) & ~3, KS2 = (K2 + 3) & ~3;
+    extern __shared__ double sm[];
+    const int R = a.R, W = a.P;
+    // two LDS buffers of {va[R][KS], vm[R][KS], va2[R][KS2], off[R][KS], off2[R][KS2], row[R]}
+    const int val_doubles = (HAS_M ? 2 : 1) * R * KS + R * KS2;
+    const int buf_doubles = (val_doubles + (R * KS + R * KS2 + R + 1) / 2 + 2) & ~1;
+    const int tid = threadIdx.x;
+    const int r = tid / W;
+    const int p = tid - r * W;
+    const bool lane_ok = r < R;
+    const int t0 = 2 * p;
+    const bool has1 = t0 + 1 < a.n_loc;
+    const uint32_t ld_bytes = stk_slab<WIDE>::row_stride(a.ld);
+    const uint32_t t0_bytes = (uint32_t)t0 * 8u;
+    const stk_slab<WIDE> sx(a.x, a.x_bytes), sx2(b.x2, b.x2_bytes), sy(a.y, a.y_bytes);
+
+    double cm0 = 0.0, cm1 = 0.0;
+    if (HAS_M && lane_ok) {
+        cm0 = a.cm[t0];
+        if (has1) cm1 = a.cm[t0 + 1];
+    }
+    const int xcd = blockIdx.x & 7;
+    const int step = gridDim.x >> 3;
+    const int gend = min((xcd + 1) * a.chunk, a.ngroups);
+    int g = xcd * a.chunk + (int)(blockIdx.x >> 3);
+
+    int32_t pidx[NPF], pidx2[NPF];
+    double pva[NPF], pvm[NPF], pva2[NPF];
+    int32_t prow = 0;
+#pragma unroll
+    for (int q = 0; q < NPF; ++q) {
+        pidx[q] = pidx2[q] = 0;
+        pva[q] = pvm[q] = pva2[q] = 0.0;
+    }
+    auto load_group = [&](int gq) {
+        const int gg = a.reverse ? (a.ngroups - 1 - gq) : gq;
+        const int first = a.pos_begin + gg * R;
+        const int rows = min(R, a.pos_end - first);
+        const size_t base = (size_t)first * K, base2 = (size_t)first * K2;
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) {
+            const int i = tid + q * BS;
+            if (i < rows * K) {
+                pidx[q] = a.idx[base + i];
+                pva[q] = a.va[base + i];
+                if (HAS_M) pvm[q] = a.vm[base + i];
+            }
+            if (i < rows * K2) {
+                pidx2[q] = b.idx2[base2 + i];
+                pva2[q] = b.va2[base2 + i];
+            }
+        }
+        if (tid < rows) prow = a.row_ids ? a.row_ids[first + tid] : first + tid;
+    };
+    if (g < gend) load_group(g);
+
+    int flip = 0;
+    for (; g < gend; g += step, flip ^= 1) {
+        double *b_va = sm + flip * buf_doubles;
+        double *b_vm = b_va + R * KS;
+        double *b_va2 = b_va + (HAS_M ? 2 : 1) * R * KS;
+        uint32_t *b_off = reinterpret_cast<uint32_t *>(b_va2 + R * KS2);
+        uint32_t *b_off2 = b_off + R * KS;
+        uint32_t *b_row = b_off2 + R * KS2;
+
+        const int first = a.pos_begin + (a.reverse ? (a.ngroups - 1 - g) : g) * R;
+        const int rows = min(R, a.pos_end - first);
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) {
+            const int i = tid + q * BS;
+            if (i < rows * K) {
+                const int at = (i / K) * KS + (i % K);
+                b_off[at] = (uint32_t)pidx[q] * ld_bytes;
+                b_va[at] = a.ca * pva[q];
+                if (HAS_M) b_vm[at] = pvm[q];
+            }
+            if (i < rows * K2) {
+                const int at = (i / K2) * KS2 + (i % K2);
+                b_off2[at] = (uint32_t)pidx2[q] * ld_bytes;
+                b_va2[at] = pva2[q];  // (1.0 * va: what the separate pass multiplied with)
+            }
+        }
+        if (tid < rows) b_row[tid] = (uint32_t)prow * ld_bytes;
+        __syncthreads();
+        if (g + step < gend) load_group(g + step);  // in flight behind the gathers
+
+        if (lane_ok && r < rows) {
+            const uint32_t yo = b_row[r];
+            double s0 = 0.0, s1 = 0.0;
+            {
+                const uint32_t *so = b_off + r * KS;
+                const double *sva = b_va + r * KS;
+                const double *svm = b_vm + r * KS;
+                double2 xv[K];
+#pragma unroll
+                for (int u = 0; u < K; ++u) xv[u] = sx.load(so[u], t0_bytes);
+#pragma unroll
+                for (int u = 0; u < K; ++u) {
+                    double v0 = sva[u], v1 = v0;
+                    if (HAS_M) {
+                        const double m = svm[u];
+                        v0 = fma(cm0, m, v0);
+                        v1 = fma(cm1, m, v1);
+                    }
+                    s0 = fma(v0, xv[u].x, s0);
+                    s1 = fma(v1, xv[u].y, s1);
+                }
+            }
+            double z0 = 0.0, z1 = 0.0;
+            {
+                const uint32_t *so2 = b_off2 + r * KS2;
+                const double *sva2 = b_va2 + r * KS2;
+                double2 xw[K2];
+#pragma unroll
+                for (int u = 0; u < K2; ++u) xw[u] = sx2.load(so2[u], t0_bytes);
+#pragma unroll
+                for (int u = 0; u < K2; ++u) {
+                    z0 = fma(sva2[u], xw[u].x, z0);
+                    z1 = fma(sva2[u], xw[u].y, z1);
+                }
+            }
+            // second pass of the two-pass form: o = 1 * s, then fma(-1, z, o)
+            double o0 = fma(-1.0, z0, s0), o1 = fma(-1.0, z1, s1);
+            if (!has1) o1 = 0.0;  // padding slot stays zero
+            sy.store(yo, t0_bytes, make_double2(o0, o1));
+        }
+    }
+}
+
+template <int K, int K2, bool HAS_M, bool WIDE>
+int launch2_npf(hipStream_t st, const Rows2Args &b, unsigned grid, size_t lds)
+{
+    const int npf = (b.a.R * K + BS - 1) / BS;
+    STK_REQUIRE(lds <= 64 * 1024, "rows_ell2: %zu bytes of LDS per workgroup", lds);
+    if (npf <= 1)
+        hipLaunchKernelGGL((rows_ell2_kernel<K, K2, 1, HAS_M, WIDE>), dim3(grid), dim3(BS), lds, st, b);
+    else if (npf <= 2)
+        hipLaunchKernelGGL((rows_ell2_kernel<K, K2, 2, HAS_M, WIDE>), dim3(grid), dim3(BS), lds, st, b);
+    else
+        hipLaunchKernelGGL((rows_ell2_kernel<K, K2, 4, HAS_M, WIDE>), dim3(grid), dim3(BS), lds, st, b);
+    STK_LAUNCH_CHECK();
+    return 0;
+}
+
 int g_rows_wg_per_cu = 0;
 int g_rows_force_wide = 0;  // testing: 64-bit addressing on small slabs
 int g_rows_alternate = 1;   // alternate the walking direction between launches
@@ -332,6 +497,73 @@ int stk_rows_ell_launch(hipStream_t st, int mode, const stk_ell_rows *e, int32_t
     if (mode == MODE_GS)
         return has_m ? launch_k<MODE_GS, true>(st, a, K, grid, lds) : launch_k<MODE_GS, false>(st, a, K, grid, lds);
     return has_m ? launch_k<MODE_SPMM, true>(st, a, K, grid, lds) : launch_k<MODE_SPMM, false>(st, a, K, grid, lds);
+}
+
+// y = A(t) x - B x2 for the instantiated pair of slot counts (20, 7): the restricted
+// residual of mg.hip.  Returns -1 when this pair of matrices has no instantiation (the
+// caller then takes the two passes).
+int stk_rows_ell2_launch(hipStream_t st, const stk_ell_rows *e, const stk_ell_rows *e2, int32_t n_loc, int32_t ld,
+                         int64_t x_rows, int64_t y_rows, double ca, const double *cm, const double *x,
+                         const double *x2, double *y)
+{
+    if (e->K != 20 || e2->K != 7 || e->n_pos != e2->n_pos || e->n_pos <= 0) return -1;
+    STK_REQUIRE(e->idx && e->va && e2->idx && e2->va, "rows_ell2: incomplete matrix");
+    STK_REQUIRE((cm == nullptr) || e->vm, "rows_ell2: cm given but the matrix has no vm");
+    STK_REQUIRE(n_loc > 0 && ld >= n_loc && (ld & 1) == 0, "rows_ell2: bad n_loc=%d ld=%d", n_loc, ld);
+    STK_REQUIRE(x_rows * ld * 8 < ((int64_t)1 << 36) && y_rows * ld * 8 < ((int64_t)1 << 36), "rows_ell2: slab exceeds 64 GiB");
+    STK_REQUIRE((((uintptr_t)x | (uintptr_t)x2 | (uintptr_t)y) & 15) == 0, "rows_ell2: slabs must be 16-byte aligned");
+    STK_REQUIRE((n_loc + 1) / 2 <= BS, "rows_ell2: n_loc too large");
+    constexpr int K = 20, K2 = 7, KS = 20, KS2 = 8;
+    Rows2Args b;
+    RowsArgs &a = b.a;
+    a.idx = e->idx;
+    a.va = e->va;
+    a.vm = cm ? e->vm : nullptr;
+    a.row_ids = e->row_ids;
+    a.dia_a = a.dia_m = nullptr;
+    a.cm = cm;
+    a.x = x;
+    a.z = y;
+    a.y = y;
+    a.ca = ca;
+    a.alpha = 1.0;
+    a.beta = 0.0;
+    a.pos_begin = 0;
+    a.pos_end = e->n_pos;
+    a.n_loc = n_loc;
+    a.ld = ld;
+    a.P = (n_loc + 1) / 2;
+    a.R = BS / a.P;
+    if (a.R * K > 4 * BS) a.R = 4 * BS / K;  // at most 4 prefetched entries per thread and matrix
+    a.ngroups = (e->n_pos + a.R - 1) / a.R;
+    a.chunk = (a.ngroups + 7) / 8;
+    a.reverse = g_rows_alternate ? (int)(g_rows_launch_count++ & 1u) : 0;
+    a.zero_own = 0;
+    a.wide = g_rows_force_wide || x_rows * ld * 8 >= ((int64_t)1 << 32) || y_rows * ld * 8 >= ((int64_t)1 << 32);
+    a.x_bytes = a.wide ? 0u : (uint32_t)(x_rows * ld * 8);
+    a.y_bytes = a.wide ? 0u : (uint32_t)(y_rows * ld * 8);
+    b.idx2 = e2->idx;
+    b.va2 = e2->va;
+    b.x2 = x2;
+    b.x2_bytes = a.x_bytes;
+    const bool has_m = cm != nullptr;
+    auto lds_of = [&](int R) {
+        const size_t val_doubles = (size_t)(has_m ? 2 : 1) * R * KS + (size_t)R * KS2;
+        const size_t buf_doubles = (val_doubles + ((size_t)R * KS + (size_t)R * KS2 + R + 1) / 2 + 2) & ~(size_t)1;
+        return 2 * buf_doubles * sizeof(double) + 16;
+    };
+    while (a.R > 1 && lds_of(a.R) > 60 * 1024) --a.R;  // short slabs: two workgroups per CU keep their LDS
+    a.ngroups = (e->n_pos + a.R - 1) / a.R;
+    a.chunk = (a.ngroups + 7) / 8;
+    const size_t lds = lds_of(a.R);
+    const int n_cu = stk_cu_count();
+    int per_xcd = (n_cu / 8) * 2;
+    if (per_xcd > a.chunk) per_xcd = a.chunk;
+    if (per_xcd < 1) per_xcd = 1;
+    const unsigned grid = (unsigned)per_xcd * 8;
+    if (has_m)
+        return a.wide ? launch2_npf<K, K2, true, true>(st, b, grid, lds) : launch2_npf<K, K2, true, false>(st, b, grid, lds);
+    return a.wide ? launch2_npf<K, K2, false, true>(st, b, grid, lds) : launch2_npf<K, K2, false, false>(st, b, grid, lds);
 }
 
 extern "C" int stk_ell_spmm(void *stream, const stk_ell_rows *ell, int32_t n_loc, int32_t ld, int32_t x_rows,

@@ -90,6 +90,12 @@ int stk_rows_ell_launch(hipStream_t st, int mode, const stk_ell_rows *e, int32_t
                         int32_t n_loc, int32_t ld, int64_t x_rows, int64_t y_rows, double ca, const double *cm,
                         const double *x, double alpha, double beta, const double *z, double *y, int zero_own = 0);
 
+// y = A(t) x - B x2 in one pass (the restricted residual (R A) u - R f); -1: no
+// instantiation for this pair of matrices, take the two passes.
+int stk_rows_ell2_launch(hipStream_t st, const stk_ell_rows *e, const stk_ell_rows *e2, int32_t n_loc, int32_t ld,
+                         int64_t x_rows, int64_t y_rows, double ca, const double *cm, const double *x,
+                         const double *x2, double *y);
+
 // ---- slab access from device code (kron_ell.hip, rows_ell.hip, mg_coarse.hip) -----
 #if defined(__HIPCC__)
 typedef int stk_v4i __attribute__((ext_vector_type(4)));

@@ -581,6 +581,30 @@ def test_wide_slab_addressing_matches(stk):
             stk.check(stk.lib().stk_set_tuning(key, 0))
 
 
+def test_restricted_residual_in_one_pass_is_exact(stk):
+    """(R A) u - R f in ONE pass of a two-matrix row kernel (csrc/rows_ell.hip,
+    rows_ell2_kernel; tuning key mg_restrict_one_pass) against the two passes of the row
+    engine it replaces -- d = R f, then d = (R A) u - d: the same sums and the same final
+    fused multiply-add, so K^-1, S and P must not change by a bit; one matrix and the
+    family's per-slice coefficients, slabs of 3 / 9 / 17 / 65 steps (lane, group and
+    prefetch instances), 64-bit addressing forced."""
+    import heateq_mpi as hm
+    for J_time, J_space, wide in ((1, 5, 0), (3, 6, 0), (4, 5, 1), (6, 4, 0)):
+        h = hm.HeatEquationMPI(J_space=J_space, J_time=J_time, arithmetic='fast')
+        x = _vec(h.dofs_distr, np.random.RandomState(23).rand(h.N, h.M))
+        res = []
+        try:
+            stk.check(stk.lib().stk_set_tuning(b'rows_force_wide', wide))
+            for one_pass in (0, 2):  # 2: every plan (the default, 1, leaves K's plans on two passes)
+                stk.check(stk.lib().stk_set_tuning(b'mg_restrict_one_pass', one_pass))
+                res.append((_np(h.S @ x), _np(h.P @ x)))
+        finally:
+            stk.check(stk.lib().stk_set_tuning(b'mg_restrict_one_pass', 1))
+            stk.check(stk.lib().stk_set_tuning(b'rows_force_wide', 0))
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]), (J_time, J_space)
+        assert np.isfinite(res[1][1]).all()
+
+
 def test_coarse_subcycle_variants_agree(stk):
     """The coarse end of the V-cycle runs level by level, as one job-list
     kernel on global workspaces, or as one kernel with all level vectors in LDS
