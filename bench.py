@@ -281,6 +281,8 @@ def main():
                     help='time budget of each leg (1 core, all cores) of the CPU baseline')
     ap.add_argument('--preheat', type=float, default=0.5,
                     help='seconds of untimed applies before the warm-up steps')
+    ap.add_argument('--cpu-baseline-only', action='store_true',
+                    help='(internal) run the CPU baseline alone and print its record as JSON')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'RANK' not in os.environ:
@@ -304,18 +306,34 @@ def main():
     M_x, A_x = space_matrices(mesh_space, scipy_path=True)
     N, M = A_t.shape[0], M_x.shape[0]
 
-    # CPU baseline first: nothing has touched the GPU yet, so its process pool
-    # can fork (rank 0 of a one-GPU run only)
+    # CPU baseline first: nothing has touched the GPU yet (rank 0 of a one-GPU run only).
+    # It runs in a CHILD process of its own, so that the process that times the GPU has
+    # never held the baseline's host arrays or forked its pool of workers.  (On one box
+    # the Kronecker kernel took 0.291-0.296 ms in runs WITH the baseline and 0.273-0.275 ms
+    # in runs without, whichever process ran it -- profiles/r04_bench_baseline_in_process.log;
+    # on another box 0.291 ms either way.  The cause was not found; the boxes of the pool
+    # differ by that much anyway.)
     cpu = None
+    if args.cpu_baseline_only:
+        nb = 16 * N * M + 12 * (M_x.nnz + A_x.nnz) + 8 * (M + 1)
+        print(json.dumps(cpu_baseline(A_t, M_t, M_x, A_x, N, M, nb, args.cpu_seconds)))
+        return
     if profiler_preloaded() and not args.no_cpu_baseline:
         # a profiler's preloaded library has initialised the GPU before main():
-        # forking the baseline's process pool from here is not allowed
+        # starting other processes from here is not allowed
         args.no_cpu_baseline = True
         print('bench.py: profiler preload detected, CPU baseline skipped', file=sys.stderr)
     if (int(os.environ.get('RANK', '0')) == 0 and args.gpus == 1
             and int(os.environ.get('WORLD_SIZE', '1')) == 1 and not args.no_cpu_baseline):
-        nb = 16 * N * M + 12 * (M_x.nnz + A_x.nnz) + 8 * (M + 1)
-        cpu = cpu_baseline(A_t, M_t, M_x, A_x, N, M, nb, args.cpu_seconds)
+        import subprocess
+        child = subprocess.run(
+            [sys.executable, os.path.abspath(__file__), '--cpu-baseline-only', '--J_time', str(args.J_time),
+             '--J_space', str(args.J_space), '--problem', args.problem, '--cpu-seconds', str(args.cpu_seconds)],
+            capture_output=True, text=True)
+        lines = [ln for ln in child.stdout.splitlines() if ln.startswith('{')]
+        if child.returncode != 0 or not lines:
+            sys.exit('bench.py: the CPU baseline failed:\n' + child.stdout[-2000:] + child.stderr[-2000:])
+        cpu = json.loads(lines[-1])
 
     import torch
     from source.comm import MPI
