@@ -71,8 +71,8 @@ def cpu_baseline(A_t, M_t, M_x, A_x, N, M, nbytes, budget_s=10.0):
     host cores of this box, protocol of reference heateq_mpi_timing.py:81-102
     (seeded vector, warm-up, repeated applies): the WHOLE N time rows on one
     core, and on all cores as independent time slabs in a process pool
-    (SURVEY.md section 8d).  Runs before anything touches the GPU, so the pool
-    can fork."""
+    (SURVEY.md section 8d).  Runs in a process that never touches the GPU (bench.py
+    starts itself with --cpu-baseline-only as a child), so the pool can fork."""
     import multiprocessing as mp
     import platform
     from oracle import kron as okron
@@ -306,25 +306,26 @@ def main():
     M_x, A_x = space_matrices(mesh_space, scipy_path=True)
     N, M = A_t.shape[0], M_x.shape[0]
 
-    # CPU baseline first: nothing has touched the GPU yet (rank 0 of a one-GPU run only).
-    # It runs in a CHILD process of its own, so that the process that times the GPU has
-    # never held the baseline's host arrays or forked its pool of workers.  (On one box
-    # the Kronecker kernel took 0.291-0.296 ms in runs WITH the baseline and 0.273-0.275 ms
-    # in runs without, whichever process ran it -- profiles/r04_bench_baseline_in_process.log;
-    # on another box 0.291 ms either way.  The cause was not found; the boxes of the pool
-    # differ by that much anyway.)
+    # The CPU baseline (rank 0 of a one-GPU run only) runs in a CHILD process, and LAST:
+    # see run_cpu_baseline below.
     cpu = None
     if args.cpu_baseline_only:
         nb = 16 * N * M + 12 * (M_x.nnz + A_x.nnz) + 8 * (M + 1)
         print(json.dumps(cpu_baseline(A_t, M_t, M_x, A_x, N, M, nb, args.cpu_seconds)))
         return
     if profiler_preloaded() and not args.no_cpu_baseline:
-        # a profiler's preloaded library has initialised the GPU before main():
-        # starting other processes from here is not allowed
+        # under a profiler the program must not start other processes
         args.no_cpu_baseline = True
         print('bench.py: profiler preload detected, CPU baseline skipped', file=sys.stderr)
-    if (int(os.environ.get('RANK', '0')) == 0 and args.gpus == 1
-            and int(os.environ.get('WORLD_SIZE', '1')) == 1 and not args.no_cpu_baseline):
+
+    def run_cpu_baseline():
+        """The baseline in a process of its own, started as a child AFTER every GPU
+        measurement of this run is complete.  On some boxes of the pool the Kronecker
+        kernel runs 6 % slower for many seconds after all host cores have been busy --
+        0.291-0.296 ms in runs that had the baseline before the GPU part, 0.273-0.275 ms
+        in runs without it, whichever process ran the baseline
+        (profiles/r04_bench_baseline_in_process.log); other boxes do not care.  The
+        timed GPU region should not depend on what this script did to the host before."""
         import subprocess
         child = subprocess.run(
             [sys.executable, os.path.abspath(__file__), '--cpu-baseline-only', '--J_time', str(args.J_time),
@@ -333,7 +334,7 @@ def main():
         lines = [ln for ln in child.stdout.splitlines() if ln.startswith('{')]
         if child.returncode != 0 or not lines:
             sys.exit('bench.py: the CPU baseline failed:\n' + child.stdout[-2000:] + child.stderr[-2000:])
-        cpu = json.loads(lines[-1])
+        return json.loads(lines[-1])
 
     import torch
     from source.comm import MPI
@@ -498,6 +499,9 @@ def main():
 
     if rank != 0:
         return
+    if args.gpus == 1 and size == 1 and not args.no_cpu_baseline:
+        torch.cuda.synchronize()
+        cpu = run_cpu_baseline()
     achieved = my_bytes / (kernel_ms * 1e-3) / 1e9
     kernel = fused.kernel_name(n_loc)
     traffic, traffic_src = pmc_traffic(args, size, kernel)

@@ -11,7 +11,7 @@ elif mode == 'forkidle':
 elif mode == 'child':
     import subprocess
     subprocess.run([sys.executable, '-c', 'import time; time.sleep(%f)' % burn])
-elif burn > 0:
+elif burn > 0:  # 'fork' and 'recover'
     import multiprocessing as mp
     def spin(t):
         t0=time.time(); a=np.random.rand(512,512)
@@ -34,8 +34,13 @@ def step():
     x._invalidate(); op._matvec(x,y)
 for _ in range(200): step()
 torch.cuda.synchronize()
-for rep in range(3):
+pauses = [0, 0, 0] + ([15, 15, 15, 15] if mode == 'recover' else [])
+for pause in pauses:
+    if pause:
+        time.sleep(pause)
+        for _ in range(50): step()
+        torch.cuda.synchronize()
     t0=time.perf_counter()
     for _ in range(200): step()
     t1=time.perf_counter(); torch.cuda.synchronize(); t2=time.perf_counter()
-    print(mode, 'burn %.0f s: host enqueue %.1f us per step, total %.1f us per step' % (burn, (t1-t0)/200*1e6, (t2-t0)/200*1e6), flush=True)
+    print(mode, 'pause %2d' % pause, 'burn %.0f s: host enqueue %.1f us per step, total %.1f us per step' % (burn, (t1-t0)/200*1e6, (t2-t0)/200*1e6), flush=True)
