@@ -397,6 +397,8 @@ class HeatEquationMPI:
             _lib.stream(), self.M, self.rhs.n_loc, self.rhs.ld, _lib.ptr(u_t),
             _lib.ptr(u_x), _lib.ptr(self.rhs.buf)))
 
+        from source.linop import forget_union_pattern
+        forget_union_pattern()
         mark('operators and right-hand side')
         self.setup_time = MPI.Wtime() - start_time
         self.mem_after_mpi = mem()

@@ -207,6 +207,13 @@ def union_pattern(mats):
 _union_slots, _union_lock = {}, threading.Lock()
 
 
+def forget_union_pattern():
+    """Drops the kept union pattern (HeatEquationMPI calls it when its plans are built:
+    the arrays are as large as the matrices)."""
+    with _union_lock:
+        _union_slots.clear()
+
+
 def _union_pattern(mats):
     if len(mats) == 1:  # nothing to unite
         m = mats[0]
