@@ -33,11 +33,13 @@ XGMI_LINK_GBS_PER_DIRECTION = 76.8  # xGMI: 7 point-to-point links per GPU, ~153
 
 
 def seeded_slab(t_begin, t_end, M):
-    """Rows [t_begin, t_end) of the reference's timing vector: `np.random.seed(128);
-    np.random.rand(N, M)` drawn GLOBALLY and then sliced (reference
-    heateq_mpi_timing.py:81-83), so that every rank count
-    sees the same global vector.  The generator's stream is row-major: the rows
-    before the slab are drawn and dropped one at a time."""
+    """Rows [t_begin, t_end) of ONE global vector `np.random.RandomState(128).rand(N, M)`
+    (drawn globally and then sliced, so that every rank count
+    sees the same data).  On one rank this is the reference's timing vector
+    (heateq_mpi_timing.py:81-83); on several ranks it deliberately DEVIATES from the
+    reference, which seeds 128 on every rank and draws rand(*X_loc.shape) locally, so
+    that all its ranks hold the same leading rows.  The generator's stream is
+    row-major: the rows before the slab are drawn and dropped one at a time."""
     rs = np.random.RandomState(128)
     for _ in range(t_begin):
         rs.rand(M)
@@ -117,13 +119,62 @@ def cpu_baseline(A_t, M_t, M_x, A_x, N, M, nbytes, budget_s=10.0):
     }
 
 
-KERNEL_SOURCES = ('csrc/kron_pack.hip', 'csrc/kron_ell.hip', 'csrc/stk_common.h',
-                  'csrc/plan.hip', 'source/linop.py')
+def pcg_cpu_baseline(problem, J_time, J_space):
+    """ONE iteration of PCG(W^T S W, P, rhs) through the CPU oracle -- the loop the
+    reference times (heateq_mpi.py:281-288; operators wired as heateq_mpi.py:166-185:
+    five-term S with four multigrid applies, per-level wavelet steps, block-diagonal
+    P) -- on the host cores of this box: time slices are independent in every space
+    operator, so batches of slices run side by side on all cores
+    (oracle.multigrid.THREADS; the sweeps themselves are the C restatement
+    oracle/gs.c, the rest SciPy).  The iteration timed is the first one (from
+    `t = T p` to the update of p); one iteration is the whole sample: at config 3
+    it is tens of seconds of CPU work."""
+    from oracle import multigrid as omg
+    from oracle.heat import HeatEquationOracle
+    from oracle.krylov import _dot
+    from source.assembly import prolongation_matrices, space_load, space_matrices, time_matrices
+    from source.problem import problem_helper
+    cores = len(os.sched_getaffinity(0))
+    omg.THREADS = cores
+    t_setup = time.perf_counter()
+    mesh, _, tmesh, data, _ = problem_helper(problem, J_space, J_time)
+    A_t, L_t, M_t, G_t, u0_t = time_matrices(tmesh)
+    M_x, A_x = space_matrices(mesh, scipy_path=True)
+    o = HeatEquationOracle(dict(A_t=A_t, L_t=L_t, M_t=M_t, G_t=G_t, M_x=M_x, A_x=A_x,
+                                P_mats=prolongation_matrices(mesh), u0_t=u0_t,
+                                u0_x=space_load(mesh, data['u0'])), J_time)
+    b = o.rhs()
+    t_setup = time.perf_counter() - t_setup
+    w = np.zeros_like(b)
+    r = b.copy()
+    p = o.P(r)
+    abs_r = _dot(r, p)
+    tic = time.perf_counter()
+    t = o.WT_S_W(p)  # linalg.py:28-41
+    alpha = abs_r / _dot(p, t)
+    w += alpha * p
+    r -= alpha * t
+    z = o.P(r)
+    abs_r_new = _dot(r, z)
+    p *= abs_r_new / abs_r
+    p += z
+    dt = time.perf_counter() - tic
+    return {'value': 1.0 / dt, 'unit': 'iterations/s', 'cores': cores, 'kind': 'port',
+            's_per_iteration': dt, 'oracle_setup_s': t_setup,
+            'r_dot_Pr': [abs_r, abs_r_new],
+            'sample': 'iteration 1 of PCG(W^T S W, P, rhs), J_time=%d J_space=%d %s, all %d time '
+                      'rows, %d threads over independent time slices; one iteration = %.1f s'
+                      % (J_time, J_space, problem, o.N, cores, dt)}
+
+
+KERNEL_SOURCES = ('csrc/kron_pack.hip', 'csrc/stk_common.h')
 
 
 def kernel_source_sha():
-    """Identity of the build the PMC traffic figure belongs to: a hash of the
-    sources of the benched kernel and of its plan builder."""
+    """Identity of the CODE the PMC traffic figure belongs to: a hash of the
+    sources the benched kernel is compiled from (the kernel file and the header
+    it includes -- nothing else: round 4 hashed the whole of source/linop.py and
+    lost its record to an unrelated edit two minutes after the PMC pass)."""
     import hashlib
     h = hashlib.sha256()
     for rel in KERNEL_SOURCES:
@@ -131,13 +182,29 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(args, size, kernel):
+def plan_sha(packed):
+    """Identity of the DATA the kernel streams: a hash of the packed plan itself
+    (slot words, row list, dictionary, the sizes that fix the launch), whichever
+    planner built it.  Together with kernel_source_sha() this names what a PMC
+    record was measured on; an edit that changes neither cannot change the
+    kernel's traffic."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(np.array([packed.M, packed.K, packed.col_bits, packed.n_codes, packed.n_mats,
+                       packed.rows_per_unit, packed.n_units], dtype=np.int64).tobytes())
+    for arr in (packed.slots, packed.row_ids, packed.dict):
+        if arr is not None:
+            h.update(np.ascontiguousarray(arr.cpu().numpy()).tobytes())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(args, size, kernel, plan):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes
     (tools/pmc_passes.sh + tools/pmc_traffic.py: FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE, both KiB;
-    separate passes).  The record names the kernel and the source hash it was
-    measured on; a record of another kernel, build or configuration is refused
-    (null), not reported."""
+    separate passes).  The record names the kernel, the hash of the kernel's
+    sources and the hash of the plan it was measured on; a record of another
+    kernel, code, plan or configuration is refused (null), not reported."""
     import glob
     if size != 1:
         return None, None
@@ -146,12 +213,13 @@ def pmc_traffic(args, size, kernel):
         rec = json.load(open(path))
         if ((rec.get('J_time'), rec.get('J_space'), rec.get('problem')) == (
                 args.J_time, args.J_space, args.problem)
-                and rec.get('source_sha') == sha and rec.get('kernel', '') in kernel):
+                and rec.get('source_sha') == sha and rec.get('plan_sha') == plan
+                and rec.get('kernel', '') in kernel):
             return rec['hbm_bytes_per_launch'], {
                 'file': os.path.relpath(path, REPO), 'kernel': rec['kernel'],
-                'source_sha': sha, 'fetch_size_kib': rec.get('fetch_size_kib'),
+                'source_sha': sha, 'plan_sha': plan, 'fetch_size_kib': rec.get('fetch_size_kib'),
                 'write_size_kib': rec.get('write_size_kib')}
-    return None, {'source_sha': sha, 'note': 'no PMC record for this build'}
+    return None, {'source_sha': sha, 'plan_sha': plan, 'note': 'no PMC record for this code and plan'}
 
 
 def pcg_byte_model(h, n_loc):
@@ -311,7 +379,11 @@ def main():
     cpu = None
     if args.cpu_baseline_only:
         nb = 16 * N * M + 12 * (M_x.nnz + A_x.nnz) + 8 * (M + 1)
-        print(json.dumps(cpu_baseline(A_t, M_t, M_x, A_x, N, M, nb, args.cpu_seconds)))
+        rec = cpu_baseline(A_t, M_t, M_x, A_x, N, M, nb, args.cpu_seconds)
+        if args.solve_iters > 0:
+            rec['pcg'] = pcg_cpu_baseline(args.problem, args.J_time, args.J_space)
+            rec['pcg']['cpu_model'] = rec['cpu_model']
+        print(json.dumps(rec))
         return
     if profiler_preloaded() and not args.no_cpu_baseline:
         # under a profiler the program must not start other processes
@@ -329,7 +401,8 @@ def main():
         import subprocess
         child = subprocess.run(
             [sys.executable, os.path.abspath(__file__), '--cpu-baseline-only', '--J_time', str(args.J_time),
-             '--J_space', str(args.J_space), '--problem', args.problem, '--cpu-seconds', str(args.cpu_seconds)],
+             '--J_space', str(args.J_space), '--problem', args.problem, '--cpu-seconds', str(args.cpu_seconds),
+             '--solve-iters', str(args.solve_iters)],
             capture_output=True, text=True)
         lines = [ln for ln in child.stdout.splitlines() if ln.startswith('{')]
         if child.returncode != 0 or not lines:
@@ -359,17 +432,13 @@ def main():
     if size > 1:
         # first contact with a multi-GPU node: every rank checks that its plans live on
         # its own device and reports backend / RCCL / peer access on stderr; the halo
-        # form (direct, or routed over 3 / 7 links) is chosen by a probe on real rows
-        # unless STK_HALO_ROUTES pins it
-        from source.mpi_vector import probe_halo_form, startup_report
+        # form is the direct exchange unless STK_HALO_ROUTES pins a routed one or asks
+        # for the probe on real rows (=auto; mpi_vector.choose_halo_form)
+        from source.mpi_vector import choose_halo_form, startup_report
         pk = fused.ell.packed_for(n_loc) if getattr(fused, 'use_ell', False) else None
         startup_report(dd, [x.buf, y.buf] + list(fused.tri) +
                        ([pk.slots, pk.dict] if pk is not None and pk.ok else []))
-        pinned = os.environ.get('STK_HALO_ROUTES', 'auto')
-        if pinned == 'auto':
-            halo = probe_halo_form(dd)
-        else:
-            halo = {'chosen': int(pinned), 'reason': 'pinned by STK_HALO_ROUTES'}
+        halo = choose_halo_form(dd)
     wire_wait = [0.0]
 
     def step():
@@ -504,7 +573,8 @@ def main():
         cpu = run_cpu_baseline()
     achieved = my_bytes / (kernel_ms * 1e-3) / 1e9
     kernel = fused.kernel_name(n_loc)
-    traffic, traffic_src = pmc_traffic(args, size, kernel)
+    pk = fused.ell.packed_for(n_loc) if getattr(fused, 'use_ell', False) and type(fused).use_pack else None
+    traffic, traffic_src = pmc_traffic(args, size, kernel, plan_sha(pk) if pk is not None and pk.ok else None)
     out = {
         'metric': 'Kronecker-matvec GB/s (algorithmic bytes; share of 8 TB/s HBM '
                   'peak in roofline.frac) + PCG iters/s, J_time=%d J_space=%d %s'
@@ -568,6 +638,11 @@ def main():
             },
         }
     if cpu is not None:
+        pcg_cpu = cpu.pop('pcg', None)
+        if pcg_cpu is not None and solve is not None:
+            # the same loop on the host: the oracle's first r.Pr entries are the check that
+            # both sides iterate on the same problem
+            solve['cpu_baseline'] = pcg_cpu
         out['cpu_baseline'] = cpu
     print(json.dumps(out))
 

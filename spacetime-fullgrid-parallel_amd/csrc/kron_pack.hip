@@ -615,6 +615,8 @@ __global__ __launch_bounds__(256) void interleave_ghosts_kernel(int32_t M, const
 int g_pack_wg_per_cu = 0;
 int g_pack_flags = 3;  // non-temporal y stores and slot loads: measured 2-3 % faster at J_time = 6 / J_space = 9
 int g_pack_block = 512;                   // threads per workgroup: 512 or 256
+int g_pack_multi_wg_per_cu = 0;           // inputs per term: workgroups per CU (0: as the one-input form)
+int g_pack_multi_r = 0;                   // inputs per term: cap on the slot rows of a group (0: none)
 unsigned long long *g_pack_diag = nullptr;  // set: the next headline-shape launch runs the DIAG instantiation
 
 template <int NT, int K, bool GHOST, int BS, int RP>
@@ -674,6 +676,8 @@ int launch(hipStream_t st, PackArgs<NT> a, int K)
     const bool ghost = a.gh != nullptr;
     a.W = a.P + (ghost ? 1 : 0);
     a.R = BS / a.W;
+    const bool multi = a.xk[0] != nullptr;
+    if (multi && g_pack_multi_r > 0 && a.R > g_pack_multi_r) a.R = g_pack_multi_r;
     if (a.R * K > 4 * BS) a.R = 4 * BS / K;  // at most 4 prefetched words per thread
     if (a.vals && a.R * K * RP * NT > 2 * BS) a.R = 2 * BS / (K * RP * NT);  // ... and 2 values
     STK_REQUIRE(a.R >= 1, "stk_kron_pack_apply: a slot row of %d x %d x %d values is too wide", K, RP, NT);
@@ -693,6 +697,7 @@ int launch(hipStream_t st, PackArgs<NT> a, int K)
     STK_REQUIRE(lds <= 64 * 1024, "stk_kron_pack_apply: %zu bytes of LDS per workgroup (dictionary too large?)", lds);
     const int n_cu = stk_cu_count();
     int per_cu = g_pack_wg_per_cu > 0 ? g_pack_wg_per_cu : ((K >= 12 || RP > 1) ? 2 : 3) * (512 / BS);
+    if (multi && g_pack_multi_wg_per_cu > 0) per_cu = g_pack_multi_wg_per_cu;
     const int by_lds = (int)(160 * 1024 / (lds + 256));
     if (per_cu > by_lds) per_cu = by_lds > 0 ? by_lds : 1;
     int per_xcd = (n_cu / 8) * per_cu;
@@ -768,6 +773,14 @@ int stk_kron_pack_set_tuning(const char *key, int32_t value)
     }
     if (std::strcmp(key, "pack_flags") == 0) {
         g_pack_flags = value;
+        return 0;
+    }
+    if (std::strcmp(key, "pack_multi_wg_per_cu") == 0) {
+        g_pack_multi_wg_per_cu = value;
+        return 0;
+    }
+    if (std::strcmp(key, "pack_multi_r") == 0) {
+        g_pack_multi_r = value;
         return 0;
     }
     if (std::strcmp(key, "pack_block") == 0) {

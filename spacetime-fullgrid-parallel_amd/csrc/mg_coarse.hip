@@ -394,7 +394,9 @@ __global__ __launch_bounds__(UBS) void mg_coarse_uniform_kernel(const CoarseArgs
     typedef typename E::type V;
     extern __shared__ double sm_raw[];
     V *sv = reinterpret_cast<V *>(sm_raw);
-    CJob *s_jobs = reinterpret_cast<CJob *>(sv + a.lds_rows);
+    // the descriptors are copied with 16-byte accesses: their region starts on a 16-byte
+    // boundary also where V = double and lds_rows is odd
+    CJob *s_jobs = reinterpret_cast<CJob *>(sm_raw + (PAIR ? 2 * a.lds_rows : ((a.lds_rows + 1) & ~1)));
     const int tid = threadIdx.x;
     const int t0 = (PAIR ? 2 : 1) * (int)blockIdx.x;
     const bool has1 = PAIR && t0 + 1 < a.n_loc;
@@ -881,7 +883,7 @@ int stk_coarse_plan_run(const stk_coarse_plan *p, hipStream_t st, int n_loc, int
             m.dia_a = p->u_da;
             m.dia_m = p->u_dm;
             m.row = p->u_row;
-            const size_t lds_u = lds + sizeof(CJob) * (size_t)p->n_jobs;
+            const size_t lds_u = lds + (pair ? 0 : sizeof(double) * (p->lds_rows & 1)) + sizeof(CJob) * (size_t)p->n_jobs;
             if (lds_u <= 160 * 1024 - 512) return launch_uniform(p->KU, cm != nullptr, pair, grid, lds_u, st, a, m);
         }
         if (cm && pair)

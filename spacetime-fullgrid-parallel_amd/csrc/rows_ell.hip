@@ -45,7 +45,28 @@ struct RowsArgs {
     int32_t zero_own;  // GS: the rows' own values are zero (first sweep from u = 0)
     uint32_t x_bytes, y_bytes;
     int32_t wide;  // a slab of 4 GiB or more: 64-bit addressing
+    int32_t nt_store;  // y is stored with the non-temporal hint (it is not read again by this launch)
 };
+
+// The output row of an SPMM pass is written once and not gathered by the same launch:
+// stored plainly it occupies the XCD's L2 next to the rows of x that neighbouring
+// workgroups are about to gather again (PMC of round 4: I kron A_x fetched its input
+// 1.75 times; kron_pack.hip, which stores y with the hint, 1.05 times).
+template <bool WIDE>
+__device__ inline void store_nt(const stk_slab<WIDE> &s, uint32_t row_off, uint32_t t_bytes, double2 v)
+{
+    if constexpr (WIDE) {
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        v2d o;
+        o.x = v.x, o.y = v.y;
+        __builtin_nontemporal_store(
+            o, reinterpret_cast<v2d *>(const_cast<char *>(s.base) + (((size_t)row_off) << 4) + t_bytes));
+    } else {
+        stk_v4i w;
+        __builtin_memcpy(&w, &v, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(w, s.rs, row_off + t_bytes, 0, 2);  // aux bit 1: nt
+    }
+}
 
 template <int MODE, int K, int NPF, bool HAS_M, bool WIDE>
 __global__ __launch_bounds__(BS, K >= 12 ? 4 : 6) void rows_ell_kernel(const RowsArgs a)
@@ -201,7 +222,10 @@ __global__ __launch_bounds__(BS, K >= 12 ? 4 : 6) void rows_ell_kernel(const Row
                 }
             }
             if (!has1) o1 = 0.0;  // padding slot stays zero
-            sy.store(yo, t0_bytes, make_double2(o0, o1));
+            if (a.nt_store)
+                store_nt<WIDE>(sy, yo, t0_bytes, make_double2(o0, o1));
+            else
+                sy.store(yo, t0_bytes, make_double2(o0, o1));
         }
     }
 }
@@ -351,7 +375,10 @@ __global__ __launch_bounds__(BS, 4) void rows_ell2_kernel(const Rows2Args b)
             // second pass of the two-pass form: o = 1 * s, then fma(-1, z, o)
             double o0 = fma(-1.0, z0, s0), o1 = fma(-1.0, z1, s1);
             if (!has1) o1 = 0.0;  // padding slot stays zero
-            sy.store(yo, t0_bytes, make_double2(o0, o1));
+            if (a.nt_store)
+                store_nt<WIDE>(sy, yo, t0_bytes, make_double2(o0, o1));
+            else
+                sy.store(yo, t0_bytes, make_double2(o0, o1));
         }
     }
 }
@@ -374,6 +401,7 @@ int launch2_npf(hipStream_t st, const Rows2Args &b, unsigned grid, size_t lds)
 int g_rows_wg_per_cu = 0;
 int g_rows_force_wide = 0;  // testing: 64-bit addressing on small slabs
 int g_rows_alternate = 1;   // alternate the walking direction between launches
+int g_rows_nt_store = 0;    // bit 0: SPMM passes, bit 1: Gauss-Seidel groups, bit 2: the two-matrix pass
 unsigned g_rows_launch_count = 0;
 
 template <int MODE, int K, bool HAS_M, bool WIDE>
@@ -431,6 +459,10 @@ int stk_rows_ell_set_tuning(const char *key, int32_t value)
         g_rows_alternate = value;
         return 0;
     }
+    if (std::strcmp(key, "rows_nt_store") == 0) {
+        g_rows_nt_store = value;
+        return 0;
+    }
     if (std::strcmp(key, "rows_wg_per_cu") == 0) {
         g_rows_wg_per_cu = value;
         return 0;
@@ -480,6 +512,7 @@ int stk_rows_ell_launch(hipStream_t st, int mode, const stk_ell_rows *e, int32_t
     a.wide = g_rows_force_wide || x_rows * ld * 8 >= ((int64_t)1 << 32) || y_rows * ld * 8 >= ((int64_t)1 << 32);
     a.x_bytes = a.wide ? 0u : (uint32_t)(x_rows * ld * 8);
     a.y_bytes = a.wide ? 0u : (uint32_t)(y_rows * ld * 8);
+    a.nt_store = (g_rows_nt_store >> (mode == MODE_GS ? 1 : 0)) & 1;
     if (mode == MODE_GS) STK_REQUIRE(e->dia_a && (!cm || e->dia_m), "rows_ell: GS needs the diagonal arrays");
     const int K = e->K;
     const int KS = (K + 3) & ~3;
@@ -542,6 +575,7 @@ int stk_rows_ell2_launch(hipStream_t st, const stk_ell_rows *e, const stk_ell_ro
     a.wide = g_rows_force_wide || x_rows * ld * 8 >= ((int64_t)1 << 32) || y_rows * ld * 8 >= ((int64_t)1 << 32);
     a.x_bytes = a.wide ? 0u : (uint32_t)(x_rows * ld * 8);
     a.y_bytes = a.wide ? 0u : (uint32_t)(y_rows * ld * 8);
+    a.nt_store = (g_rows_nt_store >> 2) & 1;
     b.idx2 = e2->idx;
     b.va2 = e2->va;
     b.x2 = x2;

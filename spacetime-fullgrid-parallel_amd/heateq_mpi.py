@@ -435,13 +435,12 @@ def main(argv=None):
     record = {'rank': rank, 'mem_after_construction': mem()}
     if size > 1:
         # first contact with several GPUs: where this rank's plans live, the backend and
-        # RCCL version, peer access (stderr); on 3 ranks and more the halo form -- direct,
-        # or routed over 3 / 7 links -- is chosen by a probe on real rows unless
-        # STK_HALO_ROUTES pins it (source/mpi_vector.py)
-        from source.mpi_vector import probe_halo_form, startup_report
+        # RCCL version, peer access (stderr); the halo form -- direct, or with
+        # STK_HALO_ROUTES=auto chosen by a probe on real rows among direct and routed
+        # over 3 / 7 links (source/mpi_vector.py choose_halo_form)
+        from source.mpi_vector import choose_halo_form, startup_report
         record['startup'] = startup_report(heat.dofs_distr, [heat.rhs.buf])
-        if os.environ.get('STK_HALO_ROUTES', 'auto') == 'auto':
-            record['halo_form'] = probe_halo_form(heat.dofs_distr)
+        record['halo_form'] = choose_halo_form(heat.dofs_distr)
     if rank == 0:
         record.update(args=vars(args), N=heat.N, M=heat.M)
         driver.report_construction(heat)

@@ -190,6 +190,32 @@ def probe_halo_form(dofs_distr, candidates=(3, 7), reps=3):
     return rec
 
 
+def choose_halo_form(dofs_distr):
+    """The halo form of a multi-rank run, decided once at start-up (bench.py and the
+    driver call this; collective).  STK_HALO_ROUTES=k pins k routes; =auto runs
+    probe_halo_form.  UNSET: the direct exchange on RCCL -- the routed two-phase
+    point-to-point pattern has only ever run over gloo, a stall of it on a real node
+    would hang the start-up of every multi-GPU run and no `except` catches a hang
+     -- and the probe on gloo, where the tests exercise it.  Once a node has
+    passed `STK_HALO_ROUTES=auto`, that can become the default."""
+    import os
+    import torch.distributed as dist
+    pinned = os.environ.get('STK_HALO_ROUTES')
+    if pinned is None:
+        on_gloo = dofs_distr.size > 1 and dist.is_initialized() and dist.get_backend(
+            dofs_distr.comm.group) == 'gloo'
+        pinned = 'auto' if on_gloo else '1'
+        why = 'STK_HALO_ROUTES unset: %s' % ('probe (gloo)' if on_gloo else 'direct on RCCL (probe is opt-in: =auto)')
+    else:
+        why = 'STK_HALO_ROUTES=%s' % pinned
+    if pinned == 'auto':
+        rec = probe_halo_form(dofs_distr)
+        rec['policy'] = why
+        return rec
+    KronVectorMPI.HALO_ROUTES = int(pinned)
+    return {'chosen': int(pinned), 'reason': 'not probed', 'policy': why}
+
+
 def startup_report(dofs_distr, tensors=()):
     """First-contact checks of a multi-rank run, on stderr: every rank asserts that
     the given plan tensors live on ITS device (LOCAL_RANK), and reports the
@@ -515,10 +541,10 @@ class KronVectorMPI:
 
     # Pieces a halo row is cut into so that they travel over different links
     # (environment STK_HALO_ROUTES; 1 = the whole row straight to the neighbour).
-    # Opt-in: it has only ever run over gloo -- no multi-GPU node was available to
-    # measure it or to prove it on RCCL.
-    # STK_HALO_ROUTES=auto (what bench.py and the driver do on 3 ranks and more when the
-    # variable is unset): probe_halo_form decides at start-up.
+    # Opt-in on RCCL: it has only ever run over gloo -- no multi-GPU node was available
+    # to measure it or to prove it there.  STK_HALO_ROUTES=auto:
+    # probe_halo_form decides at start-up; unset: choose_halo_form (direct on RCCL, the
+    # probe on gloo).
     HALO_ROUTES = int(__import__('os').environ.get('STK_HALO_ROUTES', '1').replace('auto', '1'))
 
     def _routed_halo(self, first, last, callback):

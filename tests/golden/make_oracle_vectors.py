@@ -76,11 +76,16 @@ def lean_operators(o, chunk=8):
     return S, (lambda X: o.WT(S(o.W(X))))
 
 
-def lean_pcg(T, P, b, kmax):
+def lean_pcg(T, P, b, kmax, keep_at=(), sample=None, progress=None):
     """oracle.krylov.pcg with every vector update done in place, row block by row
-    block (identical per entry; no full-size temporaries)."""
+    block (identical per entry; no full-size temporaries).  `keep_at`: iteration
+    numbers after which norm and sample of the iterate are kept (the head of a
+    long trajectory stays comparable on its own); `progress`: a JSON file that
+    holds the history so far (a run of hours that dies keeps what it had)."""
+    import json
     from oracle.krylov import _dot
     N = b.shape[0]
+    kept = {}
 
     def axpy(y, a, x):  # y += a * x
         for t in range(N):
@@ -101,6 +106,11 @@ def lean_pcg(T, P, b, kmax):
         abs_r_old, abs_r = abs_r, _dot(r, z)
         hist.append(abs_r)
         print('  iteration %d: r.Pr = %.6e' % (k, abs_r), flush=True)
+        if k in keep_at:
+            kept[k] = (np.linalg.norm(w), sample(w).copy())
+        if progress:
+            with open(progress, 'w') as f:
+                json.dump(dict(hist=[float.hex(float(v)) for v in hist]), f)
         if abs_r < 1e-12:
             break
         beta = abs_r / abs_r_old
@@ -108,7 +118,7 @@ def lean_pcg(T, P, b, kmax):
             p[row] *= beta
             p[row] += z[row]
         del z
-    return w, len(hist) - 1, hist
+    return w, len(hist) - 1, hist, kept
 
 
 def main():
@@ -148,7 +158,9 @@ def main():
         if args.lean:
             S_lean, T_lean = lean_operators(o)
             o.S = S_lean
-            w, iters, hist = lean_pcg(T_lean, o.P, o.rhs(), args.kmax)
+            w, iters, hist, kept = lean_pcg(
+                T_lean, o.P, o.rhs(), args.kmax, keep_at=(5,), sample=lambda v: v[::st, ::sx],
+                progress=os.path.join(REPO, 'gpurun_out', 'oracle_progress_' + os.path.basename(path) + '.json'))
         else:
             w, iters, hist = pcg(o.WT_S_W, o.P, o.rhs(), kmax=args.kmax, callback=cb)
         print('oracle PCG: %d iterations in %.1f s' % (iters, time.time() - t0))
@@ -156,6 +168,9 @@ def main():
                    iters=iters, kmax=args.kmax, hist=np.array(hist),
                    w_norm=np.linalg.norm(w), w_sample=w[::st, ::sx].copy(),
                    sample_strides=np.array([st, sx]))
+        if args.lean:
+            for k, (nrm, smp) in kept.items():
+                out['w%d_norm' % k], out['w%d_sample' % k] = nrm, smp
     if not args.no_ops:
         # the bench's vector (bench.seeded_slab): the reference's timing vector,
         # np.random.seed(128); rand(N, M) (heateq_mpi_timing.py:81-83)

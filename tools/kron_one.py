@@ -54,3 +54,8 @@ for name in args.kernels.split(','):
             ell.packed.apply([(tri[0], 0), (tri[1], 1)], x, gh, n_loc, ld, 0.0, y)
     torch.cuda.synchronize()
 print('done', M, n_loc)
+if 'packed' in args.kernels.split(','):
+    # what the PMC record of this run is stamped with (tools/pmc_traffic.py reads the line
+    # from the pass's log): the hash of the kernel's sources and of the plan it streamed
+    import bench  # noqa: E402
+    print('fingerprint source_sha=%s plan_sha=%s' % (bench.kernel_source_sha(), bench.plan_sha(ell.packed)))

@@ -2,7 +2,9 @@
 # One rocprofv3 --pmc pass per counter group over a target command; per-kernel
 # sums and averages by tools/pmc_summary.py.  The program itself follows `--`
 # (python3 ...), never a wrapper.
-# usage: tools/pmc_passes.sh <tag> <groups: kron|gs|all> python3 <script> [args]
+# usage: tools/pmc_passes.sh <tag> <groups: kron|gs|traffic|all> python3 <script> [args]
+#   traffic: the three groups that say how many bytes a kernel moved and how its L2 did
+#   (FETCH_SIZE, WRITE_SIZE, TCC hits / misses)
 # The profiled command must not fork once the profiler's preloaded library has
 # initialised the GPU: pass --no-cpu-baseline to bench.py (it also skips the CPU
 # baseline by itself when it detects the preload).
@@ -23,6 +25,7 @@ groups=(
   "GRBM_GUI_ACTIVE"
 )
 [ "$which" = "gs" ] && groups=("${groups[@]:0:6}" "${groups[@]:8:1}")
+[ "$which" = "traffic" ] && groups=("${groups[@]:0:3}")
 i=0
 for grp in "${groups[@]}"; do
   i=$((i+1))

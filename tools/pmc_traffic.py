@@ -3,8 +3,9 @@
 record bench.py reports as roofline.traffic: HBM bytes per launch of one kernel
 = 2 * FETCH_SIZE + WRITE_SIZE (KiB; the factor 2 is MI355X_MICROARCH.md's gfx950
 rule for FETCH_SIZE), stamped with the hash of the kernel sources it was
-measured on (bench.kernel_source_sha).  Run on the GPU box right after the
-passes, from the same tree.
+measured on and of the plan it streamed -- both as the PROFILED program printed
+them (the `fingerprint` line tools/kron_one.py leaves in every pass's log), not
+recomputed afterwards.  Run on the GPU box right after the passes.
 
     python tools/pmc_traffic.py gpurun_out/pmc_<tag> kron_pack_kernel out.json [J_time J_space problem]
 """
@@ -28,12 +29,20 @@ for f in glob.glob(root + '/p*/**/*counter_collection.csv', recursive=True):
             vals.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
             names.add(r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0])
 avg = {k: sum(v) / len(v) for k, v in vals.items()}
+prints = set()
+for f in glob.glob(root + '/p*.log'):
+    for line in open(f, errors='replace'):
+        if line.startswith('fingerprint '):
+            prints.add(line.strip())
+assert len(prints) == 1, 'the passes do not agree on one fingerprint: %r' % sorted(prints)
+stamp = dict(kv.split('=') for kv in prints.pop().split()[1:])
+assert stamp['source_sha'] == bench.kernel_source_sha(), 'the tree changed since the passes ran'
 fetch, write = avg['FETCH_SIZE'], avg['WRITE_SIZE']
 rec = {
     'kernel': kernel,
     'kernel_instances': sorted(names),
     'J_time': J_time, 'J_space': J_space, 'problem': problem,
-    'source_sha': bench.kernel_source_sha(),
+    'source_sha': stamp['source_sha'], 'plan_sha': stamp['plan_sha'],
     'fetch_size_kib': fetch, 'write_size_kib': write,
     'hbm_bytes_per_launch': (2.0 * fetch + write) * 1024.0,
     'launches_averaged': {k: len(v) for k, v in vals.items() if k in ('FETCH_SIZE', 'WRITE_SIZE')},
