@@ -421,18 +421,35 @@ int stk_kron_pack_ghost_apply(void *stream, const stk_pack_pattern *pattern_host
  * heateq_mpi.py:166-181 once K is applied to two right-hand sides instead of four
  * times: (I kron M_x) v1 + (I kron A_x) v2 + (G_t kron M_x) x, i.e. three
  * TridiagKronMatMPI / IdentityKronMatMPI applies and the sum of SumMPI._matvec
- * (mpi_kron.py:77-90, 135-150, 214-219) in one pass.  The terms take turns on the
- * slot words of a row (K gathers from xs[k], then term k's sums); a lane skips the
- * turn of a term whose time factor never multiplies its pair of time steps (G_t
- * has the single entry (0, 0)), so a term costs the traffic of the time steps it
- * reads.  No ghost time steps: a term whose factor couples to the neighbour
- * ranks' rows takes stk_kron_pack_apply.  The pattern must have a dictionary;
- * xs_host: n_terms device pointers (host array), 2 or 3 terms.  Every row's sums
- * are those of stk_kron_pack_apply, term by term. */
+ * (mpi_kron.py:77-90, 135-150, 214-219) in one pass.  Every slot row gets a LANE
+ * GROUP PER TERM (csrc/kron_pack_multi.hip): a lane gathers K columns of ITS
+ * term's slab for one pair of time steps, the sums of all lanes meet in LDS, and
+ * the first lane group applies the time factors and adds the terms in term order.
+ * A lane whose term's time factor never multiplies its pair of time steps does
+ * not gather (G_t has the single entry (0, 0)).  No ghost time steps: a term whose
+ * factor couples to the neighbour ranks' rows takes stk_kron_pack_apply.  The
+ * pattern must have a dictionary; xs_host: n_terms device pointers (host array),
+ * 2 or 3 terms.  Every row's sums are those of stk_kron_pack_apply, term by term,
+ * bit for bit.  (Slot rows that would need more than 512 lanes, and tuning key
+ * "pack_multi_lanes" = 0: the terms take turns in one lane, round 4's form.) */
 int stk_kron_pack_apply_multi(void *stream, const stk_pack_pattern *pattern_host,
                               int32_t n_loc, int32_t ld, int32_t n_terms,
                               const stk_kron_pack_term *terms_host,
                               const double *const *xs_host, double beta, double *y);
+/* ... with the caller's knowledge of the time factors (host arrays of n_terms
+ * entries, or both NULL): term k's factor has no non-zero entry in a COLUMN
+ * outside the local time steps [t_begin_host[k], t_end_host[k]) -- it reads
+ * xs[k] at those steps only -- so term k gets lanes for those pairs of steps only
+ * and a workgroup holds more slot rows of the others (G_t: [0, 1); an identity or
+ * a full tridiagonal factor: [0, n_loc)).  Term 0's lanes also write y and always
+ * cover every step.  A range that leaves out a column the factor does reach gives
+ * a wrong result: the library cannot see the factors' entries from the host. */
+int stk_kron_pack_apply_multi_steps(void *stream, const stk_pack_pattern *pattern_host,
+                                    int32_t n_loc, int32_t ld, int32_t n_terms,
+                                    const stk_kron_pack_term *terms_host,
+                                    const double *const *xs_host,
+                                    const int32_t *t_begin_host,
+                                    const int32_t *t_end_host, double beta, double *y);
 
 /* ---- plan construction from CSR (no Python needed) ---------------------------
  * Everything the three forms above stream is derived here, on the host side of

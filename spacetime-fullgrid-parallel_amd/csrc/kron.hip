@@ -20,6 +20,7 @@
 
 int stk_kron_ell_set_tuning(const char *key, int32_t value);  // kron_ell.hip
 int stk_kron_pack_set_tuning(const char *key, int32_t value);  // kron_pack.hip
+int stk_kron_pack_terms_set_tuning(const char *key, int32_t value);  // kron_pack_multi.hip
 extern int g_plan_pack_rows;                                   // plan.hip
 int stk_rows_ell_set_tuning(const char *key, int32_t value);  // rows_ell.hip
 int stk_wavelet_set_tuning(const char *key, int32_t value);   // wavelet.hip
@@ -427,6 +428,7 @@ extern "C" int stk_set_tuning(const char *key, int32_t value)
     }
     if (stk_kron_ell_set_tuning(key, value) == 0) return 0;
     if (stk_kron_pack_set_tuning(key, value) == 0) return 0;
+    if (stk_kron_pack_terms_set_tuning(key, value) == 0) return 0;
     if (stk_rows_ell_set_tuning(key, value) == 0) return 0;
     if (stk_wavelet_set_tuning(key, value) == 0) return 0;
     if (std::strcmp(key, "pack_rows") == 0) {  // plans created from now on: matrix rows per slot row (1 or 2)

@@ -615,6 +615,7 @@ __global__ __launch_bounds__(256) void interleave_ghosts_kernel(int32_t M, const
 int g_pack_wg_per_cu = 0;
 int g_pack_flags = 3;  // non-temporal y stores and slot loads: measured 2-3 % faster at J_time = 6 / J_space = 9
 int g_pack_block = 512;                   // threads per workgroup: 512 or 256
+int g_pack_multi_lanes = 1;               // inputs per term: 0 = the terms take turns in one lane (round 4)
 int g_pack_multi_wg_per_cu = 0;           // inputs per term: workgroups per CU (0: as the one-input form)
 int g_pack_multi_r = 0;                   // inputs per term: cap on the slot rows of a group (0: none)
 unsigned long long *g_pack_diag = nullptr;  // set: the next headline-shape launch runs the DIAG instantiation
@@ -783,6 +784,10 @@ int stk_kron_pack_set_tuning(const char *key, int32_t value)
         g_pack_multi_r = value;
         return 0;
     }
+    if (std::strcmp(key, "pack_multi_lanes") == 0) {
+        g_pack_multi_lanes = value;
+        return 0;
+    }
     if (std::strcmp(key, "pack_block") == 0) {
         g_pack_block = value == 256 ? 256 : 512;
         return 0;
@@ -832,9 +837,15 @@ extern "C" int stk_kron_pack_apply(void *stream, const stk_pack_pattern *pat, in
     }
 }
 
-extern "C" int stk_kron_pack_apply_multi(void *stream, const stk_pack_pattern *pat, int32_t n_loc, int32_t ld,
-                                         int32_t n_terms, const stk_kron_pack_term *t, const double *const *xs_host,
-                                         double beta, double *y)
+// kron_pack_multi.hip: a lane group per term (-1: a slot row would need more than 512 lanes)
+int stk_kron_pack_terms_launch(hipStream_t st, const stk_pack_pattern *pat, int32_t n_loc, int32_t ld, int32_t n_terms,
+                               const stk_kron_pack_term *t, const double *const *xs, const int32_t *t_begin,
+                               const int32_t *t_end, double beta, double *y);
+
+extern "C" int stk_kron_pack_apply_multi_steps(void *stream, const stk_pack_pattern *pat, int32_t n_loc, int32_t ld,
+                                               int32_t n_terms, const stk_kron_pack_term *t,
+                                               const double *const *xs_host, const int32_t *t_begin_host,
+                                               const int32_t *t_end_host, double beta, double *y)
 {
     const stk_timed timed_(STK_OP_KRON, stream);
     STK_REQUIRE(pat && t && xs_host && y, "stk_kron_pack_apply_multi: null pointer");
@@ -854,16 +865,33 @@ extern "C" int stk_kron_pack_apply_multi(void *stream, const stk_pack_pattern *p
                 "stk_kron_pack_apply_multi: bad sizes n_loc=%d ld=%d (ld must be even)", n_loc, ld);
     STK_REQUIRE(n_terms >= 2 && n_terms <= 3, "stk_kron_pack_apply_multi: n_terms=%d not 2 or 3", n_terms);
     STK_REQUIRE((n_loc + 1) / 2 + 2 <= 512, "stk_kron_pack_apply_multi: n_loc=%d too large", n_loc);
+    STK_REQUIRE((t_begin_host == nullptr) == (t_end_host == nullptr),
+                "stk_kron_pack_apply_multi_steps: t_begin and t_end come together");
     for (int k = 0; k < n_terms; ++k) {
         STK_REQUIRE(t[k].mat >= 0 && t[k].mat < pat->n_mats, "stk_kron_pack_apply_multi: term %d names matrix %d of %d",
                     k, t[k].mat, pat->n_mats);
         STK_REQUIRE(xs_host[k] && xs_host[k] != y && ((uintptr_t)xs_host[k] & 15) == 0,
                     "stk_kron_pack_apply_multi: input %d missing, aliasing the output or not 16-byte aligned", k);
+        STK_REQUIRE(!t_begin_host || (t_begin_host[k] >= 0 && t_begin_host[k] <= t_end_host[k] && t_end_host[k] <= n_loc),
+                    "stk_kron_pack_apply_multi_steps: term %d states the time steps [%d, %d) of %d", k,
+                    t_begin_host ? t_begin_host[k] : 0, t_end_host ? t_end_host[k] : 0, n_loc);
     }
     STK_REQUIRE(((uintptr_t)y & 15) == 0, "stk_kron_pack_apply_multi: y must be 16-byte aligned");
     hipStream_t st = stk_stream(stream);
+    if (g_pack_multi_lanes) {
+        const int rc = stk_kron_pack_terms_launch(st, pat, n_loc, ld, n_terms, t, xs_host, t_begin_host, t_end_host,
+                                                  beta, y);
+        if (rc >= 0) return rc;
+    }
     if (n_terms == 2) return dispatch<2>(st, pat, n_loc, ld, t, xs_host[0], nullptr, beta, y, xs_host);
     return dispatch<3>(st, pat, n_loc, ld, t, xs_host[0], nullptr, beta, y, xs_host);
+}
+
+extern "C" int stk_kron_pack_apply_multi(void *stream, const stk_pack_pattern *pat, int32_t n_loc, int32_t ld,
+                                         int32_t n_terms, const stk_kron_pack_term *t, const double *const *xs_host,
+                                         double beta, double *y)
+{
+    return stk_kron_pack_apply_multi_steps(stream, pat, n_loc, ld, n_terms, t, xs_host, nullptr, nullptr, beta, y);
 }
 
 extern "C" int stk_interleave_ghosts(void *stream, int32_t M, const double *lo, const double *hi, double *ghosts)

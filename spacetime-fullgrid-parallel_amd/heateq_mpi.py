@@ -20,7 +20,8 @@ from source.assembly import (prolongation_matrices, space_load,
                              space_matrices, time_matrices)
 from source.comm import MPI
 from source.linalg import PCG
-from source.linop import CompositeLinOp, EllMatrices, InvLinOp, as_space_op
+from source.linop import (CompositeLinOp, EllMatrices, InvLinOp, as_space_op,
+                          time_factor_steps)
 from source.mpi_kron import (BlockDiagMPI, CompositeMPI, LinearOperatorMPI,
                              MatKronIdentityMPI, SumMPI, TridiagKronMatMPI,
                              _local_tridiag)
@@ -57,13 +58,14 @@ class SchurMPI(LinearOperatorMPI):
         self._linops = None
         self.Kinv_x = as_space_op(Kinv_x)
         self.ell = EllMatrices.shared([M_x, A_x])  # matrix 0 = M_x, 1 = A_x
-        self._couples = {}
+        self._couples, self._steps = {}, {}
 
         def tri(T):
             host = _local_tridiag(dofs_distr, T)
             dev = _lib.to_dev(host)
             # does the factor reach the neighbour ranks' time rows at all?
             self._couples[id(dev)] = (host[0, 0] != 0.0, host[2, -1] != 0.0)
+            self._steps[id(dev)] = time_factor_steps(host)
             return dev
 
         self.tA, self.tL, self.tM, self.tG = tri(A_t), tri(L_t), tri(
@@ -156,7 +158,8 @@ class SchurMPI(LinearOperatorMPI):
             # the three inputs through the packed slot stream, one turn per term;
             # G_t's turn only in the lanes of the time steps it multiplies
             packed.apply_multi([(None, 0, v1), (None, 1, v2), (self.tG, 0, x)],
-                               n_loc, ld, 0.0, vec_out.buf)
+                               n_loc, ld, 0.0, vec_out.buf,
+                               steps=[None, None, self._steps[id(self.tG)]])
         else:
             self.ell.apply([(None, 0, v1, None, None), (None, 1, v2, None, None),
                             self._spec(self.tG, 0, vec_in)], n_loc, ld, 0.0,

@@ -563,6 +563,22 @@ class EllMatrices:
                 len(specs), self._terms(specs, True), _lib.ptr(out)))
 
 
+def time_factor_steps(tri_host):
+    """[t_begin, t_end): the local time steps at which a time factor given by its
+    three diagonals (`tri_host`: (3, n_loc) sub / main / super, as the kernels take
+    them) reads its input -- column t is reached through sub[t + 1], dia[t] and
+    super[t - 1].  None for an identity factor (tri_host None): every step."""
+    if tri_host is None:
+        return None
+    t = np.asarray(tri_host)
+    n = t.shape[1]
+    used = t[1] != 0.0
+    used[:-1] |= t[0, 1:] != 0.0
+    used[1:] |= t[2, :-1] != 0.0
+    idx = np.flatnonzero(used)
+    return (0, 0) if len(idx) == 0 else (int(idx[0]), int(idx[-1]) + 1)
+
+
 def _few_unique(v, limit):
     """np.unique(v, return_inverse=True) for an int64 array that is expected to
     hold at most `limit` distinct values: candidates from a sample, then binary
@@ -808,16 +824,24 @@ class PackedEllMatrices:
             _lib.stream(), ctypes.byref(self._pattern_for(specs)), n_loc, ld, len(specs),
             self._terms(specs), _lib.ptr(x_lo), _lib.ptr(x_hi), _lib.ptr(out)))
 
-    def apply_multi(self, specs, n_loc, ld, beta, out):
+    def apply_multi(self, specs, n_loc, ld, beta, out, steps=None):
         """y = beta*y + sum over specs (tri, matrix index, x): every term reads a
-        slab of its own, no ghost time steps (stk_kron_pack_apply_multi); the
-        dictionary form only (`explicit` plans keep the plain form)."""
+        slab of its own, no ghost time steps (stk_kron_pack_apply_multi_steps); the
+        dictionary form only (`explicit` plans keep the plain form).  `steps`: per
+        term None or (t_begin, t_end), the local time steps the term's time factor
+        reads its input at (time_factor_steps of the host copy of the factor): the
+        term then gets lanes for those steps only."""
         assert not self.explicit and 2 <= len(specs) <= 3
         terms = self._terms([(tri, k) for tri, k, _ in specs])
         xs = (ctypes.c_void_p * len(specs))(*[_lib.ptr(x) for _, _, x in specs])
-        _lib.check(_lib.lib().stk_kron_pack_apply_multi(
+        t0 = t1 = None
+        if steps is not None and any(s_ is not None for s_ in steps):
+            rng = [(0, n_loc) if s_ is None else s_ for s_ in steps]
+            t0 = (ctypes.c_int32 * len(specs))(*[int(a) for a, _ in rng])
+            t1 = (ctypes.c_int32 * len(specs))(*[int(b) for _, b in rng])
+        _lib.check(_lib.lib().stk_kron_pack_apply_multi_steps(
             _lib.stream(), ctypes.byref(self.pattern), n_loc, ld, len(specs),
-            terms, xs, beta, _lib.ptr(out)))
+            terms, xs, t0, t1, beta, _lib.ptr(out)))
 
     def apply(self, specs, x, ghosts, n_loc, ld, beta, out):
         """y = beta*y + sum over specs (tri, matrix index) applied to x;

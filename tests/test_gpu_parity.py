@@ -1466,9 +1466,14 @@ def test_kron_pack_inputs_per_term(stk):
     added in the same order) for the Schur shape, and dense NumPy for random time
     factors -- among them factors with a single entry, whose term only a few lanes
     gather; one row and row pairs per slot row; 2 and 3 terms, beta, slab lengths
-    through the lane / group / prefetch instances."""
+    through the lane / group / prefetch instances.  Three forms of the pass: a lane
+    group per term (round 5: csrc/kron_pack_multi.hip) without and with the
+    caller's statement of the time steps each factor reads (`steps`), and round 4's
+    turn-taking lanes (tuning key pack_multi_lanes = 0) -- all three bit for bit the
+    same."""
+    from source import _lib
     from source.assembly import space_matrices
-    from source.linop import EllMatrices
+    from source.linop import EllMatrices, time_factor_steps
     from source.problem import problem_helper
     rng = np.random.RandomState(77)
     families = []
@@ -1529,6 +1534,19 @@ def test_kron_pack_inputs_per_term(stk):
                     form.apply_multi([(dev_tri[k], which[k], xs[k]) for k in range(nt)],
                                      n_loc, ld, beta, y)
                     tag = (name, n_loc, shape, rows)
+                    y_steps = slab(y0)
+                    form.apply_multi([(dev_tri[k], which[k], xs[k]) for k in range(nt)],
+                                     n_loc, ld, beta, y_steps,
+                                     steps=[time_factor_steps(t) for t in tris])
+                    assert torch.equal(y_steps, y), tag
+                    _lib.check(_lib.lib().stk_set_tuning(b'pack_multi_lanes', 0))
+                    try:
+                        y_turns = slab(y0)
+                        form.apply_multi([(dev_tri[k], which[k], xs[k]) for k in range(nt)],
+                                         n_loc, ld, beta, y_turns)
+                    finally:
+                        _lib.check(_lib.lib().stk_set_tuning(b'pack_multi_lanes', 1))
+                    assert torch.equal(y_turns, y), tag
                     assert relerr(y[:, :n_loc].cpu().numpy(), want) < 1e-13, tag
                     if shape == 'schur':
                         assert torch.equal(y, y_plain), tag

@@ -22,7 +22,8 @@ import heateq_mpi as hm  # noqa: E402
 from source import _lib  # noqa: E402
 
 DEFAULTS = {'rows_nt_store': 0, 'rows_wg_per_cu': 0, 'rows_alternate': 1, 'pack_wg_per_cu': 0,
-            'pack_flags': 3, 'pack_multi_wg_per_cu': 0, 'pack_multi_r': 0}
+            'pack_flags': 3, 'pack_multi_wg_per_cu': 0, 'pack_multi_r': 0, 'pack_multi_lanes': 1,
+            'terms_wg_per_cu': 0, 'terms_flags': 3}
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--J_time', type=int, default=6)
@@ -65,7 +66,9 @@ from source.mpi_vector import KronVectorMPI  # noqa: E402
 xv = KronVectorMPI(h.dofs_distr, x[:, :n_loc].t().contiguous().cpu().numpy())
 
 ops = {
-    'multi': lambda: packed.apply_multi([(None, 0, v1), (None, 1, v2), (S.tG, 0, x)], n_loc, ld, 0.0, y),
+    'multi': lambda: packed.apply_multi([(None, 0, v1), (None, 1, v2), (S.tG, 0, x)], n_loc, ld, 0.0, y,
+                                        steps=[None, None, (0, 1)]),
+    'multi_nosteps': lambda: packed.apply_multi([(None, 0, v1), (None, 1, v2), (S.tG, 0, x)], n_loc, ld, 0.0, y),
     'ax': lambda: A_x.apply(x, out=y, n_loc=n_loc),
     'Kinv': lambda: h.Kinv_x.apply(x, n_loc=n_loc),
     'P': lambda: (h.P @ xv).buf,
