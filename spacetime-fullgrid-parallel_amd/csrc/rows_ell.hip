@@ -401,7 +401,7 @@ int launch2_npf(hipStream_t st, const Rows2Args &b, unsigned grid, size_t lds)
 int g_rows_wg_per_cu = 0;
 int g_rows_force_wide = 0;  // testing: 64-bit addressing on small slabs
 int g_rows_alternate = 1;   // alternate the walking direction between launches
-int g_rows_nt_store = 0;    // bit 0: SPMM passes, bit 1: Gauss-Seidel groups, bit 2: the two-matrix pass
+int g_rows_nt_store = 1;    // bit 0: SPMM passes, bit 1: Gauss-Seidel groups, bit 2: the two-matrix pass
 unsigned g_rows_launch_count = 0;
 
 template <int MODE, int K, bool HAS_M, bool WIDE>
