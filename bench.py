@@ -537,12 +537,37 @@ def main():
         if size > 1:
             dist.all_reduce(ds, op=dist.ReduceOp.MAX)
         ds = float(ds[0])
+        phases = None
+        if size > 1:
+            # where an iteration goes on THIS rank, in a short pass of its own after the
+            # timed one (every apply then ends with an event synchronisation): device
+            # time of S / P / W / W^T per apply, the host's wait for the one halo of
+            # an S apply, and the scalar all-reduces -- how many per iteration and what
+            # one costs the host -- so that a SCALE record splits into compute, wire and
+            # latency without a profiler
+            from source.mpi_kron import LinearOperatorMPI
+            ops = {'S': h.S, 'P': h.P, 'W': h.W, 'WT': h.WT}
+            for o in ops.values():
+                o.num_applies = o.time_applies = o.time_communication = 0
+            LinearOperatorMPI.sync_timing, type(comm).timing = True, True
+            comm.reset_counters()
+            try:
+                _, its3 = PCG(h.WT_S_W, h.P, h.rhs, kmax=4)
+            finally:
+                LinearOperatorMPI.sync_timing, type(comm).timing = False, False
+            phases = {'rank': rank, 'n_loc': n_loc, 'iterations': its3,
+                      'allreduce_calls_per_iteration': comm.allreduce_calls / max(its3, 1),
+                      'allreduce_host_ms_each': comm.allreduce_host_s / max(comm.allreduce_calls, 1) * 1e3}
+            for name, o in ops.items():
+                phases[name + '_device_ms_per_apply'] = o.time_applies / max(o.num_applies, 1) * 1e3
+            phases['S_host_wait_for_halo_ms_last_apply'] = h.S.time_communication * 1e3
+            phases = comm.gather(phases)
         model_bytes, parts = pcg_byte_model(h, n_loc)
         mb = torch.tensor([model_bytes, parts['total_tight']], dtype=torch.float64, device=red_dev)
         if size > 1:
             dist.all_reduce(mb, op=dist.ReduceOp.SUM)
         model_total, model_tight = float(mb[0]), float(mb[1])
-        return {'arithmetic': arithmetic, 'setup_s': h.setup_time,
+        return {'arithmetic': arithmetic, 'setup_s': h.setup_time, 'per_rank': phases,
                 'iters_timed': n_it, 'iters_per_s': n_it / ds,
                 'ms_per_iter': ds / n_it * 1e3,
                 'r_dot_Pr': [float(v) for v in hist],
@@ -559,12 +584,14 @@ def main():
                     'frac_tight': model_tight / (ds / n_it) / 1e9 / (HBM_PEAK_GBS * size),
                     'breakdown_rank0_bytes': parts}}
 
-    solve = solve_fast = None
+    solve = solve_fast = solve_per_rank = None
     if args.solve_iters > 0:
         solve = timed_solve('accurate')
+        solve_per_rank = solve.pop('per_rank', None)
         torch.cuda.empty_cache()
         solve_fast = timed_solve('fast')
         del solve_fast['roofline']['breakdown_rank0_bytes']
+        solve_fast.pop('per_rank', None)
 
     if rank != 0:
         return
@@ -627,6 +654,7 @@ def main():
         out['multi_gpu'] = {
             'halo_form': halo,
             'per_rank': per_rank,
+            'solve_per_rank': solve_per_rank,
             'wire_bound': {
                 'bytes_per_neighbour_per_step': 8 * M,
                 'xgmi_GBs_per_link_and_direction': link,

@@ -453,6 +453,8 @@ def main(argv=None):
             print('.', end='', flush=True)
 
     LinearOperatorMPI.sync_timing = True
+    type(comm).timing = size > 1  # count and time the scalar all-reduces of the solve
+    comm.reset_counters()
     comm.Barrier()
     began = MPI.Wtime()
     history = []
@@ -460,7 +462,10 @@ def main(argv=None):
                           history=history)
     comm.Barrier()
     record.update(solve_time=MPI.Wtime() - began, mem_after_solve=mem(),
-                  iters=iters, r_dot_Pr=list(history))
+                  iters=iters, r_dot_Pr=list(history),
+                  allreduce_calls=comm.allreduce_calls,
+                  allreduce_host_s=comm.allreduce_host_s)
+    type(comm).timing = False
     for name in driver.OPERATORS + ('WT_S_W',):
         record[name] = driver.counters(getattr(heat, name))
     if rank == 0:

@@ -25,7 +25,15 @@ class Comm:
     STK_FORCE_COLLECTIVES=1 it does not: the scalar all-reduce, barrier and
     object broadcast / gather then run on the backend (RCCL) even at world size
     1 -- the transport can be executed on a one-GPU box."""
+    # Set (the drivers and bench.py's per-rank pass do): every scalar all-reduce is
+    # bracketed by host time stamps after the device has drained, so that
+    # `allreduce_host_s` is the latency of the collective itself (plus the read of
+    # its result), not the wait for the kernels before it.
+    timing = False
+
     def __init__(self, group=None, distributed=None):
+        self.allreduce_calls = 0
+        self.allreduce_host_s = 0.0
         self.group = group
         self.distributed = dist.is_initialized() if distributed is None else distributed
         if self.distributed:
@@ -55,13 +63,26 @@ class Comm:
         """In-place sum of a small tensor that already lives on the compute
         device (keeps the dot result on the GPU until the single D2H read)."""
         if self.collective:
+            self.allreduce_calls += 1
+            began = None
+            if Comm.timing:
+                if t.is_cuda:
+                    torch.cuda.synchronize()
+                began = time.perf_counter()
             if t.is_cuda and self._device().type == 'cpu':
                 host = t.cpu()  # gloo: stage through the host
                 dist.all_reduce(host, group=self.group)
                 t.copy_(host)
             else:
                 dist.all_reduce(t, group=self.group)
+            if began is not None:
+                if t.is_cuda:
+                    torch.cuda.synchronize()
+                self.allreduce_host_s += time.perf_counter() - began
         return t
+
+    def reset_counters(self):
+        self.allreduce_calls, self.allreduce_host_s = 0, 0.0
 
     def bcast(self, obj, root=0):
         if not self.collective:

@@ -104,6 +104,26 @@ def main():
         assert all(rec['identical'].values()), rec  # gloo delivers the routed rows intact
         assert rec['chosen'] == 1 or rec['ms'][rec['chosen']] < rec['ms'][1]
     KronVectorMPI.HALO_ROUTES = 1
+    # the policy around the probe (choose_halo_form): the variable unset means the probe
+    # on gloo (and the direct exchange on RCCL, where the routed form has never run); a
+    # pinned value is taken as it is, without a probe
+    from source.mpi_vector import choose_halo_form
+    assert 'STK_HALO_ROUTES' not in os.environ
+    pol = choose_halo_form(dd)
+    assert 'probe (gloo)' in pol['policy'] and pol['chosen'] == KronVectorMPI.HALO_ROUTES
+    os.environ['STK_HALO_ROUTES'] = '1'
+    try:
+        pol = choose_halo_form(dd)
+    finally:
+        del os.environ['STK_HALO_ROUTES']
+    assert pol['chosen'] == 1 and pol['reason'] == 'not probed' and KronVectorMPI.HALO_ROUTES == 1
+    # the counters of the scalar all-reduce (what the drivers report per iteration)
+    type(comm).timing = True
+    comm.reset_counters()
+    for _ in range(3):
+        comm.allreduce_tensor_(torch.ones(1, dtype=torch.float64))
+    type(comm).timing = False
+    assert comm.allreduce_calls == 3 and comm.allreduce_host_s > 0.0
     info = startup_report(dd, [v.buf])
     assert info['rank'] == rank and info['backend'] == 'gloo'
     v._invalidate()

@@ -165,6 +165,14 @@ def test_bench_runs_as_the_driver_launches_it(nproc, backend):
         if nproc > 2:
             assert mg['halo_form']['identical'] and all(mg['halo_form']['identical'].values())
         assert mg['wire_bound']['ceiling_GBs'] > 0
+        # ... and where an ITERATION of the solve goes on every rank: device time of S, P,
+        # W, W^T per apply, the host's wait for S's one halo, the scalar all-reduces
+        assert [r['rank'] for r in mg['solve_per_rank']] == list(range(nproc))
+        for r in mg['solve_per_rank']:
+            assert r['S_device_ms_per_apply'] > 0 and r['P_device_ms_per_apply'] > 0
+            assert r['W_device_ms_per_apply'] > 0 and r['WT_device_ms_per_apply'] > 0
+            assert r['S_host_wait_for_halo_ms_last_apply'] >= 0
+            assert r['allreduce_calls_per_iteration'] >= 2 and r['allreduce_host_ms_each'] > 0
         assert res.stderr.count('stk start-up:') == nproc
 
 

@@ -690,6 +690,30 @@ def _bench_vector(N, M):
     return np.random.RandomState(128).rand(N, M)
 
 
+def _solve_against_fixture(problem, J_space, J_time, arithmetic):
+    import heateq_mpi as hm
+    from source.linalg import PCG
+    g = load_golden('o1_pcg_%s_J%d_J%d' % (problem, J_time, J_space))
+    h = hm.HeatEquationMPI(J_space=J_space, J_time=J_time, problem=problem,
+                           arithmetic=arithmetic)
+    st, sx = (int(v) for v in g['sample_strides'])
+    x = _vec(h.dofs_distr, _bench_vector(h.N, h.M))
+    assert relerr(_np(h.W @ x)[::st, ::sx], g['WX_sample']) < 1e-13
+    assert relerr(_np(h.S @ x)[::st, ::sx], g['SX_sample']) < 1e-10
+    assert relerr(_np(h.P @ x)[::st, ::sx], g['PX_sample']) < 1e-10
+    del x
+    hist = []
+    w, it = PCG(h.WT_S_W, h.P, h.rhs, history=hist)
+    assert it == int(g['iters']), (it, int(g['iters']))
+    tag = '%s_J%d_J%d' % (problem, J_time, J_space) + ('' if arithmetic == 'fast' else '_%s_arithmetic' % arithmetic)
+    dev = _record_history_dev(tag, hist, g['hist'])
+    assert dev < (HIST_RTOL if arithmetic == 'fast' else HIST_RTOL_REFERENCE), dev
+    wn = _np(w)
+    assert abs(np.linalg.norm(wn) - g['w_norm']) < 1e-10 * g['w_norm']
+    assert relerr(wn[::st, ::sx], g['w_sample']) < (1e-9 if arithmetic == 'fast' else 1e-10)
+    return h
+
+
 @pytest.mark.parametrize('arithmetic', ['fast', 'accurate', 'reference'])
 @pytest.mark.parametrize('problem,J_space,J_time', [('square', 6, 3),
                                                     ('square', 8, 5),
@@ -716,26 +740,30 @@ def test_baseline_configs_solve_matches_oracle_trajectory(stk, problem, J_space,
     fast default is held to 1e-9 per entry = twice what it measures (4.6e-10),
     and to 1e-10 relative to the initial residual; DESIGN.md section 5 attributes
     the difference."""
-    import heateq_mpi as hm
-    from source.linalg import PCG
-    g = load_golden('o1_pcg_%s_J%d_J%d' % (problem, J_time, J_space))
-    h = hm.HeatEquationMPI(J_space=J_space, J_time=J_time, problem=problem,
-                           arithmetic=arithmetic)
-    st, sx = (int(v) for v in g['sample_strides'])
-    x = _vec(h.dofs_distr, _bench_vector(h.N, h.M))
-    assert relerr(_np(h.W @ x)[::st, ::sx], g['WX_sample']) < 1e-13
-    assert relerr(_np(h.S @ x)[::st, ::sx], g['SX_sample']) < 1e-10
-    assert relerr(_np(h.P @ x)[::st, ::sx], g['PX_sample']) < 1e-10
-    del x
-    hist = []
-    w, it = PCG(h.WT_S_W, h.P, h.rhs, history=hist)
-    assert it == int(g['iters']), (it, int(g['iters']))
-    tag = '%s_J%d_J%d' % (problem, J_time, J_space) + ('' if arithmetic == 'fast' else '_%s_arithmetic' % arithmetic)
-    dev = _record_history_dev(tag, hist, g['hist'])
-    assert dev < (HIST_RTOL if arithmetic == 'fast' else HIST_RTOL_REFERENCE), dev
-    wn = _np(w)
-    assert abs(np.linalg.norm(wn) - g['w_norm']) < 1e-10 * g['w_norm']
-    assert relerr(wn[::st, ::sx], g['w_sample']) < (1e-9 if arithmetic == 'fast' else 1e-10)
+    _solve_against_fixture(problem, J_space, J_time, arithmetic)
+
+
+@pytest.mark.parametrize('arithmetic', ['fast', 'accurate', 'reference'])
+@pytest.mark.parametrize('problem,J_space,J_time', [('cube', 4, 4), ('lshape_jitter', 6, 4)])
+def test_second_problem_and_irregular_values_solve_matches_oracle_trajectory(stk, problem, J_space, J_time,
+                                                                             arithmetic):
+    """The whole solve (reference heateq_mpi_test.py:138-189) on the reference's SECOND
+    problem and on matrices whose values do not repeat, against oracle fixtures
+    (tests/golden/make_oracle_vectors.py --problem ...): iteration count equal, every
+    r.Pr within the bound, the iterate and S / P / W of the bench vector on the sample.
+    `cube`, J_space = 4 (reference source/problem.py:21-41): M = 29 791, 15-point rows
+    (K = 16 slots), 8 Gauss-Seidel dependency groups, the 15^3 level inside the fused
+    coarse kernel, Galerkin products with rows beyond 32 entries.  `lshape_jitter`,
+    J_space = 6: every interior vertex moved, so no two entries of M_x, A_x or of any
+    Galerkin product repeat (BASELINE config 4's "irregular CSR"; the reference takes
+    any CSR, source/mpi_kron.py:135-150) -- S streams row pairs with explicit values,
+    its last stage the plain sliced-ELL form, and the family's Gauss-Seidel copies
+    carry irregular values through every level."""
+    h = _solve_against_fixture(problem, J_space, J_time, arithmetic)
+    if problem == 'lshape_jitter':
+        pk = h.S.ell.packed_for(h.rhs.n_loc)
+        assert pk.ok and pk.explicit  # the solve above did stream explicit-value pairs
+
 
 
 @pytest.mark.parametrize('problem,J_space,J_time', [('square', 9, 6),
