@@ -744,7 +744,7 @@ def test_baseline_configs_solve_matches_oracle_trajectory(stk, problem, J_space,
 
 
 @pytest.mark.parametrize('arithmetic', ['fast', 'accurate', 'reference'])
-@pytest.mark.parametrize('problem,J_space,J_time', [('cube', 4, 4), ('lshape_jitter', 6, 4)])
+@pytest.mark.parametrize('problem,J_space,J_time', [('cube', 4, 4), ('lshape_jitter', 6, 5)])
 def test_second_problem_and_irregular_values_solve_matches_oracle_trajectory(stk, problem, J_space, J_time,
                                                                              arithmetic):
     """The whole solve (reference heateq_mpi_test.py:138-189) on the reference's SECOND
