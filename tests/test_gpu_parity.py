@@ -760,7 +760,7 @@ def test_second_problem_and_irregular_values_solve_matches_oracle_trajectory(stk
     its last stage the plain sliced-ELL form, and the family's Gauss-Seidel copies
     carry irregular values through every level."""
     h = _solve_against_fixture(problem, J_space, J_time, arithmetic)
-    if problem == 'lshape_jitter':
+    if problem == 'lshape_jitter' and arithmetic != 'reference':  # (the reference mode runs the five-term S)
         pk = h.S.ell.packed_for(h.rhs.n_loc)
         assert pk.ok and pk.explicit  # the solve above did stream explicit-value pairs
 
