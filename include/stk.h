@@ -474,7 +474,7 @@ int stk_kron_plan_create(int32_t M, int32_t n_mats,
 int stk_kron_plan_destroy(stk_kron_plan *plan);
 /* Any output may be NULL.  K: slots per row of the sliced-ELL copy; packed = 1
  * if the dictionary form was built; rows_per_unit = 2 if a row-pair form was
- * built as well -- stk_kron_plan_apply uses it for slabs of 24 time steps and
+ * built as well -- stk_kron_plan_apply uses it for slabs of 8 time steps and
  * more, the one-row form below (tuning key "pack_rows" = 1: no pairs in plans
  * created afterwards).  packed = 0 with rows_per_unit = 2: matrices without a
  * dictionary whose rows still share columns -- pairs with explicit values

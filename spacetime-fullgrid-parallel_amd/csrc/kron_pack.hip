@@ -878,7 +878,12 @@ extern "C" int stk_kron_pack_apply_multi_steps(void *stream, const stk_pack_patt
     }
     STK_REQUIRE(((uintptr_t)y & 15) == 0, "stk_kron_pack_apply_multi: y must be 16-byte aligned");
     hipStream_t st = stk_stream(stream);
-    if (g_pack_multi_lanes) {
+    // A lane group per term pays where the slab is long or does not fit the Infinity
+    // Cache; on short slabs of small problems the turn-taking lanes are level or ahead in
+    // a loop of launches and level inside S (profiles/r05_multi_lanes_vs_turns.log).
+    const bool lanes = g_pack_multi_lanes == 2 ||
+                       (g_pack_multi_lanes == 1 && (n_loc >= 24 || (int64_t)pat->M * ld * 8 > ((int64_t)256 << 20)));
+    if (lanes) {
         const int rc = stk_kron_pack_terms_launch(st, pat, n_loc, ld, n_terms, t, xs_host, t_begin_host, t_end_host,
                                                   beta, y);
         if (rc >= 0) return rc;

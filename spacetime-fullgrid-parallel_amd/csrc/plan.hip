@@ -482,7 +482,7 @@ extern "C" int stk_kron_plan_apply(stk_kron_plan *p, void *stream, int32_t n_loc
             if (rc) return rc;
         }
         // short slabs keep one row per slot row (measured: source/linop.py PAIR_MIN_STEPS)
-        const stk_pack_pattern *form = p->paired && n_loc >= 24 ? &p->pack_pairs : &p->pack;
+        const stk_pack_pattern *form = p->paired && n_loc >= 8 ? &p->pack_pairs : &p->pack;
         return stk_kron_pack_apply(stream, form, n_loc, ld, n_terms, t, x, ghosts ? ghost_work : nullptr, beta, y);
     }
     if (p->explicit_pairs && n_loc >= 24) {
@@ -516,7 +516,7 @@ extern "C" int stk_kron_plan_ghost_apply(stk_kron_plan *p, void *stream, int32_t
                     k, t[k].mat, p->n_mats);
     if (!x_lo && !x_hi) return 0;
     if (p->packed) {
-        const stk_pack_pattern *form = p->paired && n_loc >= 24 ? &p->pack_pairs : &p->pack;
+        const stk_pack_pattern *form = p->paired && n_loc >= 8 ? &p->pack_pairs : &p->pack;
         return stk_kron_pack_ghost_apply(stream, form, n_loc, ld, n_terms, t, x_lo, x_hi, y);
     }
     if (p->explicit_pairs && n_loc >= 24) {

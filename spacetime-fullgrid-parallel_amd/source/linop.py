@@ -502,11 +502,15 @@ class EllMatrices:
                            not main.all(), counts, own)
         self._packed, self._packed_lock = {}, threading.Lock()
 
-    # Slabs of fewer time steps than this keep one row per slot row: measured on
-    # the slab shapes of 2-, 4- and 8-GPU runs (profiles/r02_slab_shapes2.log),
-    # pairs win from 32 steps on (0.182 -> 0.175 ms) and lose below (17 steps:
-    # 0.089 -> 0.096 ms; 8 steps: 0.046 -> 0.048 ms).
-    PAIR_MIN_STEPS = 24
+    # Slabs of fewer time steps than this keep one row per slot row.  Round 2 measured
+    # pairs to win from 32 steps on and to lose below (profiles/r02_slab_shapes2.log) and
+    # set 24; on today's kernel they win on every slab shape of a 2-, 4- and 8-rank run
+    # (profiles/r05_slab_shapes_J9.log, _J10.log: 9 steps 0.053 -> 0.050 ms, 17 steps
+    # 0.086 -> 0.082 ms at J_space = 9, 0.429 -> 0.359 ms at J_space = 10).  Pairs with
+    # EXPLICIT values (no dictionary) were only measured from 33 steps on
+    # (profiles/r03_ab_jitter_J8_33.log): below 24 such matrices keep the plain form.
+    PAIR_MIN_STEPS = 8
+    EXPLICIT_PAIR_MIN_STEPS = 24
 
     @property
     def packed(self):
@@ -516,7 +520,10 @@ class EllMatrices:
     def packed_for(self, n_loc):
         """The packed form for a slab of n_loc time steps."""
         rows = PackedEllMatrices.ROWS_PER_UNIT if n_loc >= self.PAIR_MIN_STEPS else 1
-        return self.packed_variant(rows)
+        form = self.packed_variant(rows)
+        if form.ok and form.explicit and n_loc < self.EXPLICIT_PAIR_MIN_STEPS:
+            form = self.packed_variant(1)
+        return form
 
     def packed_variant(self, rows_per_unit):
         """The packed form with 1 or 2 matrix rows per slot row (falls back to 1

@@ -1558,22 +1558,23 @@ def test_kron_pack_inputs_per_term(stk):
                 for rows in (1, 2):
                     form = ell.packed_variant(rows)
                     assert form.ok and form.rows_per_unit == rows and not form.explicit
-                    y = slab(y0)
-                    form.apply_multi([(dev_tri[k], which[k], xs[k]) for k in range(nt)],
-                                     n_loc, ld, beta, y)
                     tag = (name, n_loc, shape, rows)
-                    y_steps = slab(y0)
-                    form.apply_multi([(dev_tri[k], which[k], xs[k]) for k in range(nt)],
-                                     n_loc, ld, beta, y_steps,
-                                     steps=[time_factor_steps(t) for t in tris])
-                    assert torch.equal(y_steps, y), tag
-                    _lib.check(_lib.lib().stk_set_tuning(b'pack_multi_lanes', 0))
+                    specs_ = [(dev_tri[k], which[k], xs[k]) for k in range(nt)]
+                    y, y_steps, y_turns, y_auto = slab(y0), slab(y0), slab(y0), slab(y0)
                     try:
-                        y_turns = slab(y0)
-                        form.apply_multi([(dev_tri[k], which[k], xs[k]) for k in range(nt)],
-                                         n_loc, ld, beta, y_turns)
+                        # 2: a lane group per term whatever the slab (1, the default, takes
+                        # it from 24 steps on or beyond the Infinity Cache), 0: turns
+                        _lib.check(_lib.lib().stk_set_tuning(b'pack_multi_lanes', 2))
+                        form.apply_multi(specs_, n_loc, ld, beta, y)
+                        form.apply_multi(specs_, n_loc, ld, beta, y_steps,
+                                         steps=[time_factor_steps(t) for t in tris])
+                        _lib.check(_lib.lib().stk_set_tuning(b'pack_multi_lanes', 0))
+                        form.apply_multi(specs_, n_loc, ld, beta, y_turns)
                     finally:
                         _lib.check(_lib.lib().stk_set_tuning(b'pack_multi_lanes', 1))
+                    form.apply_multi(specs_, n_loc, ld, beta, y_auto)
+                    assert torch.equal(y_steps, y), tag
+                    assert torch.equal(y_auto, y), tag
                     assert torch.equal(y_turns, y), tag
                     assert relerr(y[:, :n_loc].cpu().numpy(), want) < 1e-13, tag
                     if shape == 'schur':
