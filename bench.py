@@ -134,8 +134,6 @@ def pcg_cpu_baseline(problem, J_time, J_space):
     from oracle.krylov import _dot
     from source.assembly import prolongation_matrices, space_load, space_matrices, time_matrices
     from source.problem import problem_helper
-    cores = len(os.sched_getaffinity(0))
-    omg.THREADS = cores
     t_setup = time.perf_counter()
     mesh, _, tmesh, data, _ = problem_helper(problem, J_space, J_time)
     A_t, L_t, M_t, G_t, u0_t = time_matrices(tmesh)
@@ -143,6 +141,9 @@ def pcg_cpu_baseline(problem, J_time, J_space):
     o = HeatEquationOracle(dict(A_t=A_t, L_t=L_t, M_t=M_t, G_t=G_t, M_x=M_x, A_x=A_x,
                                 P_mats=prolongation_matrices(mesh), u0_t=u0_t,
                                 u0_x=space_load(mesh, data['u0'])), J_time)
+    # threads actually used: batches of time slices are cut into at most N chunks
+    cores = min(len(os.sched_getaffinity(0)), o.N)
+    omg.THREADS = cores
     b = o.rhs()
     t_setup = time.perf_counter() - t_setup
     w = np.zeros_like(b)

@@ -574,3 +574,25 @@ def test_row_grouping_of_the_packed_kronecker_form():
     # argument errors are reported, not executed
     assert lib.stk_pack_group_rows(4, 7, None, None, None, None, 0, 2, 10, None, None, None, None) != 0
     assert b'stk_pack_group_rows' in lib.stk_last_error()
+
+
+def test_newest_pmc_traffic_record_belongs_to_this_tree():
+    """bench.py reports roofline.traffic from the newest record
+    profiles/r*_pmc_traffic.json and refuses one measured on other kernel sources
+    (round 4's driver line lost its traffic figure to a commit made two minutes after
+    the PMC pass).  The record must carry the hash of the kernel file and its header as
+    they stand in this tree, and the hash of the plan it streamed: a change of
+    csrc/kron_pack.hip or csrc/stk_common.h without a new PMC pass
+    (tools/profile_round.sh) fails HERE, on the CPU, before the round ends."""
+    import glob
+    import json
+    import bench  # (conftest puts the repository root on sys.path)
+    records = sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_pmc_traffic.json')))
+    assert records, 'no PMC traffic record under profiles/'
+    rec = json.load(open(records[-1]))
+    assert rec['source_sha'] == bench.kernel_source_sha(), (
+        '%s was measured on other kernel sources: run tools/profile_round.sh on the GPU box and '
+        'commit its pmc_traffic.json' % os.path.basename(records[-1]))
+    assert rec.get('plan_sha'), 'the record does not name the plan it streamed'
+    assert (rec['J_time'], rec['J_space'], rec['problem']) == (6, 9, 'square')  # bench.py's default workload
+    assert 0.5e9 < rec['hbm_bytes_per_launch'] < 2.5e9
