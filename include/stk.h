@@ -709,6 +709,19 @@ typedef struct {
     const double *data;
 } stk_csr_host;
 
+/* The exact solve on level 0 (multigrid.py:161-165, 169-171) is a dense inverse
+ * here.  By default the library inverts the coarsest matrices itself (Gauss-Jordan
+ * with partial pivoting); a caller whose other code path inverts them with its own
+ * factorisation -- the Python planner of this repository takes numpy.linalg.inv,
+ * i.e. LAPACK -- hands that routine over, and plans created from then on carry ITS
+ * inverse: the two planners' V-cycles are then equal bit for bit, not to 1e-13.
+ * fn(n, a, inv, user): a and inv are n x n, row-major, HOST; returns 0 on success.
+ * fn = NULL restores the built-in inverse.  Called on the thread that calls
+ * stk_mg_create_from_csr. */
+typedef int (*stk_dense_inverse_fn)(int32_t n, const double *a, double *inv,
+                                    void *user);
+int stk_mg_set_coarse_inverse(stk_dense_inverse_fn fn, void *user);
+
 int stk_mg_create_from_csr(int32_t n_levels, const stk_csr_host *A_fine,
                            const stk_csr_host *M_fine,
                            const stk_csr_host *P_host,

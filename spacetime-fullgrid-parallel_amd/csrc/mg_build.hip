@@ -438,9 +438,14 @@ bool ell_rows(Builder &B, const Union &u, const std::vector<int32_t> &order, boo
 
 Union union_of(const Csr &m) { return make_union(m, nullptr); }
 
+// The caller's own dense inverse (stk_mg_set_coarse_inverse), or none.
+stk_dense_inverse_fn g_inverse_fn = nullptr;
+void *g_inverse_user = nullptr;
+
 // dense inverse by Gauss-Jordan elimination with partial pivoting (level 0 is tiny)
 bool dense_inverse(std::vector<double> a, int n, double *out)
 {
+    if (g_inverse_fn != nullptr) return g_inverse_fn(n, a.data(), out, g_inverse_user) == 0;
     std::vector<double> inv((size_t)n * n, 0.0);
     for (int i = 0; i < n; ++i) inv[(size_t)i * n + i] = 1.0;
     for (int c = 0; c < n; ++c) {
@@ -473,6 +478,13 @@ bool dense_inverse(std::vector<double> a, int n, double *out)
 }
 
 }  // namespace
+
+extern "C" int stk_mg_set_coarse_inverse(stk_dense_inverse_fn fn, void *user)
+{
+    g_inverse_fn = fn;
+    g_inverse_user = user;
+    return 0;
+}
 
 extern "C" int stk_mg_create_from_csr(int32_t n_levels, const stk_csr_host *A_fine, const stk_csr_host *M_fine,
                                       const stk_csr_host *P_host, const double *coords_host, int32_t dim,

@@ -402,6 +402,8 @@ class HeatEquationMPI:
 
         from source.linop import forget_union_pattern
         forget_union_pattern()
+        if hasattr(self.hierarchy, 'forget'):
+            self.hierarchy.forget()  # Galerkin chains, R A products: only the plans' construction needs them
         mark('operators and right-hand side')
         self.setup_time = MPI.Wtime() - start_time
         self.mem_after_mpi = mem()

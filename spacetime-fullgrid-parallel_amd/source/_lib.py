@@ -167,6 +167,7 @@ _PROTOTYPES = {
         c_p, ctypes.POINTER(PackPattern), c_i32, c_i32, c_i32,
         ctypes.POINTER(KronPackTerm), ctypes.POINTER(c_p), c_p, c_p, c_f64, c_p
     ]),
+    'stk_mg_set_coarse_inverse': (ctypes.c_int, [c_p, c_p]),
     'stk_interleave_ghosts': (ctypes.c_int, [c_p, c_i32, c_p, c_p, c_p]),
     'stk_kron_plan_create': (ctypes.c_int, [
         c_i32, c_i32, ctypes.POINTER(c_p), ctypes.POINTER(c_p),

@@ -63,6 +63,19 @@ class MeshHierarchy:
                 slot['value'] = make()
         return slot['value']
 
+    def forget(self):
+        """Drops what depends on matrix VALUES -- Galerkin chains, R A products and the
+        device copies of R, P they were formed from -- once the plans that asked for
+        them are built (the plans keep what they point into).  Those entries are keyed
+        by the ARRAYS of the matrices (_mat_key): the matrices handed to MultiGrid /
+        MultiGridFamily are treated as immutable while plans are being built on a
+        hierarchy, and a caller that changes values in place calls this before it
+        builds the next plan (HeatEquationMPI calls it at the end of its set-up).  What
+        depends on the mesh alone (tile orders, bands, transfer copies) stays."""
+        with self._shared_lock:
+            for key in [k for k in self._shared if k[0] in ('galerkin', 'galerkin_rp', 'ra')]:
+                del self._shared[key]
+
     def tile_order(self, n):
         """Mesh-tile processing order of the first n dofs (index order without
         coordinates)."""
@@ -163,14 +176,19 @@ def galerkin_product(R, A, P, cache=None):
     if _lib.compute_device().type != 'cuda' or R.shape[0] < 64:
         return on_host()
 
+    def upload(m):
+        return (_lib.to_dev(np.asarray(m.indptr, dtype=np.int32)), _lib.to_dev(np.asarray(m.indices, dtype=np.int32)),
+                _lib.to_dev(np.asarray(m.data, dtype=np.float64)))
+
     def up(m, key=None):
-        if cache is not None and key is not None and key in cache:
+        if cache is None or key is None:
+            return upload(m)
+        # the per-level dict is shared by the plan builders' threads (K's chain and the
+        # family's two run side by side): filled under its own lock
+        with cache.setdefault('lock', threading.Lock()):
+            if key not in cache:
+                cache[key] = upload(m)
             return cache[key]
-        dev = (_lib.to_dev(np.asarray(m.indptr, dtype=np.int32)), _lib.to_dev(np.asarray(m.indices, dtype=np.int32)),
-               _lib.to_dev(np.asarray(m.data, dtype=np.float64)))
-        if cache is not None and key is not None:
-            cache[key] = dev
-        return dev
 
     nc, cap = R.shape[0], (16 if P is not None else 32)
     dR, dA = up(R, 'R'), up(A)  # `cache` is per level: the role names the matrix

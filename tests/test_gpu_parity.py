@@ -2372,6 +2372,32 @@ def test_multigrid_plan_from_csr_through_ctypes_only(stk):
                 # accumulation order in both; the coarsest level's dense inverse comes
                 # from LAPACK in one and from Gauss-Jordan in the other)
                 stk.check(lib.stk_mg_destroy(plan))
+                # ... and with the caller's inverse handed over (stk_mg_set_coarse_inverse:
+                # numpy.linalg.inv, what the Python planner takes) the two planners'
+                # V-cycles are EQUAL
+                INV = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_int32, ctypes.POINTER(ctypes.c_double),
+                                       ctypes.POINTER(ctypes.c_double), ctypes.c_void_p)
+
+                def lapack_inverse(n0, a_ptr, inv_ptr, user):
+                    a = np.ctypeslib.as_array(a_ptr, shape=(n0, n0))
+                    np.ctypeslib.as_array(inv_ptr, shape=(n0, n0))[...] = np.linalg.inv(a)
+                    return 0
+
+                hook = INV(lapack_inverse)
+                stk.check(lib.stk_mg_set_coarse_inverse(ctypes.cast(hook, ctypes.c_void_p), None))
+                try:
+                    plan = ctypes.c_void_p()
+                    stk.check(lib.stk_mg_create_from_csr(
+                        len(P_mats) + 1, ctypes.byref(a_h), None, P_arr,
+                        coords.ctypes.data if with_coords else None, coords.shape[1],
+                        3, 2, 1.0, 0, None, ld, ctypes.byref(plan)))
+                finally:
+                    stk.check(lib.stk_mg_set_coarse_inverse(None, None))
+                u_eq = torch.empty_like(f)
+                stk.check(lib.stk_mg_apply(plan, stk.stream(), n_loc, ld, 1.0, None,
+                                           None, stk.ptr(f), stk.ptr(u_eq)))
+                assert np.array_equal(u_eq[:, :n_loc].cpu().numpy(), py), (problem, with_coords)
+                stk.check(lib.stk_mg_destroy(plan))
                 # --- the same plan with the default arithmetic of HeatEquationMPI
                 # ('accurate'): Gauss-Seidel rows with their diagonal (plan-time key
                 # "mg_gs_diag_free" = 0) and the restricted residual as R (A u - f)
