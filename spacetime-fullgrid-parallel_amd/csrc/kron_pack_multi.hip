@@ -266,6 +266,7 @@ __global__ __launch_bounds__(BS, 4) void kron_pack_terms_kernel(const TermArgs<N
 
 int g_terms_wg_per_cu = 0;  // 0: two workgroups per CU
 int g_terms_flags = 3;
+int g_terms_r = 0;  // cap on the slot rows of a group (0: as many as 512 lanes hold)
 
 template <int NT, int K, int RP>
 int launch_npf(hipStream_t st, const TermArgs<NT> &a, unsigned grid, size_t lds)
@@ -285,6 +286,7 @@ template <int NT, int RP>
 int launch(hipStream_t st, TermArgs<NT> a, int K)
 {
     a.R = BS / a.W;
+    if (g_terms_r > 0 && a.R > g_terms_r) a.R = g_terms_r;
     if (a.R * K > 4 * BS) a.R = 4 * BS / K;  // at most 4 prefetched words per thread
     const int KS = (K + 3) & ~3;
     auto lds_of = [&](int R) {
@@ -372,6 +374,10 @@ int stk_kron_pack_terms_set_tuning(const char *key, int32_t value)
 {
     if (std::strcmp(key, "terms_wg_per_cu") == 0) {
         g_terms_wg_per_cu = value;
+        return 0;
+    }
+    if (std::strcmp(key, "terms_r") == 0) {
+        g_terms_r = value;
         return 0;
     }
     if (std::strcmp(key, "terms_flags") == 0) {

@@ -596,3 +596,28 @@ def test_newest_pmc_traffic_record_belongs_to_this_tree():
     assert rec.get('plan_sha'), 'the record does not name the plan it streamed'
     assert (rec['J_time'], rec['J_space'], rec['problem']) == (6, 9, 'square')  # bench.py's default workload
     assert 0.5e9 < rec['hbm_bytes_per_launch'] < 2.5e9
+
+
+def test_time_factor_steps():
+    """linop.time_factor_steps: the local time steps at which a tridiagonal time factor
+    (three diagonals, as the kernels take them) reads its input -- what
+    stk_kron_pack_apply_multi_steps is told per term.  Column t is reached through
+    sub[t + 1], dia[t] and super[t - 1]; against the dense matrix's non-zero columns."""
+    from source.linop import time_factor_steps
+    rng = np.random.RandomState(8)
+    assert time_factor_steps(None) is None
+    for n in (1, 2, 5, 17):
+        for trial in range(40):
+            t = np.zeros((3, n))
+            for _ in range(int(rng.randint(0, 3))):
+                d, c = int(rng.randint(3)), int(rng.randint(n))
+                if (d == 0 and c == 0) or (d == 2 and c == n - 1):
+                    continue  # those entries couple to the neighbour ranks' rows, not to local steps
+                t[d, c] = rng.rand() + 0.1
+            T = np.diag(t[1]) + np.diag(t[0, 1:], -1) + np.diag(t[2, :-1], 1)
+            cols = np.flatnonzero(np.abs(T).sum(axis=0))
+            want = (0, 0) if len(cols) == 0 else (int(cols[0]), int(cols[-1]) + 1)
+            assert time_factor_steps(t) == want, (n, t)
+    g = np.zeros((3, 65))
+    g[1, 0] = 1.0  # G_t = e_0 e_0^T (reference heateq_mpi.py:86-88)
+    assert time_factor_steps(g) == (0, 1)
