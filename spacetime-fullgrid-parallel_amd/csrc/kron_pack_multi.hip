@@ -7,7 +7,7 @@
 //
 // Round 4 let the terms take TURNS in one lane (kron_pack.hip, MULTI = true: K gathers
 // from xs[0], its sums, K gathers from xs[1], ...).  Its counters (round 5,
-// profiles/r05a_pmc_*.txt) showed what that costs: a workgroup of 15 slot rows x 33
+// profiles/r05_refetch_pmc_turns_*.txt) showed what that costs: a workgroup of 15 slot rows x 33
 // lanes keeps TWO slabs' neighbourhoods of 30 matrix rows alive, the 64 workgroups of
 // an XCD together more than its 4 MiB L2 holds, and the launch fetched 3.1 GB where
 // 1.3 GB suffice; with half the workgroups the traffic halved but the time grew --
