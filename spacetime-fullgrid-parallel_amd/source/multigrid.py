@@ -311,6 +311,16 @@ def coupling_bands(coords, indptr, indices, rows_of=None, coord_band=None):
     return band
 
 
+# Mesh rows per band of the strip-wise sweeps.  coupling_bands gives the thinnest bands
+# the coupling allows (single mesh rows on a structured mesh); the rows of a dependency
+# group are listed band by band and in tile order inside a band.  With one mesh row per
+# band a stage walks the level's full width before it comes back to the row above, and
+# the two readers of a gathered row are a whole mesh row of operands apart; with
+# BAND_MERGE rows per band the tile order inside the (thicker) band brings them within a
+# tile's width.  Coupled rows still lie at most one band apart (coarser bands keep the
+# property), the rows of a launch are independent, so results do not change by a bit.
+BAND_MERGE = int(__import__('os').environ.get('STK_BAND_MERGE', '1'))
+
 # Gauss-Seidel rows on the device: True = diagonal-free copies,
 # u_i = (f_i - sum_{j != i} a_ij u_j) / a_ii (PETSc MatSOR's form; one gather less
 # per row); False = the whole row in the slots and the reference's pure-Python
@@ -419,6 +429,8 @@ class _DeviceHierarchy:
             # bands for the strip-wise sweeps: coupled rows at most one band apart
             band = coupling_bands(hierarchy.coords, indptr, indices, rows_of,
                                   hierarchy.coord_band(n) if hasattr(hierarchy, 'coord_band') else None)
+            if band is not None and BAND_MERGE > 1 and hierarchy.coords is not None:
+                band = band // BAND_MERGE
             key = rank if band is None else band * np.int64(n) + rank
             vm = vals[1] if self.has_m else None
             # transfer operators and the restricted-residual product R A: independent
