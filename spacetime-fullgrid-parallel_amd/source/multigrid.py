@@ -320,6 +320,8 @@ def coupling_bands(coords, indptr, indices, rows_of=None, coord_band=None):
 # tile's width.  Coupled rows still lie at most one band apart (coarser bands keep the
 # property), the rows of a launch are independent, so results do not change by a bit.
 BAND_MERGE = int(__import__('os').environ.get('STK_BAND_MERGE', '1'))
+# ... for plans with per-slice coefficients (the preconditioner family)
+BAND_MERGE_FAMILY = int(__import__('os').environ.get('STK_BAND_MERGE_FAMILY', str(BAND_MERGE)))
 
 # Gauss-Seidel rows on the device: True = diagonal-free copies,
 # u_i = (f_i - sum_{j != i} a_ij u_j) / a_ii (PETSc MatSOR's form; one gather less
@@ -429,8 +431,9 @@ class _DeviceHierarchy:
             # bands for the strip-wise sweeps: coupled rows at most one band apart
             band = coupling_bands(hierarchy.coords, indptr, indices, rows_of,
                                   hierarchy.coord_band(n) if hasattr(hierarchy, 'coord_band') else None)
-            if band is not None and BAND_MERGE > 1 and hierarchy.coords is not None:
-                band = band // BAND_MERGE
+            merge = BAND_MERGE_FAMILY if self.has_m else BAND_MERGE
+            if band is not None and merge > 1 and hierarchy.coords is not None:
+                band = band // merge
             key = rank if band is None else band * np.int64(n) + rank
             vm = vals[1] if self.has_m else None
             # transfer operators and the restricted-residual product R A: independent
