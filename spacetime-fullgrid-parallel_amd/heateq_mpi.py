@@ -335,10 +335,15 @@ class HeatEquationMPI:
                         [self.M_x, self.A_x]).packed_for(n_steps)))
                 kinv = pool.submit(on_dev(MultiGrid), self.A_x, hierarchy,
                                    smoothsteps=smoothsteps, vcycles=vcycles, gs_rows=gs_rows)
+                # bands of 6 mesh rows for the family's strip-wise sweeps on longer slabs
+                # (source/multigrid.py BAND_MERGE: P -2 %, bit-identical); an
+                # environment override serves the A/B
+                n_steps_ = self.dofs_distr.t_end - self.dofs_distr.t_begin
+                merge = None if 'STK_BAND_MERGE_FAMILY' in os.environ else (6 if n_steps_ >= 16 else 1)
                 members = pool.submit(
                     on_dev(MultiGridFamily), self.A_x, self.M_x, hierarchy, ca=alpha,
                     cms=[2**j for j in range(self.J_time + 1)],
-                    smoothsteps=smoothsteps, vcycles=vcycles, gs_rows=gs_rows)
+                    smoothsteps=smoothsteps, vcycles=vcycles, gs_rows=gs_rows, band_merge=merge)
                 self.Kinv_x, self.C_family = kinv.result(), members.result()
             if arithmetic == 'accurate':
                 for plans in (self.Kinv_x._dev, self.C_family._dev):

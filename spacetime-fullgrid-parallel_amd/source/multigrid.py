@@ -311,16 +311,20 @@ def coupling_bands(coords, indptr, indices, rows_of=None, coord_band=None):
     return band
 
 
-# Mesh rows per band of the strip-wise sweeps.  coupling_bands gives the thinnest bands
-# the coupling allows (single mesh rows on a structured mesh); the rows of a dependency
-# group are listed band by band and in tile order inside a band.  With one mesh row per
-# band a stage walks the level's full width before it comes back to the row above, and
-# the two readers of a gathered row are a whole mesh row of operands apart; with
-# BAND_MERGE rows per band the tile order inside the (thicker) band brings them within a
-# tile's width.  Coupled rows still lie at most one band apart (coarser bands keep the
-# property), the rows of a launch are independent, so results do not change by a bit.
+# Mesh rows per band of the strip-wise sweeps (constructor argument `band_merge` of
+# MultiGrid / MultiGridFamily; None = these defaults).  coupling_bands gives the thinnest
+# bands the coupling allows (single mesh rows on a structured mesh); the rows of a
+# dependency group are listed band by band and in tile order inside a band.  With one
+# mesh row per band a stage walks the level's full width before it comes back to the row
+# above; with several mesh rows per band the tile order inside the (thicker) band keeps
+# the two readers of a gathered row within a tile's width.  Coupled rows still lie at most
+# one band apart (coarser bands keep the property, which mg.hip's strips rest on) and the
+# rows of a launch are independent: results do not change by a bit.  Measured
+# (profiles/r05_band_merge.log): the preconditioner family's P 21.6 -> 21.1 ms at 65 steps
+# and 26.0 -> 25.5 ms on config 5's 17-step slab with 4-8 rows per band, 5.36 -> 5.41 ms at
+# 9 steps; K's plans (two chains side by side inside S) gain nothing.  HeatEquationMPI
+# asks for 6 rows per band in the family's plan from 16 time steps on.
 BAND_MERGE = int(__import__('os').environ.get('STK_BAND_MERGE', '1'))
-# ... for plans with per-slice coefficients (the preconditioner family)
 BAND_MERGE_FAMILY = int(__import__('os').environ.get('STK_BAND_MERGE_FAMILY', str(BAND_MERGE)))
 
 # Gauss-Seidel rows on the device: True = diagonal-free copies,
@@ -341,7 +345,7 @@ GS_ALT_COPIES = False
 class _DeviceHierarchy:
     """Everything one libstk multigrid plan needs, resident on the device."""
     def __init__(self, mat_a, mat_m, hierarchy, smoothsteps, vcycles,
-                 coarse_mats, gs_rows=None):
+                 coarse_mats, gs_rows=None, band_merge=None):
         # row form of the Gauss-Seidel copies: 'free' (diagonal-free on every level),
         # 'full' (the reference's form on every level), 'owned' (the reference's form
         # on the finest level, which also gets the diagonal-free copies as its
@@ -349,6 +353,9 @@ class _DeviceHierarchy:
         # arithmetic runs on), None: the module switches GS_DIAG_FREE* above
         assert gs_rows in (None, 'free', 'full', 'owned')
         self.gs_rows = gs_rows
+        if band_merge is None:
+            band_merge = BAND_MERGE_FAMILY if mat_m is not None else BAND_MERGE
+        self.band_merge = max(1, int(band_merge))
         self.J = hierarchy.J
         self.smoothsteps, self.vcycles = smoothsteps, vcycles
         self.has_m = mat_m is not None
@@ -431,9 +438,8 @@ class _DeviceHierarchy:
             # bands for the strip-wise sweeps: coupled rows at most one band apart
             band = coupling_bands(hierarchy.coords, indptr, indices, rows_of,
                                   hierarchy.coord_band(n) if hasattr(hierarchy, 'coord_band') else None)
-            merge = BAND_MERGE_FAMILY if self.has_m else BAND_MERGE
-            if band is not None and merge > 1 and hierarchy.coords is not None:
-                band = band // merge
+            if band is not None and self.band_merge > 1 and hierarchy.coords is not None:
+                band = band // self.band_merge
             key = rank if band is None else band * np.int64(n) + rank
             vm = vals[1] if self.has_m else None
             # transfer operators and the restricted-residual product R A: independent
@@ -628,14 +634,15 @@ class MultiGrid(SpaceOp):
     member = None
 
     def __init__(self, mat, hierarchy, smoothsteps=2, vcycles=1,
-                 fuse_restrict=None, gs_rows=None):
+                 fuse_restrict=None, gs_rows=None, band_merge=None):
         self.num_applies = 0
         self.time_applies = 0
         self.hierarchy = hierarchy
         self.smoothsteps = smoothsteps
         self.vcycles = vcycles
         self._dev = _DeviceHierarchy(mat, None, hierarchy, smoothsteps,
-                                     vcycles, lambda a0, m0: [a0], gs_rows=gs_rows)
+                                     vcycles, lambda a0, m0: [a0], gs_rows=gs_rows,
+                                     band_merge=band_merge)
         if fuse_restrict is not None:
             # False: the restricted residual as the reference forms it,
             # R (A u - f) (multigrid.py:174-175); see stk_mg_set_option
@@ -695,7 +702,7 @@ class MultiGridFamily:
     BlockDiagMPI recognises members of one family and runs all time slices in
     one batched V-cycle."""
     def __init__(self, mat_a, mat_m, hierarchy, ca, cms, smoothsteps=2,
-                 vcycles=1, fuse_restrict=None, gs_rows=None):
+                 vcycles=1, fuse_restrict=None, gs_rows=None, band_merge=None):
         self.ca = float(ca)
         self.cms = [float(c) for c in cms]
         self.hierarchy = hierarchy
@@ -705,7 +712,7 @@ class MultiGridFamily:
             return [a0] + [self.ca * a0 + c * m0 for c in self.cms]
 
         self._dev = _DeviceHierarchy(mat_a, mat_m, hierarchy, smoothsteps,
-                                     vcycles, coarse, gs_rows=gs_rows)
+                                     vcycles, coarse, gs_rows=gs_rows, band_merge=band_merge)
         if fuse_restrict is not None:
             self._dev.set_option('fuse_restrict', bool(fuse_restrict))
         self.shape = self._dev.shape
