@@ -701,6 +701,11 @@ int stk_mg_smooth(stk_mg *mg, void *stream, int32_t level, int32_t n_loc,
  * ("fast_parts", 1) is the arithmetic the mirrored driver runs by default (r.Pr
  * histories within 1e-10 of the CPU path for 4 % of the solve); key 0 with
  * ("fuse_restrict", 0) has the reference's forms everywhere.
+ * With coordinates, the bands of the strip-wise sweeps hold several mesh rows
+ * (tuning key "mg_band_merge" as it stands when the plan is built; 0 = the default:
+ * 6 for a family, 1 for a single matrix): inside a thicker band a stage walks mesh
+ * tiles instead of the level's full width (a family's P apply 2 % faster on slabs of
+ * 17 time steps and more, bit-identical).
  * The host work runs on the threads of the library (STK_HOST_THREADS overrides
  * their number); STK_PLAN_TIMING=1 prints the seconds per stage on stderr. */
 typedef struct {

@@ -405,6 +405,7 @@ __global__ __launch_bounds__(SBS) void time_csr_kernel(int64_t total, int32_t M,
 
 int g_stk_tuning_epoch = 0;  // captured V-cycle graphs (mg.hip) belong to the tuning state they were recorded under
 extern int g_mg_graph, g_mg_graph_replays;
+extern int g_mg_band_merge;  // mg_build.hip
 
 extern "C" int stk_set_tuning(const char *key, int32_t value)
 {
@@ -418,6 +419,10 @@ extern "C" int stk_set_tuning(const char *key, int32_t value)
         return 0;
     }
     ++g_stk_tuning_epoch;
+    if (std::strcmp(key, "mg_band_merge") == 0) {  // plans built by stk_mg_create_from_csr from now on
+        g_mg_band_merge = value;
+        return 0;
+    }
     if (std::strcmp(key, "mg_graph") == 0) {
         g_mg_graph = value;
         return 0;

@@ -29,6 +29,8 @@
 
 #include "stk_common.h"
 
+int g_mg_band_merge = 0;  // tuning key "mg_band_merge": mesh rows per band of the strip-wise sweeps (0 = default)
+
 namespace {
 
 struct Csr {
@@ -623,7 +625,16 @@ extern "C" int stk_mg_create_from_csr(int32_t n_levels, const stk_csr_host *A_fi
         std::vector<int64_t> rank(n);
         for (int p = 0; p < n; ++p) rank[tile[p]] = p;
         lap("tile order");
-        const std::vector<int32_t> band = coupling_bands(coords_host, dim, u);
+        std::vector<int32_t> band = coupling_bands(coords_host, dim, u);
+        // several mesh rows per band for the strip-wise sweeps (tuning key "mg_band_merge" as
+        // it stands when the plan is built; 0 = the default: 6 for families a(t) = ca A +
+        // cm[t] M, 1 otherwise -- source/multigrid.py BAND_MERGE has the measurements):
+        // coarser bands keep "coupled rows at most one band apart", results do not change
+        if (coords_host && !band.empty()) {
+            const int merge = g_mg_band_merge > 0 ? g_mg_band_merge : (M_fine ? 6 : 1);
+            if (merge > 1)
+                for (auto &b : band) b /= merge;
+        }
         lap("bands");
         auto key = [&](int i) { return (band.empty() ? (int64_t)0 : (int64_t)band[i] * n) + rank[i]; };
         bool ells_ok = ell_rows(B, u, tile, false, 0, nullptr, nullptr, &K.a);
