@@ -63,6 +63,21 @@ def _hist_dev(tag, hist, ref, tol):
     return dev
 
 
+def _scalar_dev(tag, dev, tol):
+    """One measured deviation, recorded like _hist_dev's and then asserted."""
+    import json
+    import os
+    dev = float(dev)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    if os.path.isdir(out):
+        path = os.path.join(out, 'parity_history_dev.json')
+        rec = json.load(open(path)) if os.path.exists(path) else {}
+        rec[tag] = {'max_rel_dev': dev, 'entries': 1, 'asserted_bound': tol}
+        json.dump(rec, open(path, 'w'), indent=1, sort_keys=True)
+    assert dev < tol, (tag, dev, tol)
+    return dev
+
+
 # ---------------------------------------------------------------------------
 def test_blas1_and_dot(stk):
     rng = np.random.RandomState(0)
@@ -286,16 +301,21 @@ def test_heat_operators_and_solve_match_reference_golden(stk, g3, schur):
     assert iters == int(g3['pcg_iters_multigrid'])
     _hist_dev('golden_%d_%d_%s_rr' % (N, M, schur), rr, g3['pcg_rr_multigrid'], 1e-10)
     assert relerr(_np(w), g3['pcg_w_multigrid']) < 1e-10
+    tag = 'golden_%d_%d_%s' % (N, M, schur)
+    # 60 unconverged steps of plain CG amplify the last bits of one S apply
+    # (the oracle itself sits 7.5e-9 from the reference on g3_square3): the
+    # iterate after FIVE steps is held to the north star's 1e-10, the one after
+    # 60 to ten times what is recorded in parity_history_dev.json
     w2, it2 = PCG(S, IdentityMPI(dd), rhs, kmax=60)
     assert it2 == int(g3['pcg_unprec_iters_multigrid'])
-    assert relerr(_np(w2), g3['pcg_unprec_w_multigrid']) < 1e-6
+    _scalar_dev(tag + '_unprec_w', relerr(_np(w2), g3['pcg_unprec_w_multigrid']), 1e-7)
 
     lz = Lanczos(WT_S_W, P, w=_vec(dd, g3['X']))
     assert lz.iterations == int(g3['lz_its_multigrid'])
-    assert abs(lz.lmax - g3['lz_lmax_multigrid']) < 1e-6 * lz.lmax
-    assert abs(lz.lmin - g3['lz_lmin_multigrid']) < 1e-6 * lz.lmin
-    n = min(len(lz.alpha), 6)
-    assert np.allclose(lz.alpha[:n], g3['lz_alpha_multigrid'][:n], rtol=1e-7)
+    _scalar_dev(tag + '_lz_lmax', abs(lz.lmax / g3['lz_lmax_multigrid'] - 1.0), 1e-10)
+    _scalar_dev(tag + '_lz_lmin', abs(lz.lmin / g3['lz_lmin_multigrid'] - 1.0), 1e-10)
+    assert len(lz.alpha) == len(g3['lz_alpha_multigrid'])
+    _hist_dev(tag + '_lz_alpha', lz.alpha, g3['lz_alpha_multigrid'], 1e-10)
 
 
 @pytest.mark.parametrize('problem,J_space', [('square', 4), ('lshape', 3),

@@ -197,23 +197,30 @@ def test_heat_wiring_pcg_lanczos_match_reference(g3, precond):
     assert relerr(heat.P(X), g3['P_' + precond]) < 1e-11
     assert relerr(heat.WT_S_W(X), g3['WTSW_' + precond]) < 1e-11
 
+    # Bounds = ten times what the oracle measures against the reference's own
+    # output on the four fixtures (rr <= 1.4e-12, iterate <= 4.5e-16, Lanczos
+    # alpha <= 2.1e-14 over all iterations, lmax / lmin <= 2.1e-15): the GPU is
+    # held to 1e-10 against ORACLE trajectories, so the oracle's own pin must
+    # be tighter than that.
     rr = []
     w, iters, hist = pcg(heat.WT_S_W, heat.P, heat.rhs(),
                          callback=lambda w, r, k: rr.append(np.vdot(r, r)))
     assert iters == int(g3['pcg_iters_' + precond])
-    assert np.allclose(rr, g3['pcg_rr_' + precond], rtol=1e-6, atol=1e-22)
-    assert relerr(w, g3['pcg_w_' + precond]) < 1e-8
+    assert np.allclose(rr, g3['pcg_rr_' + precond], rtol=2e-11, atol=0.0)
+    assert relerr(w, g3['pcg_w_' + precond]) < 1e-14
+    # 60 unconverged steps of plain CG on S amplify a last-bit difference of
+    # one apply: 7.5e-9 on g3_square3 / multigrid, <= 1e-16 on the other seven
     w2, it2, _ = pcg(heat.S, lambda r: r.copy(), heat.rhs(), kmax=60)
     assert it2 == int(g3['pcg_unprec_iters_' + precond])
-    assert relerr(w2, g3['pcg_unprec_w_' + precond]) < 1e-6
+    assert relerr(w2, g3['pcg_unprec_w_' + precond]) < 1e-7
 
     lz = Lanczos(heat.WT_S_W, heat.P, X)
     assert lz.iterations == int(g3['lz_its_' + precond])
     n = len(g3['lz_alpha_' + precond])
-    assert np.allclose(lz.alpha[:min(n, 8)],
-                       g3['lz_alpha_' + precond][:min(n, 8)], rtol=1e-7)
-    assert abs(lz.lmax - g3['lz_lmax_' + precond]) < 1e-6 * lz.lmax
-    assert abs(lz.lmin - g3['lz_lmin_' + precond]) < 1e-6 * lz.lmin
+    assert len(lz.alpha) == n
+    assert np.allclose(lz.alpha, g3['lz_alpha_' + precond], rtol=2e-13, atol=0.0)
+    assert abs(lz.lmax - g3['lz_lmax_' + precond]) < 1e-13 * lz.lmax
+    assert abs(lz.lmin - g3['lz_lmin_' + precond]) < 1e-13 * lz.lmin
 
 
 def test_serial_wiring_equals_parallel_wiring():
