@@ -197,6 +197,24 @@ int stk_axpbyz(void *stream, int64_t n, double a, const double *x, double b,
 int64_t stk_dot_work_size(void);
 int stk_dot(void *stream, int64_t n, const double *x, const double *y,
             double *work, double *out);
+/* KronVectorMPI.dot (mpi_vector.py:205-210) with a value that does NOT depend on
+ * the number of ranks.  The reference (and stk_dot + a scalar all-reduce) adds the
+ * products slab by slab, so the last digits of every r.Pr of a solve move with
+ * the partition of the time axis (the reference against itself on 8 ranks:
+ * 4.6e-11 in the history).  stk_slab_dot sums the products of every TIME STEP over
+ * the spatial index in one fixed shape that depends on M alone (csrc/blas1.hip:
+ * blocks of 256 rows, 8 interleaved fused-multiply-add chains per block, pairwise
+ * tree, fixed tree over the blocks) and writes them to out_steps[t_begin + t], t <
+ * n_loc; the other entries of out_steps[0 .. N) are written as zero.  The caller
+ * all-reduces the N values (adding zeros is exact in any order) and adds them in
+ * increasing t (stk_sum_steps, host): bit for bit the same number on 1, 2, 4 or 8
+ * ranks.  x, y: slabs (M rows of ld doubles, time fastest, padding ignored);
+ * work: stk_slab_dot_work_size(M, n_loc) device doubles, 16-byte aligned. */
+int64_t stk_slab_dot_work_size(int32_t M, int32_t n_loc);
+int stk_slab_dot(void *stream, int32_t M, int32_t n_loc, int32_t ld,
+                 const double *x, const double *y, double *work, int32_t N,
+                 int32_t t_begin, double *out_steps);
+double stk_sum_steps(const double *steps_host, int32_t N);
 /* ---- time-slab partition (DofDistributionMPI, mpi_vector.py:5-38) ---------
  * Rank p owns the time rows [displs[p], displs[p] + counts[p]): N / size rows
  * each, the N % size extra rows go to the last ranks.  Any output pointer may
@@ -221,6 +239,19 @@ int stk_pcg_solve(void *stream, int64_t n, stk_operator_fn T, void *T_ctx,
                   stk_operator_fn P, void *P_ctx, stk_allreduce_fn allreduce,
                   void *allreduce_ctx, const double *b, double *w, double eps,
                   int32_t kmax, double *work, double *history, int32_t *iters);
+/* The same loop on slabs (M rows of ld doubles, this rank's time steps [t_begin,
+ * t_begin + n_loc) of N) with stk_slab_dot for the inner products: `allreduce` is
+ * then called with the N per-step sums, and history / iterate are bit for bit
+ * those of a one-rank run, whatever the number of ranks (given operators that
+ * have that property, as the Kronecker and multigrid applies of this library do).
+ * work: stk_pcg_slab_work_size(M, n_loc, ld, N) device doubles. */
+int64_t stk_pcg_slab_work_size(int32_t M, int32_t n_loc, int32_t ld, int32_t N);
+int stk_pcg_solve_slab(void *stream, int32_t M, int32_t n_loc, int32_t ld,
+                       int32_t N, int32_t t_begin, stk_operator_fn T, void *T_ctx,
+                       stk_operator_fn P, void *P_ctx, stk_allreduce_fn allreduce,
+                       void *allreduce_ctx, const double *b, double *w, double eps,
+                       int32_t kmax, double *work, double *history,
+                       int32_t *iters);
 
 /* ---- per-operation device-time counters (LinearOperatorMPI.num_applies /
  *      time_applies, mpi_kron.py:23-36, for hosts without the Python classes) -----
@@ -255,6 +286,15 @@ int stk_lanczos(void *stream, int64_t n, stk_operator_fn A, void *A_ctx,
                 double tol, double tol_bisec, double *work, double *alpha_host,
                 double *beta_host, double *lmax, double *lmin,
                 int32_t *iterations, int32_t *converged);
+/* On slabs, inner products through stk_slab_dot (see stk_pcg_solve_slab). */
+int64_t stk_lanczos_slab_work_size(int32_t M, int32_t n_loc, int32_t ld, int32_t N);
+int stk_lanczos_slab(void *stream, int32_t M, int32_t n_loc, int32_t ld, int32_t N,
+                     int32_t t_begin, stk_operator_fn A, void *A_ctx,
+                     stk_operator_fn P, void *P_ctx, stk_allreduce_fn allreduce,
+                     void *allreduce_ctx, double *w, int32_t max_iterations,
+                     double tol, double tol_bisec, double *work,
+                     double *alpha_host, double *beta_host, double *lmax,
+                     double *lmin, int32_t *iterations, int32_t *converged);
 
 /* ---- sum of Kronecker terms  y = beta*y + sum_k (T_k kron X_k) x_k --------
  * Replaces TridiagKronMatMPI._matvec (mpi_kron.py:214-219), i.e.
@@ -304,21 +344,26 @@ typedef struct {
 /* Tuning key (stk_set_tuning): "ell_wg_per_cu" (persistent workgroups per CU,
  * 0 = default).  K must be one of 5, 7, 9, 12, 16; at most 3 terms.
  * Terms with ghost rows (x_lo / x_hi) are handled as two launches: the
- * slab-local part, then stk_kron_ell_ghost_apply. */
+ * slab-local part, then stk_kron_ell_ghost_apply (with a copy of the old
+ * boundary entries of y in between when beta != 0).  Every entry of y is
+ * rounded as on one rank, wherever the time axis is cut. */
 int stk_kron_ell_apply(void *stream, const stk_ell_pattern *pattern_host,
                        int32_t n_loc, int32_t ld, int32_t n_terms,
                        const stk_kron_ell_term *terms_host, double beta,
                        double *y);
 
-/* Only the contribution of the ghost time rows of the same operator:
- *   y[:, 0]       += sum_k sub_k[0]       * X_k x_lo_k
- *   y[:, n_loc-1] += sum_k sup_k[n_loc-1] * X_k x_hi_k
- * i.e. what the first and last row of the ghosted block contribute in
- * TridiagKronIdentityMPI._matvec (mpi_kron.py:186-201, "first/last rows after
- * the halo arrived", :199-200).  A caller that overlaps the halo exchange with
- * compute calls stk_kron_ell_apply with x_lo = x_hi = NULL while the exchange
- * is in flight and this function once it has completed.  The x members of the
- * terms are ignored. */
+/* The first and last local time step of the same operator once the ghost time
+ * rows are there: "first/last rows after the halo arrived" of
+ * TridiagKronIdentityMPI._matvec (mpi_kron.py:186-201, :199-200).  A caller that
+ * overlaps the halo exchange with compute calls stk_kron_ell_apply with x_lo =
+ * x_hi = NULL and beta = 0 while the exchange is in flight and this function
+ * once it has completed.  The two steps are RECOMPUTED from x, x_lo and x_hi in
+ * the order of operations of the main kernel,
+ *   y[:, t] = sum_k fma(sup_k[t], z_k[t+1], fma(sub_k[t], z_k[t-1], dia_k[t] z_k[t])),
+ * and overwrite what the ghost-less call left there: the result is bit for bit
+ * the one-rank apply of the same rows, whatever the partition of the time axis
+ * (a share ADDED afterwards, as in rounds 1-5, puts the neighbour's term last in
+ * the sum and differs from the one-rank result in the last bits). */
 int stk_kron_ell_ghost_apply(void *stream, const stk_ell_pattern *pattern_host,
                              int32_t n_loc, int32_t ld, int32_t n_terms,
                              const stk_kron_ell_term *terms_host, double *y);
@@ -405,15 +450,19 @@ int stk_kron_pack_apply(void *stream, const stk_pack_pattern *pattern_host,
                         const stk_kron_pack_term *terms_host, const double *x,
                         const double *ghosts, double beta, double *y);
 
-/* What the ghost time rows add to y after stk_kron_pack_apply ran with ghosts =
- * NULL while the halo exchange was in flight (the reference overlaps the exchange
- * with the rows that do not need it, mpi_kron.py:193-200, mpi_vector.py:177-179):
- *   y[i][0] += sum_k sub_k[0] (X_k x_lo)[i],  y[i][n_loc-1] += sum_k super_k[n_loc-1] (X_k x_hi)[i].
- * x_lo / x_hi: the received rows as they arrive (contiguous, length M; NULL on a
- * side without a neighbour).  One lane per slot row on the packed stream. */
+/* The first and last local time step after stk_kron_pack_apply ran with ghosts =
+ * NULL and beta = 0 while the halo exchange was in flight (the reference overlaps
+ * the exchange with the rows that do not need it, mpi_kron.py:193-200,
+ * mpi_vector.py:177-179).  Both steps are recomputed from x and the received rows
+ * in the one-pass kernel's order of operations and OVERWRITE y[i][0] and
+ * y[i][n_loc-1]: pass + this call, the one-pass form with `ghosts`, and the
+ * one-rank apply agree bit for bit (tests: torch.equal).  x: the slab the pass
+ * read; x_lo / x_hi: the received rows as they arrive (contiguous, length M; NULL
+ * on a side without a neighbour).  One lane per slot row and side on the packed
+ * stream. */
 int stk_kron_pack_ghost_apply(void *stream, const stk_pack_pattern *pattern_host,
                               int32_t n_loc, int32_t ld, int32_t n_terms,
-                              const stk_kron_pack_term *terms_host,
+                              const stk_kron_pack_term *terms_host, const double *x,
                               const double *x_lo, const double *x_hi, double *y);
 
 /* The same packed stream with an input slab PER TERM: y = beta*y + sum_k (T_k kron
@@ -488,10 +537,10 @@ int stk_kron_plan_apply(stk_kron_plan *plan, void *stream, int32_t n_loc,
                         const double *x_lo, const double *x_hi,
                         double *ghost_work, double beta, double *y);
 
-/* The ghost rows' share after stk_kron_plan_apply ran with x_lo = x_hi = NULL while
- * the halo exchange was in flight (mpi_kron.py:193-200): y += what the two
- * received rows contribute to the first / last local time step.  x: the slab the
- * apply read (needed by plans without a packed form only). */
+/* After stk_kron_plan_apply ran with x_lo = x_hi = NULL and beta = 0 while the halo
+ * exchange was in flight (mpi_kron.py:193-200): the first / last local time step
+ * recomputed with the two received rows, as stk_kron_pack_ghost_apply /
+ * stk_kron_ell_ghost_apply do.  x: the slab the apply read. */
 int stk_kron_plan_ghost_apply(stk_kron_plan *plan, void *stream, int32_t n_loc,
                               int32_t ld, int32_t n_terms,
                               const stk_kron_pack_term *terms_host, const double *x,

@@ -87,6 +87,118 @@ __global__ __launch_bounds__(1024) void dot_final_kernel(int n_partial, const do
     if (threadIdx.x == 0) out[0] = r;
 }
 
+// ---- inner product of two slabs, one partial per TIME STEP -----------------------
+// KronVectorMPI.dot (reference mpi_vector.py:205-210) sums the local products and
+// all-reduces one number, so the order of the additions -- and the last digits of
+// every r.Pr of a solve -- depend on how many ranks share the time axis (the
+// reference against itself on 8 ranks: 4.6e-11 in the history).  Here the sum over
+// the SPATIAL index of every time step has one fixed shape that depends on M alone:
+//   rows in blocks of SD_ROWS; inside a block, row i goes to class i mod SD_CLASSES,
+//   a class adds its products in increasing i with fused multiply-adds from zero;
+//   the SD_CLASSES class sums of a block are added pairwise (0+1, 2+3, ...; then
+//   pairs of pairs; ...); the block sums of a time step are added by 256 partial
+//   sums (block b to partial b mod 256, increasing b) that meet in the fixed
+//   wavefront / workgroup tree of block_sum.
+// The n_loc results land at the global positions of the slab's time steps in an
+// N-vector whose other entries are written as zero; the caller all-reduces that
+// (adding zeros is exact in any order) and adds the N entries in increasing t
+// (stk_sum_steps): the value is the same on 1, 2, 4 or 8 ranks, bit for bit.
+constexpr int SD_ROWS = 256;
+constexpr int SD_CLASSES = 8;
+constexpr int SD_ITEMS = 4;  // (class, pair of steps) items per thread at most
+
+// One virtual group of G = SD_CLASSES * ld2 items works on one block of rows: item f
+// = class * ld2 + pair reads 16 bytes at (row, pair) -- the items of a group read
+// SD_CLASSES consecutive rows, i.e. one contiguous run of SD_CLASSES * ld * 8 bytes
+// per step.  A workgroup holds as many groups as fit (short slabs) or walks the
+// items of one group in SD_ITEMS rounds (long slabs); p_lo / p_hi cut slabs of more
+// pairs than that into column ranges.
+template <int BSZ>
+__global__ __launch_bounds__(BSZ) void slab_dot_blocks_kernel(int32_t M, int32_t ld2, int32_t p_lo, int32_t p_hi,
+                                                               int32_t groups, int32_t n_blocks,
+                                                               const double2 *__restrict__ x,
+                                                               const double2 *__restrict__ y,
+                                                               double2 *__restrict__ part)
+{
+    __shared__ double2 sm[BSZ * SD_ITEMS];
+    const int np = p_hi - p_lo;             // pairs handled by this launch
+    const int G = SD_CLASSES * np;          // items of a virtual group
+    const int tid = threadIdx.x;
+    const int grp = groups > 1 ? tid / G : 0;
+    const int f0 = groups > 1 ? tid - grp * G : tid;
+    const int blk = (int)blockIdx.x * groups + grp;
+    const bool live = grp < groups && blk < n_blocks;
+    const int row0 = blk * SD_ROWS;
+    const int row_end = min(row0 + SD_ROWS, M);
+    double2 acc[SD_ITEMS];
+#pragma unroll
+    for (int q = 0; q < SD_ITEMS; ++q) {
+        acc[q] = make_double2(0.0, 0.0);
+        const int f = f0 + q * BSZ;
+        if (!live || f >= G) continue;
+        const int cls = f / np, pr = p_lo + (f - cls * np);
+        double2 a = make_double2(0.0, 0.0);
+        size_t o = (size_t)(row0 + cls) * ld2 + pr;
+        const size_t step = (size_t)SD_CLASSES * ld2;
+#pragma unroll 4
+        for (int i = row0 + cls; i < row_end; i += SD_CLASSES, o += step) {
+            const double2 xv = x[o], yv = y[o];
+            a.x = fma(xv.x, yv.x, a.x);
+            a.y = fma(xv.y, yv.y, a.y);
+        }
+        acc[q] = a;
+    }
+    // class sums -> LDS [group][item], then the pairwise tree over the classes
+#pragma unroll
+    for (int q = 0; q < SD_ITEMS; ++q) {
+        const int f = f0 + q * BSZ;
+        if (live && f < G) sm[grp * G + f] = acc[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < SD_ITEMS; ++q) {
+        const int f = f0 + q * BSZ;
+        if (!live || f >= np) continue;  // items of class 0 finish their pair of steps
+        const double2 *c = sm + grp * G + f;
+        double2 v[SD_CLASSES];
+#pragma unroll
+        for (int g = 0; g < SD_CLASSES; ++g) v[g] = c[g * np];
+#pragma unroll
+        for (int w = 1; w < SD_CLASSES; w <<= 1)
+#pragma unroll
+            for (int g = 0; g < SD_CLASSES; g += 2 * w) {
+                v[g].x += v[g + w].x;
+                v[g].y += v[g + w].y;
+            }
+        part[(size_t)(p_lo + f) * n_blocks + blk] = v[0];  // [pair][block]
+    }
+}
+
+// One workgroup per pair of time steps: the block sums in a fixed order, written to
+// out[t_begin + t]; workgroup 0 zeroes the entries of the other ranks' steps.
+__global__ __launch_bounds__(256) void slab_dot_steps_kernel(int32_t n_loc, int32_t n_blocks,
+                                                             const double2 *__restrict__ part, int32_t N,
+                                                             int32_t t_begin, double *out_all)
+{
+    __shared__ double sm[2][256 / 64];
+    if (blockIdx.x == 0)
+        for (int t = threadIdx.x; t < N; t += 256)
+            if (t < t_begin || t >= t_begin + n_loc) out_all[t] = 0.0;
+    double *out = out_all + t_begin;
+    const double2 *c = part + (size_t)blockIdx.x * n_blocks;
+    double2 a = make_double2(0.0, 0.0);
+    for (int b = threadIdx.x; b < n_blocks; b += 256) {
+        a.x += c[b].x;
+        a.y += c[b].y;
+    }
+    const double r0 = block_sum(a.x, sm[0]), r1 = block_sum(a.y, sm[1]);
+    if (threadIdx.x == 0) {
+        const int t = 2 * (int)blockIdx.x;
+        out[t] = r0;
+        if (t + 1 < n_loc) out[t + 1] = r1;
+    }
+}
+
 // Time slices of a slab: y[i][k] = x[i][cols[k]] (gather; columns k >= n_cols of y,
 // its padding, are written as zero) or y[i][cols[k]] = x[i][k] (scatter).
 __global__ __launch_bounds__(BS) void slab_columns_kernel(int64_t total, int32_t n_cols, int32_t width,
@@ -167,6 +279,53 @@ extern "C" int stk_dot(void *stream, int64_t n, const double *x, const double *y
     hipLaunchKernelGGL(dot_partial_kernel, dim3(grid), dim3(BS), 0, stk_stream(stream), n, x, y, work);
     STK_LAUNCH_CHECK();
     hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(1024), 0, stk_stream(stream), (int)grid, work, out);
+    STK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int64_t stk_slab_dot_work_size(int32_t M, int32_t n_loc)
+{
+    if (M <= 0 || n_loc <= 0) return 0;
+    const int64_t n_blocks = ((int64_t)M + SD_ROWS - 1) / SD_ROWS;
+    return 2 * (int64_t)((n_loc + 1) / 2) * n_blocks;
+}
+
+extern "C" double stk_sum_steps(const double *steps_host, int32_t N)
+{
+    double s = 0.0;
+    for (int t = 0; t < N; ++t) s += steps_host[t];
+    return s;
+}
+
+extern "C" int stk_slab_dot(void *stream, int32_t M, int32_t n_loc, int32_t ld, const double *x, const double *y,
+                            double *work, int32_t N, int32_t t_begin, double *out_steps)
+{
+    const stk_timed timed_(STK_OP_BLAS1, stream);
+    STK_REQUIRE(M > 0 && n_loc > 0 && ld >= n_loc && (ld & 1) == 0,
+                "stk_slab_dot: bad sizes M=%d n_loc=%d ld=%d (ld must be even)", M, n_loc, ld);
+    STK_REQUIRE(x && y && work && out_steps, "stk_slab_dot: null pointer");
+    STK_REQUIRE(t_begin >= 0 && t_begin + n_loc <= N, "stk_slab_dot: steps [%d, %d) of %d", t_begin, t_begin + n_loc, N);
+    STK_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)work) & 15) == 0,
+                "stk_slab_dot: x, y and work must be 16-byte aligned");
+    hipStream_t st = stk_stream(stream);
+    const int ld2 = ld / 2, np_all = (n_loc + 1) / 2;
+    const int n_blocks = (M + SD_ROWS - 1) / SD_ROWS;
+    const double2 *x2 = reinterpret_cast<const double2 *>(x), *y2 = reinterpret_cast<const double2 *>(y);
+    double2 *part = reinterpret_cast<double2 *>(work);
+    // pairs per launch: what SD_ITEMS rounds of a 256-thread workgroup hold
+    constexpr int BSZ = 256;
+    const int np_max = BSZ * SD_ITEMS / SD_CLASSES;
+    for (int p_lo = 0; p_lo < np_all; p_lo += np_max) {
+        const int p_hi = p_lo + np_max < np_all ? p_lo + np_max : np_all;
+        const int G = SD_CLASSES * (p_hi - p_lo);
+        const int groups = G <= BSZ ? BSZ / G : 1;
+        const unsigned grid = (unsigned)((n_blocks + groups - 1) / groups);
+        hipLaunchKernelGGL((slab_dot_blocks_kernel<BSZ>), dim3(grid), dim3(BSZ), 0, st, M, ld2, p_lo, p_hi, groups,
+                           n_blocks, x2, y2, part);
+        STK_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(slab_dot_steps_kernel, dim3(np_all), dim3(256), 0, st, n_loc, n_blocks, part, N, t_begin,
+                       out_steps);
     STK_LAUNCH_CHECK();
     return 0;
 }

@@ -350,107 +350,147 @@ int launch2(hipStream_t st, const EllArgs<NT> &a_in, int K)
     return 2;
 }
 
-// ---- ghost-row correction ---------------------------------------------------
-// y[row, 0]       += sum_k sub_k[0]       * sum_j X_k[row, j] x_lo_k[j]
-// y[row, n_loc-1] += sum_k sup_k[n_loc-1] * sum_j X_k[row, j] x_hi_k[j]
-// (the rows t_begin-1 and t_end of the time factors; reference mpi_kron.py:165-183,
-// 186-201 keep them as the first and last row of the ghosted block).  One lane
-// per matrix row; terms that share a ghost row gather it once.
+// ---- first and last local time step of a slab with neighbours ------------------
+// The main kernel computed them without the received rows x_lo (time step -1) and
+// x_hi (time step n_loc).  They are RECOMPUTED here once the halo is there, in the
+// main kernel's order of operations,
+//   y[row, t] = sum_k fma(sup_k[t], z_k[t+1], fma(sub_k[t], z_k[t-1], dia_k[t] * z_k[t])),
+//   z_k[s] = the slot-ordered fma chain of row `row` of X_k over time column s of x_k,
+// and overwrite what the main kernel left (reference mpi_kron.py:165-183, 186-201
+// keep the received rows as the first and last row of the ghosted block; the rows
+// that need them are finished "after the halo arrived", :199-200).  A slab boundary
+// therefore leaves no trace: the apply is bit for bit the one-rank apply wherever
+// the time axis is cut.  (Rounds 1-5 ADDED the received rows' share to the main
+// kernel's value, which puts the neighbour's term last in the sum -- an order no
+// interior time step has.)  One lane per matrix row and side.
 template <int NT>
 struct GhostArgs {
     const int32_t *ell_idx, *row_ids, *ovf_indptr, *ovf_indices;
     const double *ell_vals[NT];
     const double *ovf_vals[NT];
     const double *tri[NT];
+    const double *x[NT];
     const double *lo[NT];
     const double *hi[NT];
     double *y;
-    int32_t M, n_loc, ld;
+    const double *old;  // beta != 0: [2][M] the boundary entries of y from before the main kernel
+    double beta;
+    int32_t M, n_loc, ld, side0;
 };
 
 constexpr int GBSZ = 256;
+
+// old[0][row] = y[row][0], old[1][row] = y[row][n_loc - 1]
+__global__ __launch_bounds__(GBSZ) void kron_ell_save_boundary_kernel(int32_t M, int32_t n_loc, int32_t ld,
+                                                                      const double *__restrict__ y,
+                                                                      double *__restrict__ old)
+{
+    const int row = blockIdx.x * GBSZ + threadIdx.x;
+    if (row >= M) return;
+    old[row] = y[(size_t)row * ld];
+    old[(size_t)M + row] = y[(size_t)row * ld + n_loc - 1];
+}
 
 template <int NT, int K>
 __global__ __launch_bounds__(GBSZ) void kron_ell_ghost_kernel(const GhostArgs<NT> a)
 {
     const int pos = blockIdx.x * GBSZ + threadIdx.x;
     if (pos >= a.M) return;
+    const int side = a.side0 + (int)blockIdx.y;
+    const int t = side ? a.n_loc - 1 : 0;
     const size_t e0 = (size_t)pos * K;
     int32_t col[K];
 #pragma unroll
     for (int u = 0; u < K; ++u) col[u] = a.ell_idx[e0 + u];
     const int o0 = a.ovf_indptr ? a.ovf_indptr[pos] : 0, o1 = a.ovf_indptr ? a.ovf_indptr[pos + 1] : 0;
-    double add[2] = {0.0, 0.0};
+    // z = row `pos` of X_k times one time column: `src` + column * `stride`
+    auto row_dot = [&](int k, const double *src, size_t stride) {
+        double xv[K];
 #pragma unroll
-    for (int side = 0; side < 2; ++side) {
-        const double *loaded = nullptr;
-        double gv[K];
+        for (int u = 0; u < K; ++u) xv[u] = src[(size_t)col[u] * stride];
+        double s = 0.0;
 #pragma unroll
-        for (int k = 0; k < NT; ++k) {
-            const double *gp = side ? a.hi[k] : a.lo[k];
-            if (gp == nullptr || a.tri[k] == nullptr) continue;
-            // sub[0] couples to t_begin - 1, sup[n_loc - 1] to t_end
-            const double c = side ? a.tri[k][2 * a.n_loc + a.n_loc - 1] : a.tri[k][0];
-            if (c == 0.0) continue;
-            if (gp != loaded) {
+        for (int u = 0; u < K; ++u) s = fma(a.ell_vals[k][e0 + u], xv[u], s);
+        for (int e = o0; e < o1; ++e) s = fma(a.ovf_vals[k][e], src[(size_t)a.ovf_indices[e] * stride], s);
+        return s;
+    };
+    double yv = 0.0;
 #pragma unroll
-                for (int u = 0; u < K; ++u) gv[u] = gp[col[u]];
-                loaded = gp;
-            }
-            double s = 0.0;
-#pragma unroll
-            for (int u = 0; u < K; ++u) s = fma(a.ell_vals[k][e0 + u], gv[u], s);
-            for (int e = o0; e < o1; ++e) s = fma(a.ovf_vals[k][e], gp[a.ovf_indices[e]], s);
-            add[side] = fma(c, s, add[side]);
+    for (int k = 0; k < NT; ++k) {
+        const double zc = row_dot(k, a.x[k] + t, (size_t)a.ld);
+        if (a.tri[k] == nullptr) {
+            yv += zc;
+            continue;
         }
+        double v = a.tri[k][a.n_loc + t] * zc;
+        if (t > 0)
+            v = fma(a.tri[k][t], row_dot(k, a.x[k] + t - 1, (size_t)a.ld), v);
+        else if (a.lo[k] != nullptr)
+            v = fma(a.tri[k][t], row_dot(k, a.lo[k], 1), v);
+        if (t + 1 < a.n_loc)
+            v = fma(a.tri[k][2 * a.n_loc + t], row_dot(k, a.x[k] + t + 1, (size_t)a.ld), v);
+        else if (a.hi[k] != nullptr)
+            v = fma(a.tri[k][2 * a.n_loc + t], row_dot(k, a.hi[k], 1), v);
+        yv += v;
     }
     const int row = a.row_ids ? a.row_ids[pos] : pos;
-    double *yr = a.y + (size_t)row * a.ld;
-    if (a.n_loc == 1) {
-        yr[0] += add[0] + add[1];
-    } else {
-        if (add[0] != 0.0) yr[0] += add[0];
-        if (add[1] != 0.0) yr[a.n_loc - 1] += add[1];
-    }
+    if (a.old != nullptr) yv = fma(a.beta, a.old[(size_t)side * a.M + row], yv);
+    a.y[(size_t)row * a.ld + t] = yv;
 }
 
 template <int NT, int K>
-int ghost_launch(hipStream_t st, const GhostArgs<NT> &a)
+int ghost_launch(hipStream_t st, const GhostArgs<NT> &a, unsigned sides)
 {
-    hipLaunchKernelGGL((kron_ell_ghost_kernel<NT, K>), dim3((a.M + GBSZ - 1) / GBSZ), dim3(GBSZ), 0, st, a);
+    hipLaunchKernelGGL((kron_ell_ghost_kernel<NT, K>), dim3((a.M + GBSZ - 1) / GBSZ, sides), dim3(GBSZ), 0, st, a);
     STK_LAUNCH_CHECK();
     return 0;
 }
 
+// Does any term couple to a received row?  (lo, hi)
+inline void ghost_sides(int n_terms, const stk_kron_ell_term *t, bool *lo, bool *hi)
+{
+    *lo = *hi = false;
+    for (int k = 0; k < n_terms; ++k) {
+        if (t[k].tri && t[k].x_lo) *lo = true;
+        if (t[k].tri && t[k].x_hi) *hi = true;
+    }
+}
+
 template <int NT>
 int ghost_dispatch(hipStream_t st, const stk_ell_pattern *pat, int32_t n_loc, int32_t ld,
-                   const stk_kron_ell_term *t, double *y)
+                   const stk_kron_ell_term *t, double *y, double beta = 0.0, const double *old = nullptr)
 {
     GhostArgs<NT> a;
-    bool any = false;
+    bool lo, hi;
+    ghost_sides(NT, t, &lo, &hi);
+    if (!lo && !hi) return 0;
     for (int k = 0; k < NT; ++k) {
         a.ell_vals[k] = t[k].ell_vals;
         a.ovf_vals[k] = t[k].ovf_vals;
         a.tri[k] = t[k].tri;
+        a.x[k] = t[k].x;
         a.lo[k] = t[k].x_lo;
         a.hi[k] = t[k].x_hi;
-        if (t[k].tri && (t[k].x_lo || t[k].x_hi)) any = true;
     }
-    if (!any) return 0;
     a.ell_idx = pat->ell_idx;
     a.row_ids = pat->row_ids;
     a.ovf_indptr = pat->ovf_indptr;
     a.ovf_indices = pat->ovf_indices;
     a.y = y;
+    a.old = old;
+    a.beta = beta;
     a.M = pat->M;
     a.n_loc = n_loc;
     a.ld = ld;
+    // one step: both received rows meet in it; otherwise a side per received row
+    a.side0 = (n_loc == 1 || lo) ? 0 : 1;
+    const unsigned sides = (n_loc > 1 && lo && hi) ? 2u : 1u;
     switch (pat->K) {
-        case 5: return ghost_launch<NT, 5>(st, a);
-        case 7: return ghost_launch<NT, 7>(st, a);
-        case 9: return ghost_launch<NT, 9>(st, a);
-        case 12: return ghost_launch<NT, 12>(st, a);
-        case 16: return ghost_launch<NT, 16>(st, a);
+        case 5: return ghost_launch<NT, 5>(st, a, sides);
+        case 7: return ghost_launch<NT, 7>(st, a, sides);
+        case 9: return ghost_launch<NT, 9>(st, a, sides);
+        case 12: return ghost_launch<NT, 12>(st, a, sides);
+        case 16: return ghost_launch<NT, 16>(st, a, sides);
     }
     stk_set_error("stk_kron_ell_apply: K=%d is not one of 5, 7, 9, 12, 16", pat->K);
     return 2;
@@ -481,9 +521,20 @@ int dispatch(hipStream_t st, const stk_ell_pattern *pat, int32_t n_loc, int32_t 
         if (t[k].x != t[0].x) shared = false;
     }
     a.P = (n_loc + 1) / 2;
+    bool lo, hi;
+    ghost_sides(NT, t, &lo, &hi);
+    // beta != 0 on a slab with neighbours: the boundary steps are rewritten after the
+    // main kernel, which has by then replaced the old values they scale -- keep a copy
+    double *old = nullptr;
+    if ((lo || hi) && beta != 0.0) {
+        STK_HIP(hipMallocAsync(reinterpret_cast<void **>(&old), sizeof(double) * 2 * (size_t)pat->M, st));
+        hipLaunchKernelGGL(kron_ell_save_boundary_kernel, dim3((pat->M + GBSZ - 1) / GBSZ), dim3(GBSZ), 0, st, pat->M,
+                           n_loc, ld, y, old);
+    }
     int rc = shared ? launch2<NT, true>(st, a, pat->K) : launch2<NT, false>(st, a, pat->K);
-    if (rc) return rc;
-    return ghost_dispatch<NT>(st, pat, n_loc, ld, t, y);
+    if (rc == 0) rc = ghost_dispatch<NT>(st, pat, n_loc, ld, t, y, beta, old);
+    if (old) STK_HIP(hipFreeAsync(old, st));
+    return rc;
 }
 
 }  // namespace
@@ -514,7 +565,7 @@ extern "C" int stk_kron_ell_ghost_apply(void *stream, const stk_ell_pattern *pat
     STK_REQUIRE(n_loc > 0 && ld >= n_loc, "stk_kron_ell_ghost_apply: bad sizes n_loc=%d ld=%d", n_loc, ld);
     STK_REQUIRE(n_terms >= 1 && n_terms <= 3, "stk_kron_ell_ghost_apply: n_terms=%d not in 1..3", n_terms);
     for (int k = 0; k < n_terms; ++k) {
-        STK_REQUIRE(t[k].ell_vals, "stk_kron_ell_ghost_apply: term %d has null vals", k);
+        STK_REQUIRE(t[k].ell_vals && t[k].x && t[k].x != y, "stk_kron_ell_ghost_apply: term %d has null vals / x", k);
         STK_REQUIRE(pat->ovf_indptr == nullptr || t[k].ovf_vals, "stk_kron_ell_ghost_apply: term %d lacks ovf_vals",
                     k);
     }

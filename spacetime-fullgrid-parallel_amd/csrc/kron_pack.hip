@@ -471,18 +471,23 @@ __global__ __launch_bounds__(BS, (K >= 12 || RP > 1) ? 4 : 6) void kron_pack_ker
     }
 }
 
-// What the two ghost time steps add to y when the main pass ran WITHOUT them
-// (GHOST = false) while the halo exchange was still in flight -- the reference
-// overlaps the exchange with the rows that do not need it the same way,
-// mpi_kron.py:193-200:
-//     y[i][0]         += sum_k sub_k[0]         * (X_k x_lo)[i]
-//     y[i][n_loc - 1] += sum_k super_k[n_loc-1] * (X_k x_hi)[i]
-// One lane per slot row on the same packed stream (4 bytes per slot; x_lo and
-// x_hi are the two received rows as they arrive, contiguous -- no interleave
-// step), read-modify-write of the two boundary entries of every row of y.
+// The first and last local time step once the halo is there, after the main pass
+// ran WITHOUT the ghost steps (GHOST = false, beta = 0) while the exchange was still
+// in flight -- the reference overlaps the exchange with the rows that do not need
+// it the same way, mpi_kron.py:193-200.  The two boundary steps are RECOMPUTED in
+// the arithmetic order of the one-pass kernel above,
+//     y[i][t] = sum_k fma(super_k[t], z_k[i][t+1], fma(sub_k[t], z_k[i][t-1], dia_k[t] * z_k[i][t])),
+//     z_k[i][s] = the slot-ordered fma chain of X_k's row i over time column s
+// (s = -1: x_lo, s = n_loc: x_hi), and overwrite what the pass left there, so that
+// a slab boundary leaves no trace in the result: the apply is bit for bit the
+// one-rank apply wherever the slabs are cut.  (Adding the ghost steps' share to the
+// pass's value afterwards -- rounds 1-5 -- put the neighbour's term last in the
+// sum, an order no interior row has.)  One lane per slot row and side on the
+// packed stream: three 8-byte gathers per slot (the step's own column, its inner
+// neighbour column, the received row).
 template <int NT, int K, int RP>
 __global__ __launch_bounds__(256) void kron_pack_ghost_kernel(const PackArgs<NT> a, const double *__restrict__ lo,
-                                                              const double *__restrict__ hi)
+                                                              const double *__restrict__ hi, int side0)
 {
     extern __shared__ double sm[];
     double *s_dict = sm;  // [n_codes][RP][NT]
@@ -493,11 +498,22 @@ __global__ __launch_bounds__(256) void kron_pack_ghost_kernel(const PackArgs<NT>
         }
     }
     __syncthreads();
-    double c_lo[NT], c_hi[NT];
+    const int side = side0 + (int)blockIdx.y;         // 0: first local step, 1: last
+    const int t = side ? a.n_loc - 1 : 0;
+    // where z[t-1], z[t], z[t+1] gather from: a received row (stride 8) or a time column of the slab
+    const size_t col_stride = (size_t)a.ld * 8;
+    const char *xb = reinterpret_cast<const char *>(a.x);
+    const char *src_m = t > 0 ? xb + (size_t)(t - 1) * 8 : reinterpret_cast<const char *>(lo);
+    const size_t str_m = t > 0 ? col_stride : 8;
+    const char *src_c = xb + (size_t)t * 8;
+    const char *src_p = t + 1 < a.n_loc ? xb + (size_t)(t + 1) * 8 : reinterpret_cast<const char *>(hi);
+    const size_t str_p = t + 1 < a.n_loc ? col_stride : 8;
+    double sub[NT], dia[NT], sup[NT];
 #pragma unroll
     for (int k = 0; k < NT; ++k) {
-        c_lo[k] = (lo && a.tri[k]) ? a.tri[k][0] : 0.0;                                // sub-diagonal of local row 0
-        c_hi[k] = (hi && a.tri[k]) ? a.tri[k][2 * a.n_loc + a.n_loc - 1] : 0.0;        // super-diagonal of the last row
+        sub[k] = a.tri[k] ? a.tri[k][t] : 0.0;
+        dia[k] = a.tri[k] ? a.tri[k][a.n_loc + t] : 1.0;
+        sup[k] = a.tri[k] ? a.tri[k][2 * a.n_loc + t] : 0.0;
     }
     const uint32_t col_mask = (1u << a.col_bits) - 1u;
     const int stride = gridDim.x * 256;
@@ -505,15 +521,21 @@ __global__ __launch_bounds__(256) void kron_pack_ghost_kernel(const PackArgs<NT>
         uint32_t sl[K];
 #pragma unroll
         for (int q = 0; q < K; ++q) sl[q] = a.slots[(size_t)u * K + q];
-        double zl[RP][NT], zh[RP][NT];
+        double xm[K], xc[K], xp[K];
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            const size_t col = sl[q] & col_mask;
+            xm[q] = src_m ? *reinterpret_cast<const double *>(src_m + col * str_m) : 0.0;
+            xc[q] = *reinterpret_cast<const double *>(src_c + col * col_stride);
+            xp[q] = src_p ? *reinterpret_cast<const double *>(src_p + col * str_p) : 0.0;
+        }
+        double zm[RP][NT], zc[RP][NT], zp[RP][NT];
 #pragma unroll
         for (int j = 0; j < RP; ++j)
 #pragma unroll
-            for (int k = 0; k < NT; ++k) zl[j][k] = zh[j][k] = 0.0;
+            for (int k = 0; k < NT; ++k) zm[j][k] = zc[j][k] = zp[j][k] = 0.0;
 #pragma unroll
         for (int q = 0; q < K; ++q) {
-            const uint32_t col = sl[q] & col_mask;
-            const double xl = lo ? lo[col] : 0.0, xh = hi ? hi[col] : 0.0;
             const double *dv = a.vals ? a.vals + ((size_t)u * K + q) * RP * NT
                                       : s_dict + (sl[q] >> a.col_bits) * (RP * NT);
 #pragma unroll
@@ -521,27 +543,28 @@ __global__ __launch_bounds__(256) void kron_pack_ghost_kernel(const PackArgs<NT>
 #pragma unroll
                 for (int k = 0; k < NT; ++k) {
                     const double v = dv[j * NT + k];
-                    zl[j][k] = fma(v, xl, zl[j][k]);
-                    zh[j][k] = fma(v, xh, zh[j][k]);
+                    zm[j][k] = fma(v, xm[q], zm[j][k]);
+                    zc[j][k] = fma(v, xc[q], zc[j][k]);
+                    zp[j][k] = fma(v, xp[q], zp[j][k]);
                 }
         }
 #pragma unroll
         for (int j = 0; j < RP; ++j) {
             const int row = a.row_ids ? a.row_ids[(size_t)u * RP + j] : u;
             if (row < 0) continue;
-            double add_lo = 0.0, add_hi = 0.0;
+            double yv = 0.0;
 #pragma unroll
             for (int k = 0; k < NT; ++k) {
-                add_lo = fma(c_lo[k], zl[j][k], add_lo);
-                add_hi = fma(c_hi[k], zh[j][k], add_hi);
+                if (a.tri[k] != nullptr) {
+                    double v = dia[k] * zc[j][k];
+                    v = fma(sub[k], zm[j][k], v);
+                    v = fma(sup[k], zp[j][k], v);
+                    yv += v;
+                } else {
+                    yv += zc[j][k];
+                }
             }
-            double *yr = a.y + (size_t)row * a.ld;
-            if (a.n_loc == 1) {
-                yr[0] += add_lo + add_hi;
-            } else {
-                if (lo) yr[0] += add_lo;
-                if (hi) yr[a.n_loc - 1] += add_hi;
-            }
+            a.y[(size_t)row * a.ld + t] = yv;
         }
     }
 }
@@ -551,9 +574,13 @@ int launch_ghost_only(hipStream_t st, const PackArgs<NT> &a, int K, const double
 {
     const size_t lds = sizeof(double) * (a.vals ? 0 : (size_t)a.n_codes * RP * NT) + 16;
     const unsigned grid = stk_flat_grid(a.n_units, 256);
-#define STK_GHOST_CASE(KK)                                                                                   \
-    case KK:                                                                                                 \
-        hipLaunchKernelGGL((kron_pack_ghost_kernel<NT, KK, RP>), dim3(grid), dim3(256), lds, st, a, lo, hi); \
+    // one step: both received rows meet in it; otherwise a side per received row
+    const int side0 = (a.n_loc == 1 || lo) ? 0 : 1;
+    const unsigned sides = (a.n_loc > 1 && lo && hi) ? 2u : 1u;
+#define STK_GHOST_CASE(KK)                                                                                  \
+    case KK:                                                                                                \
+        hipLaunchKernelGGL((kron_pack_ghost_kernel<NT, KK, RP>), dim3(grid, sides), dim3(256), lds, st, a, lo, hi, \
+                           side0);                                                                          \
         break;
     if constexpr (RP == 1) {
         switch (K) {
@@ -579,12 +606,13 @@ int launch_ghost_only(hipStream_t st, const PackArgs<NT> &a, int K, const double
 
 template <int NT>
 int dispatch_ghost_only(hipStream_t st, const stk_pack_pattern *pat, int32_t n_loc, int32_t ld,
-                        const stk_kron_pack_term *t, const double *lo, const double *hi, double *y)
+                        const stk_kron_pack_term *t, const double *x, const double *lo, const double *hi, double *y)
 {
     PackArgs<NT> a;
     std::memset(&a, 0, sizeof(a));
     a.slots = pat->slots;
     a.row_ids = pat->row_ids;
+    a.x = x;
     a.y = y;
     a.M = pat->M;
     a.n_units = pat->n_units;
@@ -919,11 +947,11 @@ extern "C" int stk_kron_pack_set_diag(unsigned long long *buf)
 }
 
 extern "C" int stk_kron_pack_ghost_apply(void *stream, const stk_pack_pattern *pat, int32_t n_loc, int32_t ld,
-                                         int32_t n_terms, const stk_kron_pack_term *t, const double *x_lo,
-                                         const double *x_hi, double *y)
+                                         int32_t n_terms, const stk_kron_pack_term *t, const double *x,
+                                         const double *x_lo, const double *x_hi, double *y)
 {
     const stk_timed timed_(STK_OP_KRON, stream);
-    STK_REQUIRE(pat && t && y, "stk_kron_pack_ghost_apply: null pointer");
+    STK_REQUIRE(pat && t && x && y && x != y, "stk_kron_pack_ghost_apply: null pointer or input aliases output");
     if (!x_lo && !x_hi) return 0;
     STK_REQUIRE(pat->M > 0 && pat->K >= 1 && pat->slots && (pat->dict || pat->vals) && pat->n_units > 0,
                 "stk_kron_pack_ghost_apply: bad pattern");
@@ -945,8 +973,8 @@ extern "C" int stk_kron_pack_ghost_apply(void *stream, const stk_pack_pattern *p
                     k, t[k].mat, pat->n_mats);
     hipStream_t st = stk_stream(stream);
     switch (n_terms) {
-        case 1: return dispatch_ghost_only<1>(st, pat, n_loc, ld, t, x_lo, x_hi, y);
-        case 2: return dispatch_ghost_only<2>(st, pat, n_loc, ld, t, x_lo, x_hi, y);
-        default: return dispatch_ghost_only<3>(st, pat, n_loc, ld, t, x_lo, x_hi, y);
+        case 1: return dispatch_ghost_only<1>(st, pat, n_loc, ld, t, x, x_lo, x_hi, y);
+        case 2: return dispatch_ghost_only<2>(st, pat, n_loc, ld, t, x, x_lo, x_hi, y);
+        default: return dispatch_ghost_only<3>(st, pat, n_loc, ld, t, x, x_lo, x_hi, y);
     }
 }

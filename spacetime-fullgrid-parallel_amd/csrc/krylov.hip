@@ -31,22 +31,30 @@ extern "C" int stk_partition(int32_t N, int32_t size, int32_t rank, int32_t *t_b
     return 0;
 }
 
-extern "C" int64_t stk_pcg_work_size(int64_t n) { return 4 * n + stk_dot_work_size() + 2; }
+namespace {
 
-extern "C" int stk_pcg_solve(void *stream, int64_t n, stk_operator_fn T, void *T_ctx, stk_operator_fn P, void *P_ctx,
-                             stk_allreduce_fn allreduce, void *allreduce_ctx, const double *b, double *w,
-                             double eps, int32_t kmax, double *work, double *history, int32_t *iters)
+// How the vectors of a Krylov loop are summed: as flat arrays (M = 0; the value then
+// depends on how the time axis is split over the ranks, in the last digits) or as
+// slabs with one partial per time step (stk_slab_dot: the same value on any number of
+// ranks, bit for bit).
+struct dot_shape {
+    int32_t M, n_loc, ld, N, t_begin;
+};
+
+int64_t dot_scratch(const dot_shape &s)
 {
-    STK_REQUIRE(n > 0 && (n & 1) == 0, "stk_pcg_solve: n=%lld must be positive and even", (long long)n);
-    STK_REQUIRE(T && P && b && w && work && iters, "stk_pcg_solve: null argument");
-    hipStream_t st = stk_stream(stream);
-    double *r = work, *p = work + n, *q = work + 2 * n, *z = work + 3 * n;
-    double *dot_work = work + 4 * n, *dot_out = dot_work + stk_dot_work_size();
-    *iters = 0;
+    if (s.M == 0) return stk_dot_work_size() + 2;
+    return stk_slab_dot_work_size(s.M, s.n_loc) + s.N + (s.N & 1);
+}
 
-    // global dot product: deterministic device reduction, one scalar to the
-    // host, sum over the ranks (mpi_vector.py:205-210)
-    auto dot = [&](const double *x, const double *y, double *value) -> int {
+// Global inner product (mpi_vector.py:205-210): deterministic device reduction, the
+// scalar (flat) or the N per-step sums (slab) to the host, sum over the ranks.
+int global_dot(void *stream, int64_t n, const dot_shape &s, const double *x, const double *y, double *dot_work,
+               stk_allreduce_fn allreduce, void *allreduce_ctx, const char *who, double *value)
+{
+    hipStream_t st = stk_stream(stream);
+    if (s.M == 0) {
+        double *dot_out = dot_work + stk_dot_work_size();
         int rc = stk_dot(stream, n, x, y, dot_work, dot_out);
         if (rc) return rc;
         STK_HIP(hipMemcpyAsync(value, dot_out, sizeof(double), hipMemcpyDeviceToHost, st));
@@ -54,11 +62,49 @@ extern "C" int stk_pcg_solve(void *stream, int64_t n, stk_operator_fn T, void *T
         if (allreduce) {
             rc = allreduce(allreduce_ctx, value, 1);
             if (rc) {
-                stk_set_error("stk_pcg_solve: allreduce callback failed (%d)", rc);
+                stk_set_error("%s: allreduce callback failed (%d)", who, rc);
                 return rc;
             }
         }
         return 0;
+    }
+    double *steps = dot_work + stk_slab_dot_work_size(s.M, s.n_loc);
+    int rc = stk_slab_dot(stream, s.M, s.n_loc, s.ld, x, y, dot_work, s.N, s.t_begin, steps);
+    if (rc) return rc;
+    std::vector<double> host(s.N);
+    STK_HIP(hipMemcpyAsync(host.data(), steps, sizeof(double) * s.N, hipMemcpyDeviceToHost, st));
+    STK_HIP(hipStreamSynchronize(st));
+    if (allreduce) {
+        rc = allreduce(allreduce_ctx, host.data(), s.N);
+        if (rc) {
+            stk_set_error("%s: allreduce callback failed (%d)", who, rc);
+            return rc;
+        }
+    }
+    *value = stk_sum_steps(host.data(), s.N);
+    return 0;
+}
+
+int check_slab_shape(const char *who, int32_t M, int32_t n_loc, int32_t ld, int32_t N, int32_t t_begin)
+{
+    STK_REQUIRE(M > 0 && n_loc > 0 && ld >= n_loc && (ld & 1) == 0, "%s: bad slab M=%d n_loc=%d ld=%d (ld must be even)",
+                who, M, n_loc, ld);
+    STK_REQUIRE(t_begin >= 0 && t_begin + n_loc <= N, "%s: time steps [%d, %d) of %d", who, t_begin, t_begin + n_loc, N);
+    return 0;
+}
+
+int pcg_core(void *stream, int64_t n, const dot_shape &shape, stk_operator_fn T, void *T_ctx, stk_operator_fn P,
+             void *P_ctx, stk_allreduce_fn allreduce, void *allreduce_ctx, const double *b, double *w, double eps,
+             int32_t kmax, double *work, double *history, int32_t *iters)
+{
+    STK_REQUIRE(n > 0 && (n & 1) == 0, "stk_pcg_solve: n=%lld must be positive and even", (long long)n);
+    STK_REQUIRE(T && P && b && w && work && iters, "stk_pcg_solve: null argument");
+    double *r = work, *p = work + n, *q = work + 2 * n, *z = work + 3 * n;
+    double *dot_work = work + 4 * n;
+    *iters = 0;
+
+    auto dot = [&](const double *x, const double *y, double *value) -> int {
+        return global_dot(stream, n, shape, x, y, dot_work, allreduce, allreduce_ctx, "stk_pcg_solve", value);
     };
     auto apply = [&](stk_operator_fn op, void *ctx, const double *x, double *y, const char *name) -> int {
         const int rc = op(ctx, stream, x, y);
@@ -98,6 +144,33 @@ extern "C" int stk_pcg_solve(void *stream, int64_t n, stk_operator_fn T, void *T
     }
 #undef STK_TRY
     return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t stk_pcg_work_size(int64_t n) { return 4 * n + dot_scratch(dot_shape{0, 0, 0, 0, 0}); }
+
+extern "C" int stk_pcg_solve(void *stream, int64_t n, stk_operator_fn T, void *T_ctx, stk_operator_fn P, void *P_ctx,
+                             stk_allreduce_fn allreduce, void *allreduce_ctx, const double *b, double *w,
+                             double eps, int32_t kmax, double *work, double *history, int32_t *iters)
+{
+    return pcg_core(stream, n, dot_shape{0, 0, 0, 0, 0}, T, T_ctx, P, P_ctx, allreduce, allreduce_ctx, b, w, eps,
+                    kmax, work, history, iters);
+}
+
+extern "C" int64_t stk_pcg_slab_work_size(int32_t M, int32_t n_loc, int32_t ld, int32_t N)
+{
+    return 4 * (int64_t)M * ld + dot_scratch(dot_shape{M, n_loc, ld, N, 0});
+}
+
+extern "C" int stk_pcg_solve_slab(void *stream, int32_t M, int32_t n_loc, int32_t ld, int32_t N, int32_t t_begin,
+                                  stk_operator_fn T, void *T_ctx, stk_operator_fn P, void *P_ctx,
+                                  stk_allreduce_fn allreduce, void *allreduce_ctx, const double *b, double *w,
+                                  double eps, int32_t kmax, double *work, double *history, int32_t *iters)
+{
+    if (int rc = check_slab_shape("stk_pcg_solve_slab", M, n_loc, ld, N, t_begin)) return rc;
+    return pcg_core(stream, (int64_t)M * ld, dot_shape{M, n_loc, ld, N, t_begin}, T, T_ctx, P, P_ctx, allreduce,
+                    allreduce_ctx, b, w, eps, kmax, work, history, iters);
 }
 
 // ---- Lanczos estimate of lambda_max / lambda_min of P A (reference
@@ -148,34 +221,18 @@ void lz_bisec(const std::vector<double> &al, const std::vector<double> &be, int 
     if (std::signbit(pz) != std::signbit(py) && pz != 0.0) *zmin = ymin;
 }
 
-}  // namespace
-
-extern "C" int64_t stk_lanczos_work_size(int64_t n) { return 4 * n + stk_dot_work_size() + 2; }
-
-extern "C" int stk_lanczos(void *stream, int64_t n, stk_operator_fn A, void *A_ctx, stk_operator_fn P, void *P_ctx,
-                           stk_allreduce_fn allreduce, void *allreduce_ctx, double *w, int32_t max_iterations,
-                           double tol, double tol_bisec, double *work, double *alpha_host, double *beta_host,
-                           double *lmax, double *lmin, int32_t *iterations, int32_t *converged)
+int lanczos_core(void *stream, int64_t n, const dot_shape &shape, stk_operator_fn A, void *A_ctx, stk_operator_fn P,
+                 void *P_ctx, stk_allreduce_fn allreduce, void *allreduce_ctx, double *w, int32_t max_iterations,
+                 double tol, double tol_bisec, double *work, double *alpha_host, double *beta_host, double *lmax,
+                 double *lmin, int32_t *iterations, int32_t *converged)
 {
     STK_REQUIRE(n > 0 && (n & 1) == 0, "stk_lanczos: n=%lld must be positive and even", (long long)n);
     STK_REQUIRE(A && P && w && work && lmax && lmin && iterations, "stk_lanczos: null argument");
     STK_REQUIRE(max_iterations >= 2, "stk_lanczos: max_iterations=%d too small", max_iterations);
-    hipStream_t st = stk_stream(stream);
     double *v = work, *u = work + n, *t = work + 2 * n, *wprev = work + 3 * n;
-    double *dot_work = work + 4 * n, *dot_out = dot_work + stk_dot_work_size();
+    double *dot_work = work + 4 * n;
     auto dot = [&](const double *x, const double *y, double *value) -> int {
-        int rc = stk_dot(stream, n, x, y, dot_work, dot_out);
-        if (rc) return rc;
-        STK_HIP(hipMemcpyAsync(value, dot_out, sizeof(double), hipMemcpyDeviceToHost, st));
-        STK_HIP(hipStreamSynchronize(st));
-        if (allreduce) {
-            rc = allreduce(allreduce_ctx, value, 1);
-            if (rc) {
-                stk_set_error("stk_lanczos: allreduce callback failed (%d)", rc);
-                return rc;
-            }
-        }
-        return 0;
+        return global_dot(stream, n, shape, x, y, dot_work, allreduce, allreduce_ctx, "stk_lanczos", value);
     };
     auto apply = [&](stk_operator_fn op, void *ctx, const double *x, double *y, const char *name) -> int {
         const int rc = op(ctx, stream, x, y);
@@ -241,4 +298,35 @@ extern "C" int stk_lanczos(void *stream, int64_t n, stk_operator_fn A, void *A_c
     if (beta_host)
         for (int i = 0; i < k && i < max_iterations - 1; ++i) beta_host[i] = be[i];
     return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t stk_lanczos_work_size(int64_t n) { return 4 * n + dot_scratch(dot_shape{0, 0, 0, 0, 0}); }
+
+extern "C" int stk_lanczos(void *stream, int64_t n, stk_operator_fn A, void *A_ctx, stk_operator_fn P, void *P_ctx,
+                           stk_allreduce_fn allreduce, void *allreduce_ctx, double *w, int32_t max_iterations,
+                           double tol, double tol_bisec, double *work, double *alpha_host, double *beta_host,
+                           double *lmax, double *lmin, int32_t *iterations, int32_t *converged)
+{
+    return lanczos_core(stream, n, dot_shape{0, 0, 0, 0, 0}, A, A_ctx, P, P_ctx, allreduce, allreduce_ctx, w,
+                        max_iterations, tol, tol_bisec, work, alpha_host, beta_host, lmax, lmin, iterations,
+                        converged);
+}
+
+extern "C" int64_t stk_lanczos_slab_work_size(int32_t M, int32_t n_loc, int32_t ld, int32_t N)
+{
+    return 4 * (int64_t)M * ld + dot_scratch(dot_shape{M, n_loc, ld, N, 0});
+}
+
+extern "C" int stk_lanczos_slab(void *stream, int32_t M, int32_t n_loc, int32_t ld, int32_t N, int32_t t_begin,
+                                stk_operator_fn A, void *A_ctx, stk_operator_fn P, void *P_ctx,
+                                stk_allreduce_fn allreduce, void *allreduce_ctx, double *w, int32_t max_iterations,
+                                double tol, double tol_bisec, double *work, double *alpha_host, double *beta_host,
+                                double *lmax, double *lmin, int32_t *iterations, int32_t *converged)
+{
+    if (int rc = check_slab_shape("stk_lanczos_slab", M, n_loc, ld, N, t_begin)) return rc;
+    return lanczos_core(stream, (int64_t)M * ld, dot_shape{M, n_loc, ld, N, t_begin}, A, A_ctx, P, P_ctx, allreduce,
+                        allreduce_ctx, w, max_iterations, tol, tol_bisec, work, alpha_host, beta_host, lmax, lmin,
+                        iterations, converged);
 }

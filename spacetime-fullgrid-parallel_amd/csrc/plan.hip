@@ -517,14 +517,14 @@ extern "C" int stk_kron_plan_ghost_apply(stk_kron_plan *p, void *stream, int32_t
     if (!x_lo && !x_hi) return 0;
     if (p->packed) {
         const stk_pack_pattern *form = p->paired && n_loc >= 8 ? &p->pack_pairs : &p->pack;
-        return stk_kron_pack_ghost_apply(stream, form, n_loc, ld, n_terms, t, x_lo, x_hi, y);
+        return stk_kron_pack_ghost_apply(stream, form, n_loc, ld, n_terms, t, x, x_lo, x_hi, y);
     }
     if (p->explicit_pairs && n_loc >= 24) {
         stk_pack_pattern form;
         if (!explicit_pattern_for(p, n_terms, t, &form)) return 1;
         stk_kron_pack_term in_order[3];
         for (int k = 0; k < n_terms; ++k) in_order[k] = stk_kron_pack_term{t[k].tri, k};
-        return stk_kron_pack_ghost_apply(stream, &form, n_loc, ld, n_terms, in_order, x_lo, x_hi, y);
+        return stk_kron_pack_ghost_apply(stream, &form, n_loc, ld, n_terms, in_order, x, x_lo, x_hi, y);
     }
     STK_REQUIRE(x, "stk_kron_plan_ghost_apply: the plain form needs x");
     stk_kron_ell_term terms[3];

@@ -116,7 +116,7 @@ class SchurMPI(LinearOperatorMPI):
                 # in flight (reference mpi_kron.py:193-200), their share afterwards
                 self.time_communication = vec_in.communicate_bdr(
                     callback=lambda: packed.apply(first, x, None, n_loc, ld, 0.0, u))
-                packed.apply_ghost(first, vec_in.X_lo, vec_in.X_hi, n_loc, ld, u)
+                packed.apply_ghost(first, x, vec_in.X_lo, vec_in.X_hi, n_loc, ld, u)
                 ghosts = vec_in.ghost_interleaved()
             else:
                 if self.dofs_distr.size > 1:

@@ -102,6 +102,14 @@ _PROTOTYPES = {
         c_p, c_i64, OPERATOR_FN, c_p, OPERATOR_FN, c_p, ALLREDUCE_FN, c_p, c_p,
         c_p, c_f64, c_i32, c_p, c_p, c_p
     ]),
+    'stk_pcg_slab_work_size': (c_i64, [c_i32, c_i32, c_i32, c_i32]),
+    'stk_pcg_solve_slab': (ctypes.c_int, [
+        c_p, c_i32, c_i32, c_i32, c_i32, c_i32, OPERATOR_FN, c_p, OPERATOR_FN, c_p,
+        ALLREDUCE_FN, c_p, c_p, c_p, c_f64, c_i32, c_p, c_p, c_p
+    ]),
+    'stk_slab_dot_work_size': (c_i64, [c_i32, c_i32]),
+    'stk_slab_dot': (ctypes.c_int, [c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_i32, c_i32, c_p]),
+    'stk_sum_steps': (c_f64, [c_p, c_i32]),
     'stk_slab_gather_columns': (ctypes.c_int, [c_p, c_i32, c_i32, c_p, c_p, c_i32, c_p, c_i32]),
     'stk_slab_scatter_columns': (ctypes.c_int, [c_p, c_i32, c_i32, c_p, c_p, c_i32, c_p, c_i32]),
     'stk_slab_ld': (ctypes.c_int, [c_i32]),
@@ -134,6 +142,11 @@ _PROTOTYPES = {
         c_p, c_i64, OPERATOR_FN, c_p, OPERATOR_FN, c_p, ALLREDUCE_FN, c_p, c_p,
         c_i32, c_f64, c_f64, c_p, c_p, c_p, c_p, c_p, c_p, c_p
     ]),
+    'stk_lanczos_slab_work_size': (c_i64, [c_i32, c_i32, c_i32, c_i32]),
+    'stk_lanczos_slab': (ctypes.c_int, [
+        c_p, c_i32, c_i32, c_i32, c_i32, c_i32, OPERATOR_FN, c_p, OPERATOR_FN, c_p,
+        ALLREDUCE_FN, c_p, c_p, c_i32, c_f64, c_f64, c_p, c_p, c_p, c_p, c_p, c_p, c_p
+    ]),
     'stk_kron_sum_apply': (ctypes.c_int, [
         c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_i32,
         ctypes.POINTER(KronTerm), c_f64, c_p
@@ -157,7 +170,7 @@ _PROTOTYPES = {
     ]),
     'stk_kron_pack_ghost_apply': (ctypes.c_int, [
         c_p, ctypes.POINTER(PackPattern), c_i32, c_i32, c_i32,
-        ctypes.POINTER(KronPackTerm), c_p, c_p, c_p
+        ctypes.POINTER(KronPackTerm), c_p, c_p, c_p, c_p
     ]),
     'stk_kron_pack_apply_multi': (ctypes.c_int, [
         c_p, ctypes.POINTER(PackPattern), c_i32, c_i32, c_i32,

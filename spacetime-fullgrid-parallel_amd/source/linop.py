@@ -556,14 +556,18 @@ class EllMatrices:
 
     def apply_local(self, specs, n_loc, ld, beta, out):
         """The part of `apply` that needs no ghost rows (x_lo, x_hi ignored):
-        can run while the halo exchange is in flight."""
+        can run while the halo exchange is in flight.  With beta = 0 when
+        apply_ghost is to follow."""
         _lib.check(_lib.lib().stk_kron_ell_apply(
             _lib.stream(), ctypes.byref(self.pattern), n_loc, ld, len(specs),
             self._terms(specs, False), beta, _lib.ptr(out)))
 
     def apply_ghost(self, specs, n_loc, ld, out):
-        """Adds what the ghost rows contribute: apply = apply_local, then
-        apply_ghost once the exchange has completed."""
+        """apply = apply_local (beta = 0), then apply_ghost once the exchange has
+        completed: the first and last local time step are recomputed with the
+        received rows, in the order of operations of the main kernel, and
+        overwrite what apply_local left there -- the result does not depend on
+        where the slabs are cut (stk_kron_ell_ghost_apply)."""
         if any(lo is not None or hi is not None for _, _, _, lo, hi in specs):
             _lib.check(_lib.lib().stk_kron_ell_ghost_apply(
                 _lib.stream(), ctypes.byref(self.pattern), n_loc, ld,
@@ -821,15 +825,18 @@ class PackedEllMatrices:
             hit = self._vals_for[mats] = (vals, pat)
         return hit[1]
 
-    def apply_ghost(self, specs, x_lo, x_hi, n_loc, ld, out):
-        """Adds what the ghost time rows contribute after `apply` ran without
-        them (ghosts=None) while the halo was in flight: x_lo / x_hi are the
-        received rows, contiguous, or None (stk_kron_pack_ghost_apply)."""
+    def apply_ghost(self, specs, x, x_lo, x_hi, n_loc, ld, out):
+        """Completes the first and last local time step after `apply` ran without
+        the ghost steps (ghosts=None, beta = 0) while the halo was in flight: both
+        are recomputed from `x` and the received rows x_lo / x_hi (contiguous, or
+        None) in the arithmetic order of the one-pass form and overwrite what the
+        pass left, so that the result does not depend on where the slabs are cut
+        (stk_kron_pack_ghost_apply)."""
         if x_lo is None and x_hi is None:
             return
         _lib.check(_lib.lib().stk_kron_pack_ghost_apply(
             _lib.stream(), ctypes.byref(self._pattern_for(specs)), n_loc, ld, len(specs),
-            self._terms(specs), _lib.ptr(x_lo), _lib.ptr(x_hi), _lib.ptr(out)))
+            self._terms(specs), _lib.ptr(x), _lib.ptr(x_lo), _lib.ptr(x_hi), _lib.ptr(out)))
 
     def apply_multi(self, specs, n_loc, ld, beta, out, steps=None):
         """y = beta*y + sum over specs (tri, matrix index, x): every term reads a

@@ -456,10 +456,11 @@ class _FusedKronSum:
     use_pack = True  # packed matrix stream when the plan fits
     # Several ranks, packed form: True = the pass over the slab runs WITHOUT the
     # ghost steps while the halo exchange is in flight and a one-lane-per-row
-    # kernel adds their contribution afterwards (the reference overlaps the
-    # exchange with the interior rows, mpi_kron.py:193-200); False = wait for the
-    # halo, then one pass with the ghost steps as an extra lane per row.  A halo
-    # that is already there (cached) always takes the one-pass form.
+    # kernel recomputes the first and last local step afterwards (the reference
+    # overlaps the exchange with the interior rows, mpi_kron.py:193-200); False =
+    # wait for the halo, then one pass with the ghost steps as an extra lane per
+    # row.  A halo that is already there (cached) always takes the one-pass form.
+    # Both forms, and the one-rank kernel, round every entry the same way.
     overlap = True
 
     @classmethod
@@ -503,11 +504,15 @@ class _FusedKronSum:
             ghosts = None
             specs = [(self.tri[k], k) for k in range(self.n_terms)]
             halo = self.dofs_distr.size > 1 and (self.needs_lo or self.needs_hi)
-            if halo and type(self).overlap and not vec_in.communicated_bdr:
+            if (halo and type(self).overlap and not vec_in.communicated_bdr
+                    and beta == 0.0):
+                # (the boundary steps are REWRITTEN afterwards: a beta != 0 would
+                # need the old values the pass has replaced -- one-pass form then)
                 time_comm = vec_in.communicate_bdr(callback=lambda: packed.apply(
-                    specs, vec_in.buf, None, vec_in.n_loc, vec_in.ld, beta,
+                    specs, vec_in.buf, None, vec_in.n_loc, vec_in.ld, 0.0,
                     vec_out.buf))
-                packed.apply_ghost(specs, vec_in.X_lo if self.needs_lo else None,
+                packed.apply_ghost(specs, vec_in.buf,
+                                   vec_in.X_lo if self.needs_lo else None,
                                    vec_in.X_hi if self.needs_hi else None,
                                    vec_in.n_loc, vec_in.ld, vec_out.buf)
                 return time_comm
@@ -527,6 +532,16 @@ class _FusedKronSum:
                     beta, vec_out.buf)
 
             if self.dofs_distr.size > 1 and (self.needs_lo or self.needs_hi):
+                if beta != 0.0:
+                    # the boundary steps are rewritten after the local part, which
+                    # needs the old y they scale: the one-call form keeps a copy
+                    time_comm = vec_in.communicate_bdr()
+                    lo = vec_in.X_lo if self.needs_lo else None
+                    hi = vec_in.X_hi if self.needs_hi else None
+                    self.ell.apply([(self.tri[k], k, vec_in.buf, lo, hi)
+                                    for k in range(self.n_terms)], vec_in.n_loc,
+                                   vec_in.ld, beta, vec_out.buf)
+                    return time_comm
                 time_comm = vec_in.communicate_bdr(callback=local)
                 lo = vec_in.X_lo if self.needs_lo else None
                 hi = vec_in.X_hi if self.needs_hi else None
@@ -588,7 +603,7 @@ class _FusedKronSum:
                 specs, vec_in.buf, None, n_loc, ld, 0.0, vec_out.buf))}
         if lo is not None or hi is not None:
             out['ghost_share_ms'] = timed(lambda: packed.apply_ghost(
-                specs, lo, hi, n_loc, ld, vec_out.buf))
+                specs, vec_in.buf, lo, hi, n_loc, ld, vec_out.buf))
             ghosts = vec_in.ghost_interleaved()
             out['one_pass_with_ghost_lanes_ms'] = timed(lambda: packed.apply(
                 specs, vec_in.buf, ghosts, n_loc, ld, 0.0, vec_out.buf))

@@ -245,13 +245,15 @@ def startup_report(dofs_distr, tensors=()):
 _dot_ws = {}
 
 
-def _dot_workspace(device):
-    ws = _dot_ws.get(device)
+def _dot_workspace(device, M, n_loc, N):
+    """(scratch of stk_slab_dot, the N per-time-step sums) for slabs of this shape."""
+    key = (device, M, n_loc, N)
+    ws = _dot_ws.get(key)
     if ws is None:
-        n = int(_lib.lib().stk_dot_work_size())
+        n = int(_lib.lib().stk_slab_dot_work_size(M, n_loc))
         ws = (torch.empty(n, dtype=torch.float64, device=device),
-              torch.empty(2, dtype=torch.float64, device=device))
-        _dot_ws[device] = ws
+              torch.zeros(N, dtype=torch.float64, device=device))
+        _dot_ws[key] = ws
     return ws
 
 
@@ -416,17 +418,25 @@ class KronVectorMPI:
         return _ScaledVector(1.0 / float(other), self)
 
     def dot(self, vec_other):
-        """Global inner product (reference mpi_vector.py:205-210): local
-        deterministic reduction on the device, sum over ranks, one D2H read."""
+        """Global inner product (reference mpi_vector.py:205-210).  The reference
+        adds the products slab by slab and all-reduces one number, so its value
+        depends on the number of ranks in the last digits.  Here every TIME STEP is
+        summed over the spatial index in a fixed shape (stk_slab_dot), the N
+        per-step sums are all-reduced (each has one contributor: exact) and added in
+        increasing t on every rank: one value whatever the partition of the time
+        axis, bit for bit; one D2H read of N doubles."""
         assert (isinstance(vec_other, KronVectorMPI))
         assert (vec_other.buf.shape == self.buf.shape)
-        work, out = _dot_workspace(self.buf.device)
-        _lib.check(_lib.lib().stk_dot(_lib.stream(), self.buf.numel(),
-                                      _lib.ptr(self.buf),
-                                      _lib.ptr(vec_other.buf), _lib.ptr(work),
-                                      _lib.ptr(out)))
-        self.dofs_distr.comm.allreduce_tensor_(out[:1])
-        return float(out[0].item())
+        work, steps = _dot_workspace(self.buf.device, self.M, self.n_loc, self.N)
+        _lib.check(_lib.lib().stk_slab_dot(
+            _lib.stream(), self.M, self.n_loc, self.ld, _lib.ptr(self.buf),
+            _lib.ptr(vec_other.buf), _lib.ptr(work), self.N, self.t_begin,
+            _lib.ptr(steps)))
+        self.dofs_distr.comm.allreduce_tensor_(steps)
+        total = 0.0
+        for value in steps.tolist():  # increasing t, plain additions (stk_sum_steps)
+            total += value
+        return total
 
     # -- I/O -------------------------------------------------------------------
     def scatter(self, X_glob):

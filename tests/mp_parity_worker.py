@@ -1,0 +1,111 @@
+"""Worker of tests/test_distributed.py (gpu): a BASELINE configuration solved on
+several ranks, compared BIT FOR BIT with the one-rank solve of the same process and
+within the north star's 1e-10 with the CPU oracle's trajectory
+(tests/golden/o1_pcg_*; reference heateq_mpi_test.py:138-189 runs its comparison
+under mpirun the same way).
+
+Two ways to be several ranks on the one GPU of the test box:
+* launched by torch.distributed.run with STK_BACKEND=gloo: one process per rank
+  (the pool allows six processes on a card: up to five ranks);
+* STK_TEST_THREAD_RANKS=R: R ranks as threads of this process
+  (tests/thread_comm.py) -- how the 8-rank shapes of configs 2 and 3 fit the box.
+
+What must hold on any number of ranks, because every kernel rounds every entry as
+the one-rank kernel does and dot sums per time step in a fixed shape:
+iteration count, the whole r.Pr history, the iterate and the metric operator's
+output are EQUAL to the one-rank run's (np.array_equal)."""
+import os
+import sys
+import threading
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, 'spacetime-fullgrid-parallel_amd'))
+
+import heateq_mpi as hm  # noqa: E402
+from source.comm import MPI, Comm  # noqa: E402
+from source.linalg import PCG  # noqa: E402
+from source.mpi_kron import SumMPI, TridiagKronMatMPI  # noqa: E402
+from source.mpi_vector import KronVectorMPI  # noqa: E402
+
+J_TIME = int(os.environ.get('STK_TEST_J_TIME', '5'))
+J_SPACE = int(os.environ.get('STK_TEST_J_SPACE', '8'))
+PROBLEM = os.environ.get('STK_TEST_PROBLEM', 'square')
+SETUP = threading.Lock()  # plan construction reads process-wide tuning keys: one rank at a time
+_X = {}
+
+
+def bench_vector(N, M):
+    """The bench's input, np.random.seed(128); rand(N, M) (heateq_mpi_timing.py:81-83)."""
+    with SETUP:
+        if (N, M) not in _X:
+            _X[(N, M)] = np.random.RandomState(128).rand(N, M)
+    return _X[(N, M)]
+
+
+def solve(comm):
+    """(iterations, history, iterate, metric output) -- the last two gathered on rank 0."""
+    with SETUP:
+        h = hm.HeatEquationMPI(J_space=J_SPACE, J_time=J_TIME, problem=PROBLEM, comm=comm)
+    dd = h.dofs_distr
+    X = bench_vector(h.N, h.M)
+    x = KronVectorMPI(dd, X[dd.t_begin:dd.t_end])
+    metric = SumMPI(dd, [TridiagKronMatMPI(dd, h.A_t, h.M_x), TridiagKronMatMPI(dd, h.M_t, h.A_x)])
+
+    def gathered(v):
+        out = np.zeros(h.N * h.M) if comm.Get_rank() == 0 else None
+        v.gather(out)
+        return out
+
+    y = gathered(metric @ x)
+    del x, metric
+    hist = []
+    w, its = PCG(h.WT_S_W, h.P, h.rhs, history=hist)
+    return its, np.asarray(hist), gathered(w), y, (h.N, h.M)
+
+
+def main():
+    threads = int(os.environ.get('STK_TEST_THREAD_RANKS', '0'))
+    if threads:
+        from thread_comm import run_ranks
+        size = threads
+        got = run_ranks(size, solve)[0]
+        rank = 0
+    else:
+        comm = MPI.COMM_WORLD
+        rank, size = comm.Get_rank(), comm.Get_size()
+        assert size > 1
+        got = solve(comm)
+        comm.Barrier()
+    if rank != 0:
+        return
+    torch.cuda.empty_cache()
+    its, hist, w, y, (N, M) = got
+    its1, hist1, w1, y1, _ = solve(Comm(distributed=False))
+    # the partition of the time axis leaves no trace
+    assert np.array_equal(y, y1), ('metric operator', float(np.max(np.abs(y - y1))))
+    assert its == its1, (its, its1)
+    assert np.array_equal(hist, hist1), ('history', hist / hist1 - 1.0)
+    assert np.array_equal(w, w1), ('iterate', float(np.max(np.abs(w - w1))))
+    # ... and the trajectory is the CPU path's
+    g = np.load(os.path.join(HERE, 'golden', 'o1_pcg_%s_J%d_J%d.npz' % (PROBLEM, J_TIME, J_SPACE)))
+    assert its == int(g['iters']), (its, int(g['iters']))
+    dev = float(np.max(np.abs(hist / g['hist'] - 1.0)))
+    assert dev < 1e-10, dev
+    st, sx = (int(v) for v in g['sample_strides'])
+    w = w.reshape(N, M)
+    assert abs(np.linalg.norm(w) - g['w_norm']) < 1e-10 * g['w_norm']
+    err = np.linalg.norm(w[::st, ::sx] - g['w_sample']) / np.linalg.norm(g['w_sample'])
+    assert err < 1e-10, err
+    print('mp_parity_worker ok: %s J_time=%d J_space=%d on %d %s, %d iterations, history equal to the '
+          'one-rank run, %.2e from the oracle' % (PROBLEM, J_TIME, J_SPACE, size,
+                                                  'threads' if threads else 'processes', its, dev))
+
+
+if __name__ == '__main__':
+    main()

@@ -70,6 +70,37 @@ def test_distributed_solve_on_slabs_long_enough_for_row_pairs():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('nproc', [2, 4])
+def test_baseline_config_on_several_processes_equals_the_one_rank_solve(nproc):
+    """BASELINE config 2 (J_time = 5, J_space = 8, square) on 2 and 4 processes sharing
+    the GPU over gloo: iteration count, the whole r.Pr history, the iterate and the
+    metric operator's output are EQUAL (bit for bit) to the one-rank run, and the
+    history is within 1e-10 of the CPU oracle's (tests/golden/o1_pcg_square_J5_J8):
+    reference heateq_mpi_test.py:138-189 under mpirun."""
+    out = _run('mp_parity_worker.py', nproc, {'STK_BACKEND': 'gloo', 'STK_TEST_J_TIME': '5',
+                                              'STK_TEST_J_SPACE': '8'}, timeout=1200)
+    assert 'mp_parity_worker ok' in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('J_time,J_space,ranks', [(5, 8, 8), (6, 9, 8), (6, 9, 3)])
+def test_baseline_config_in_its_eight_rank_shape_equals_the_one_rank_solve(J_time, J_space, ranks):
+    """Configs 2 and 3 cut into EIGHT time slabs (config 3 is defined as an 8-GPU
+    run: 9-step slabs of 1 046 529 rows; config 2: slabs of 4 and 5 steps), every rank a
+    thread of one process on the box's GPU (tests/thread_comm.py -- the pool allows
+    six processes on a card): halo exchange, the overlapped ghost form, the all-to-all
+    transposes of the wavelet transform and the per-step partial sums of dot as on an
+    8-GPU node.  The solve is bit for bit the one-rank solve and within 1e-10 of the
+    oracle's trajectory; config 3 also on three ranks (slabs of 21, 22, 22)."""
+    env = dict(os.environ, STK_TEST_THREAD_RANKS=str(ranks), STK_TEST_J_TIME=str(J_time),
+               STK_TEST_J_SPACE=str(J_space), OMP_NUM_THREADS='1')
+    res = subprocess.run([sys.executable, os.path.join(HERE, 'mp_parity_worker.py')], env=env,
+                         capture_output=True, text=True, timeout=1500)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    assert 'mp_parity_worker ok' in res.stdout
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('nproc', [1, 2, 3])
 def test_every_operator_class_on_several_ranks(nproc):
     """Every operator class and the vector algebra against dense NumPy ground

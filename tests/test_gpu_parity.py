@@ -7,6 +7,8 @@ are held to 1e-12 here (they differ from the reference only by the order of
 floating-point additions), whole solves in the default arithmetic to 1e-10 on
 every r.Pr entry and on the iterates, and to exact equality on iteration
 counts; the opt-in arithmetic='fast' to 1e-9 per entry (it measures 4.6e-10)."""
+import ctypes
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -303,19 +305,19 @@ def test_heat_operators_and_solve_match_reference_golden(stk, g3, schur):
     assert relerr(_np(w), g3['pcg_w_multigrid']) < 1e-10
     tag = 'golden_%d_%d_%s' % (N, M, schur)
     # 60 unconverged steps of plain CG amplify the last bits of one S apply
-    # (the oracle itself sits 7.5e-9 from the reference on g3_square3): the
-    # iterate after FIVE steps is held to the north star's 1e-10, the one after
-    # 60 to ten times what is recorded in parity_history_dev.json
+    # (the oracle itself sits 7.5e-9 from the reference on g3_square3): held to
+    # ten times what the GPU measures (5.8e-9; profiles/r06_parity_history_dev.json),
+    # the Lanczos coefficients (2.8e-14) and Ritz values (1.3e-15) likewise
     w2, it2 = PCG(S, IdentityMPI(dd), rhs, kmax=60)
     assert it2 == int(g3['pcg_unprec_iters_multigrid'])
-    _scalar_dev(tag + '_unprec_w', relerr(_np(w2), g3['pcg_unprec_w_multigrid']), 1e-7)
+    _scalar_dev(tag + '_unprec_w', relerr(_np(w2), g3['pcg_unprec_w_multigrid']), 6e-8)
 
     lz = Lanczos(WT_S_W, P, w=_vec(dd, g3['X']))
     assert lz.iterations == int(g3['lz_its_multigrid'])
-    _scalar_dev(tag + '_lz_lmax', abs(lz.lmax / g3['lz_lmax_multigrid'] - 1.0), 1e-10)
-    _scalar_dev(tag + '_lz_lmin', abs(lz.lmin / g3['lz_lmin_multigrid'] - 1.0), 1e-10)
+    _scalar_dev(tag + '_lz_lmax', abs(lz.lmax / g3['lz_lmax_multigrid'] - 1.0), 1e-13)
+    _scalar_dev(tag + '_lz_lmin', abs(lz.lmin / g3['lz_lmin_multigrid'] - 1.0), 1e-13)
     assert len(lz.alpha) == len(g3['lz_alpha_multigrid'])
-    _hist_dev(tag + '_lz_alpha', lz.alpha, g3['lz_alpha_multigrid'], 1e-10)
+    _hist_dev(tag + '_lz_alpha', lz.alpha, g3['lz_alpha_multigrid'], 1e-12)
 
 
 @pytest.mark.parametrize('problem,J_space', [('square', 4), ('lshape', 3),
@@ -1420,16 +1422,194 @@ def test_kron_pack_randomised_shapes(stk):
         y_plain = slab(y0)
         ell.apply([(tris[k], k, x, glo, ghi) for k in range(nt)], n_loc, ld,
                   beta, y_plain)
-        if glo is None and ghi is None:  # same arithmetic in the same order
-            assert torch.equal(y, y_plain), (case, M, n_loc, nt)
-        else:  # the plain form adds the ghost terms in a second kernel
-            assert relerr(got, y_plain[:, :n_loc].cpu().numpy()) < 1e-14
+        # same arithmetic in the same order -- with ghost rows too: the plain form
+        # recomputes its first and last step in a second kernel, in the main
+        # kernel's order of operations (round 6; rounds 1-5 added a share: 1e-14)
+        assert torch.equal(y, y_plain), (case, M, n_loc, nt)
     # too many distinct values: the planner keeps the plain form
     m = sp.random(300, 300, density=0.02, random_state=rng, format='csr')
     m = sp.csr_matrix(m + sp.eye(300))
     m.data = rng.rand(m.nnz)
     e = EllMatrices([m])
     assert e.ovf_indptr is not None or not e.packed.ok or e.packed.n_codes <= 512
+
+
+def _blocks(N, size):
+    """DofDistributionMPI's blocks (reference mpi_vector.py:17-34): N // size steps
+    each, the remainder to the LAST ranks."""
+    base, extra = divmod(N, size)
+    out, start = [], 0
+    for p in range(size):
+        stop = start + base + (1 if p >= size - extra else 0)
+        out.append((start, stop))
+        start = stop
+    return out
+
+
+def test_slab_dot_does_not_depend_on_the_partition(stk):
+    """stk_slab_dot: the per-time-step sums of a slab are the same doubles wherever
+    the time axis is cut (the sum over the spatial index has one shape, a function of M
+    alone), so KronVectorMPI.dot returns ONE value on 1, 2, 3, 4 or 8 ranks -- the
+    reference's (and rounds 1-5's) slab-by-slab sum moves the history of a solve by
+    4.6e-11 between 1 and 8 ranks.  Slab lengths 1 .. 300 walk through several row
+    blocks per workgroup, several items per thread and two column ranges."""
+    lib = stk.lib()
+    rng = np.random.RandomState(5)
+
+    def steps_of(Xs, Ys, N, t_begin):
+        M, n_loc = Xs.shape
+        ld = n_loc + (n_loc & 1)
+        x = torch.zeros((M, ld), dtype=torch.float64, device='cuda')
+        y = torch.zeros((M, ld), dtype=torch.float64, device='cuda')
+        x[:, :n_loc], y[:, :n_loc] = torch.from_numpy(Xs).cuda(), torch.from_numpy(Ys).cuda()
+        work = torch.empty(int(lib.stk_slab_dot_work_size(M, n_loc)), dtype=torch.float64, device='cuda')
+        out = torch.full((N,), 7.0, dtype=torch.float64, device='cuda')  # the other steps must come out as zero
+        stk.check(lib.stk_slab_dot(stk.stream(), M, n_loc, ld, stk.ptr(x), stk.ptr(y), stk.ptr(work), N, t_begin,
+                                   stk.ptr(out)))
+        return out.cpu().numpy()
+
+    for M, N in [(1, 5), (7, 9), (255, 17), (256, 33), (257, 33), (1000, 65), (4099, 129), (70001, 9), (300, 300)]:
+        X, Y = rng.randn(M, N), rng.randn(M, N)
+        whole = steps_of(X, Y, N, 0)
+        exact = np.einsum('it,it->t', X, Y)
+        assert np.allclose(whole, exact, rtol=0, atol=1e-13 * np.abs(X * Y).sum(axis=0).max())
+        for size in (2, 3, 4, 8):
+            if size > N:
+                continue
+            total = np.zeros(N)
+            for b, e in _blocks(N, size):
+                part = steps_of(np.ascontiguousarray(X[:, b:e]), np.ascontiguousarray(Y[:, b:e]), N, b)
+                assert np.all(part[:b] == 0.0) and np.all(part[e:] == 0.0)
+                total += part  # what the all-reduce does: every entry has one contributor
+            assert np.array_equal(total, whole), (M, N, size)
+        host = np.ascontiguousarray(whole)
+        lib.stk_sum_steps.restype = ctypes.c_double
+        s = 0.0
+        for v in whole:
+            s += v
+        assert lib.stk_sum_steps(host.ctypes.data_as(ctypes.c_void_p), N) == s
+    # the vector class: one value however it is cut
+    from source.mpi_vector import DofDistributionMPI, KronVectorMPI
+
+    class _Cut:  # rank `rank` of `size`, no transport: the all-reduce is done by hand below
+        def __init__(self, rank, size):
+            self.rank, self.size, self.parts = rank, size, None
+
+        def Get_rank(self):
+            return self.rank
+
+        def Get_size(self):
+            return self.size
+
+        def allreduce_tensor_(self, t):
+            self.parts = t.clone()
+            return t
+
+    N, M = 33, 961
+    X, Y = rng.rand(N, M), rng.rand(N, M)
+    one = _vec(_dd(N, M), X).dot(_vec(_dd(N, M), Y))
+    assert abs(one - np.vdot(X, Y)) < 1e-13 * np.vdot(X, Y)
+    for size in (2, 4, 8):
+        steps = torch.zeros(N, dtype=torch.float64, device='cuda')
+        for r in range(size):
+            dd = DofDistributionMPI(_Cut(r, size), N, M)
+            KronVectorMPI(dd, X[dd.t_begin:dd.t_end]).dot(KronVectorMPI(dd, Y[dd.t_begin:dd.t_end]))
+            steps += dd.comm.parts
+        total = 0.0
+        for v in steps.tolist():
+            total += v
+        assert total == one, (size, total, one)
+
+
+def test_kron_apply_does_not_depend_on_the_partition(stk):
+    """The Kronecker sum on time slabs -- the one-pass form with ghost lanes, the
+    overlapped form (pass without ghost steps + stk_kron_pack_ghost_apply) and the
+    plain sliced-ELL form (stk_kron_ell_apply + _ghost_apply) -- gives, on every
+    slab of 2, 3, 4, 5 and 8 ranks, bit for bit the rows of the ONE-RANK apply: the
+    time stencil has one order of operations in every form (rounds
+    1-5 added the ghost rows' share last, an order no interior step has).  Slabs of one
+    step (both ghost rows meet in it), odd and even lengths, row pairs, one to three
+    terms, an identity time factor among them."""
+    from source.assembly import space_matrices
+    from source.linop import EllMatrices
+    from source.problem import problem_helper
+    rng = np.random.RandomState(99)
+    M_x, A_x = space_matrices(problem_helper('square', J_space=3, J_time=2)[0])
+    mats = [M_x, A_x, sp.csr_matrix(M_x + 0.3 * A_x)]
+    ell = EllMatrices(mats, [M_x])
+    M = ell.M
+    forms = [('one row per slot row', ell.packed_variant(1)), ('row pairs', ell.packed_variant(2))]
+    assert all(f.ok for _, f in forms)
+
+    def slab(a):
+        n = a.shape[1]
+        s_ = torch.zeros((M, n + (n & 1)), dtype=torch.float64, device='cuda')
+        s_[:, :n] = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        return s_
+
+    for N, nt, identity in [(5, 2, False), (9, 2, False), (17, 3, True), (33, 1, False), (65, 2, False),
+                            (66, 3, False)]:
+        X = rng.rand(M, N)
+        tris = [None if (identity and k == 1) else rng.rand(3, N) for k in range(nt)]
+        ld = N + (N & 1)
+        x = slab(X)
+        whole = {}
+        for name, form in forms:
+            y = slab(np.zeros((M, N)))
+            form.apply([(None if t is None else _lib_dev(t), k) for k, t in enumerate(tris)], x, None, N, ld, 0.0, y)
+            whole[name] = y[:, :N].clone()
+        y = slab(np.zeros((M, N)))
+        ell.apply([(None if t is None else _lib_dev(t), k, x, None, None) for k, t in enumerate(tris)], N, ld, 0.0, y)
+        whole['plain'] = y[:, :N].clone()
+        assert torch.equal(whole['plain'], whole['row pairs']) and torch.equal(whole['plain'],
+                                                                              whole['one row per slot row'])
+        T = [np.eye(N) if t is None else np.diag(t[1]) + np.diag(t[0, 1:], -1) + np.diag(t[2, :-1], 1) for t in tris]
+        want = sum((mats[k] @ X) @ T[k].T for k in range(nt))
+        assert relerr(whole['plain'].cpu().numpy(), want) < 1e-13
+        for size in (2, 3, 4, 5, 8):
+            if size > N:
+                continue
+            for b, e in _blocks(N, size):
+                n_loc, ldl = e - b, (e - b) + ((e - b) & 1)
+                xs = slab(X[:, b:e])
+                lo = torch.from_numpy(np.ascontiguousarray(X[:, b - 1])).cuda() if b > 0 else None
+                hi = torch.from_numpy(np.ascontiguousarray(X[:, e])).cuda() if e < N else None
+                local = [None if t is None else _lib_dev(np.ascontiguousarray(t[:, b:e])) for t in tris]
+                specs = [(local[k], k) for k in range(nt)]
+                gh = None
+                if lo is not None or hi is not None:
+                    gh = torch.zeros((M, 2), dtype=torch.float64, device='cuda')
+                    if lo is not None:
+                        gh[:, 0] = lo
+                    if hi is not None:
+                        gh[:, 1] = hi
+                for name, form in forms:
+                    ref = whole[name][:, b:e]
+                    y1 = slab(rng.rand(M, n_loc))
+                    form.apply(specs, xs, gh, n_loc, ldl, 0.0, y1)
+                    assert torch.equal(y1[:, :n_loc], ref), (name, 'ghost lanes', N, size, b, e)
+                    y2 = slab(rng.rand(M, n_loc))
+                    form.apply(specs, xs, None, n_loc, ldl, 0.0, y2)
+                    form.apply_ghost(specs, xs, lo, hi, n_loc, ldl, y2)
+                    assert torch.equal(y2[:, :n_loc], ref), (name, 'overlapped', N, size, b, e)
+                    if ldl > n_loc:
+                        assert float(y2[:, n_loc:].abs().max()) == 0.0
+                y3 = slab(rng.rand(M, n_loc))
+                ell.apply([(local[k], k, xs, lo, hi) for k in range(nt)], n_loc, ldl, 0.0, y3)
+                assert torch.equal(y3[:, :n_loc], whole['plain'][:, b:e]), ('plain', N, size, b, e)
+                y4 = slab(rng.rand(M, n_loc))
+                ell.apply_local([(local[k], k, xs, None, None) for k in range(nt)], n_loc, ldl, 0.0, y4)
+                ell.apply_ghost([(local[k], k, xs, lo, hi) for k in range(nt)], n_loc, ldl, y4)
+                assert torch.equal(y4, y3), ('plain, overlapped', N, size, b, e)
+                # beta != 0 on a slab with neighbours: the one-call form keeps the old
+                # boundary entries it scales (y = beta y0 + A x, rounded as on one rank)
+                y0 = rng.rand(M, n_loc)
+                y5, y6 = slab(y0), slab(y0)
+                ell.apply([(local[k], k, xs, lo, hi) for k in range(nt)], n_loc, ldl, 0.5, y5)
+                two = forms[1][1]
+                two.apply(specs, xs, gh, n_loc, ldl, 0.5, y6)
+                assert torch.equal(y5, y6), ('beta', N, size, b, e)
+                assert relerr(y5[:, :n_loc].cpu().numpy(), 0.5 * y0 + want[:, b:e]) < 1e-13
 
 
 def test_kron_pack_row_pairs(stk):
@@ -1504,19 +1684,19 @@ def test_kron_pack_row_pairs(stk):
             if ld > n_loc:
                 assert float(y2[:, n_loc:].abs().max()) == 0.0
             # the overlapped form of several ranks (reference mpi_kron.py:193-200): the
-            # pass WITHOUT the ghost steps, then their share from the received rows as
-            # they arrive (stk_kron_pack_ghost_apply) -- the same sums, regrouped
+            # pass WITHOUT the ghost steps (beta = 0), then the first and last step
+            # recomputed with the received rows as they arrive
+            # (stk_kron_pack_ghost_apply) -- bit for bit the one-pass form
             if gh is not None:
                 dev_lo = None if lo is None else torch.from_numpy(lo).cuda()
                 dev_hi = None if hi is None else torch.from_numpy(hi).cuda()
+                y2z = slab(y0)
+                two.apply(specs, x, gh, n_loc, ld, 0.0, y2z)
                 for form in (one, two):
                     y3 = slab(y0)
-                    form.apply(specs, x, None, n_loc, ld, beta, y3)
-                    form.apply_ghost(specs, dev_lo, dev_hi, n_loc, ld, y3)
-                    assert relerr(y3[:, :n_loc].cpu().numpy(), want) < 1e-13, (name, n_loc, nt)
-                    assert float((y3 - y2).abs().max()) <= 1e-13 * float(y2.abs().max())
-                    if ld > n_loc:
-                        assert float(y3[:, n_loc:].abs().max()) == 0.0
+                    form.apply(specs, x, None, n_loc, ld, 0.0, y3)
+                    form.apply_ghost(specs, x, dev_lo, dev_hi, n_loc, ld, y3)
+                    assert torch.equal(y3, y2z), (name, n_loc, nt, float((y3 - y2z).abs().max()))
     assert seen_pairs > 0
     # rows that share nothing stay alone: the planner keeps the one-row form
     circ = lambda k: sp.csr_matrix((np.ones(64), (np.arange(64), (np.arange(64) + k) % 64)), shape=(64, 64))
@@ -1699,10 +1879,11 @@ def test_kron_pack_explicit_value_pairs(stk):
             if ld > n_loc:
                 assert float(y2[:, n_loc:].abs().max()) == 0.0
             if gh is not None:
-                y3 = slab(y0)
-                two.apply(specs, x, None, n_loc, ld, beta, y3)
-                two.apply_ghost(specs, dev_lo, dev_hi, n_loc, ld, y3)
-                assert relerr(y3[:, :n_loc].cpu().numpy(), want) < 1e-13, (name, n_loc, nt)
+                y2z, y3 = slab(y0), slab(y0)
+                two.apply(specs, x, gh, n_loc, ld, 0.0, y2z)
+                two.apply(specs, x, None, n_loc, ld, 0.0, y3)
+                two.apply_ghost(specs, x, dev_lo, dev_hi, n_loc, ld, y3)
+                assert torch.equal(y3, y2z), (name, n_loc, nt)
     # the operator classes pick the form up by themselves
     from source.mpi_kron import SumMPI, TridiagKronMatMPI
     M_x, A_x = space_matrices(problem_helper('lshape_jitter', J_space=3, J_time=2)[0])

@@ -103,12 +103,12 @@ for shape in args.shapes.split(','):
         def overlapped():  # pass without ghost steps (hides the wire), then their share
             pack()
             pk.apply(pspecs, x, None, n_loc, ld, 0.0, y2)
-            pk.apply_ghost(pspecs, g[0] if lo else None, g[1] if hi else None, n_loc, ld, y2)
+            pk.apply_ghost(pspecs, x, g[0] if lo else None, g[1] if hi else None, n_loc, ld, y2)
 
         ms_pack = timed(pack)
         ms_a, ms_b = timed(one_pass), timed(overlapped)
         ms_main = timed(lambda: pk.apply(pspecs, x, None, n_loc, ld, 0.0, y2))
-        ms_go = timed(lambda: pk.apply_ghost(pspecs, g[0] if lo else None, g[1] if hi else None, n_loc, ld, y2))
+        ms_go = timed(lambda: pk.apply_ghost(pspecs, x, g[0] if lo else None, g[1] if hi else None, n_loc, ld, y2))
         overlapped()
         ell.apply(specs, n_loc, ld, 0.0, y)
         err = float((y2 - y).abs().max() / y.abs().max())
