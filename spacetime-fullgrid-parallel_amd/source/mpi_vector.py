@@ -9,6 +9,7 @@ Same classes, attributes and call signatures as the reference; differences:
   reference's ``w += alpha * p`` (linalg.py:29) becomes one fused pass;
 * communication goes through torch.distributed (RCCL/xGMI) instead of mpi4py.
 """
+import threading
 import weakref
 
 import numpy as np
@@ -245,9 +246,11 @@ def startup_report(dofs_distr, tensors=()):
 _dot_ws = {}
 
 
-def _dot_workspace(device, M, n_loc, N):
-    """(scratch of stk_slab_dot, the N per-time-step sums) for slabs of this shape."""
-    key = (device, M, n_loc, N)
+def _dot_workspace(device, M, n_loc, N, t_begin):
+    """(scratch of stk_slab_dot, the N per-time-step sums) for this slab of the time
+    axis (t_begin in the key: ranks that live in one process, as threads in
+    tests/thread_comm.py, must not share the buffers)."""
+    key = (device, M, n_loc, N, t_begin, threading.get_ident())
     ws = _dot_ws.get(key)
     if ws is None:
         n = int(_lib.lib().stk_slab_dot_work_size(M, n_loc))
@@ -427,7 +430,7 @@ class KronVectorMPI:
         axis, bit for bit; one D2H read of N doubles."""
         assert (isinstance(vec_other, KronVectorMPI))
         assert (vec_other.buf.shape == self.buf.shape)
-        work, steps = _dot_workspace(self.buf.device, self.M, self.n_loc, self.N)
+        work, steps = _dot_workspace(self.buf.device, self.M, self.n_loc, self.N, self.t_begin)
         _lib.check(_lib.lib().stk_slab_dot(
             _lib.stream(), self.M, self.n_loc, self.ld, _lib.ptr(self.buf),
             _lib.ptr(vec_other.buf), _lib.ptr(work), self.N, self.t_begin,

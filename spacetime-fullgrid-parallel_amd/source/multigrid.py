@@ -696,6 +696,70 @@ class MultiGrid(SpaceOp):
         return u
 
 
+class Smoother:
+    """SOR smoother (reference multigrid.py:83-97): PreSmooth is one forward
+    Gauss-Seidel sweep in dof order, u_i += (f_i - row_i u) / a_ii, PostSmooth one
+    backward sweep; `u` is updated in place.  The reference loops over the rows in
+    Python; here the rows are grouped by their depth in the sweep's dependency graph
+    and a group is one launch of the row engine (csrc/rows_ell.hip, <GS>, rows with
+    their diagonal) -- every row performs the sequential sweep's arithmetic on the
+    same inputs (stk_mg_smooth).
+
+    u, f: NumPy vectors of length n as in the reference (uploaded, swept, written
+    back into u), NumPy arrays (n, k) -- k right-hand sides swept together -- or
+    device slabs (n, ld), time fastest, as KronVectorMPI.buf holds them.
+    `its`: sweeps per call (the reference's class does one)."""
+    gs_rows = 'full'
+
+    def __init__(self, mat, its=1):
+        mat = sp.csr_matrix(mat)
+        assert mat.shape[0] == mat.shape[1]
+        self.its = int(its)
+        self.shape = mat.shape
+        # the sweeps of one matrix are the sweeps of the finest level of a two-level
+        # plan whose coarse space is spanned by the first unknown (never visited here)
+        n = mat.shape[0]
+        P = sp.csr_matrix((np.ones(1), (np.zeros(1, dtype=np.int64), np.zeros(1, dtype=np.int64))),
+                          shape=(n, 1))
+        self._mg = MultiGrid(mat, MeshHierarchy(P_mats=[P]), smoothsteps=self.its, vcycles=1,
+                             gs_rows=type(self).gs_rows)
+
+    def _sweeps(self, u, f, backward):
+        if torch.is_tensor(u):
+            assert torch.is_tensor(f) and u.shape == f.shape and u.shape[0] == self.shape[0]
+            self._mg.smooth(1, u, f, self.its, backward)
+            return
+        assert u.shape == f.shape and u.shape[0] == self.shape[0]
+        cols = 1 if u.ndim == 1 else u.shape[1]
+        ld = cols + (cols & 1)
+        dev = []
+        for a in (u, f):
+            slab = torch.zeros((self.shape[0], ld), dtype=torch.float64, device=_lib.compute_device())
+            slab[:, :cols] = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).reshape(-1, cols)).to(
+                slab.device)
+            dev.append(slab)
+        self._mg.smooth(1, dev[0], dev[1], self.its, backward, n_loc=cols)
+        u[...] = dev[0][:, :cols].cpu().numpy().reshape(u.shape)
+
+    def PreSmooth(self, u, f):
+        self._sweeps(u, f, False)
+
+    def PostSmooth(self, u, f):
+        self._sweeps(u, f, True)
+
+
+class PETScSMoother(Smoother):
+    """`its` forward (PreSmooth) or backward (PostSmooth) SOR sweeps, the smoother
+    MultiGrid uses (reference multigrid.py:100-127, PETSc's MatSOR with omega = 1).
+    MatSOR updates a row as u_i = (f_i - sum_{j != i} a_ij u_j) / a_ii; so do the
+    diagonal-free Gauss-Seidel copies this class sweeps with (equal to Smoother's
+    form up to rounding)."""
+    gs_rows = 'free'
+
+    def __init__(self, mat, its):
+        super().__init__(mat, its)
+
+
 class MultiGridFamily:
     """MultiGrid operators for the matrices ca * A + cm_k * M, k = 0..K-1,
     sharing one device hierarchy.  ``members[k]`` is a MultiGrid for matrix k;

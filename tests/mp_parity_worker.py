@@ -102,6 +102,16 @@ def main():
     assert abs(np.linalg.norm(w) - g['w_norm']) < 1e-10 * g['w_norm']
     err = np.linalg.norm(w[::st, ::sx] - g['w_sample']) / np.linalg.norm(g['w_sample'])
     assert err < 1e-10, err
+    out = os.path.join(REPO, 'gpurun_out')
+    if os.path.isdir(out):  # the record DESIGN.md section 5 quotes
+        import json
+        path = os.path.join(out, 'parity_multi_rank.json')
+        rec = json.load(open(path)) if os.path.exists(path) else {}
+        rec['%s_J%d_J%d_%d_%s' % (PROBLEM, J_TIME, J_SPACE, size, 'threads' if threads else 'processes')] = {
+            'iterations': int(its), 'history_equal_to_one_rank': True, 'iterate_equal_to_one_rank': True,
+            'metric_operator_equal_to_one_rank': True, 'max_rel_dev_from_oracle_history': dev,
+            'iterate_sample_rel_err_vs_oracle': float(err)}
+        json.dump(rec, open(path, 'w'), indent=1, sort_keys=True)
     print('mp_parity_worker ok: %s J_time=%d J_space=%d on %d %s, %d iterations, history equal to the '
           'one-rank run, %.2e from the oracle' % (PROBLEM, J_TIME, J_SPACE, size,
                                                   'threads' if threads else 'processes', its, dev))

@@ -220,6 +220,61 @@ def test_wavelet_op_matrices(stk):
         assert relerr(op.T @ X, ow.apply_transposed(J, X)) < TOL
 
 
+def test_smoother_classes_as_the_reference_tests_them(stk):
+    """source.multigrid.Smoother / PETScSMoother (reference multigrid.py:83-127): the
+    reference's own test (multigrid_test.py:40-58: 150 forward resp. backward sweeps
+    from zero reach A^-1 y) for both classes, and single calls against the oracle's
+    sweep in dof order -- nonzero initial guess, 1-3 sweeps per call, NumPy vectors,
+    (n, k) arrays and device slabs, on the square (M = 49 and 16 129) and the L-shape.
+    The sweeps are the sequential sweep's arithmetic row by row, with fused
+    multiply-adds where NumPy / SciPy round twice: 1e-14 per call, not bits."""
+    from oracle.multigrid import Smoother as OracleSmoother
+    from source.assembly import space_matrices
+    from source.multigrid import PETScSMoother, Smoother
+    from source.problem import problem_helper
+    g = load_golden('g3_square')
+    A = csr_from(g, 'A_x')
+    rng = np.random.RandomState(3)
+    x = rng.rand(A.shape[1])
+    y = A @ x
+    for smoother in [Smoother(A), PETScSMoother(A, 1)]:
+        x_pre = np.zeros(A.shape[1])
+        x_post = np.zeros(A.shape[1])
+        for _ in range(150):
+            smoother.PreSmooth(x_pre, y)
+            smoother.PostSmooth(x_post, y)
+        assert np.allclose(x_post, x)
+        assert np.allclose(x_pre, x)
+    mats = [A, csr_from(load_golden('g3_lshape'), 'A_x'),
+            space_matrices(problem_helper('square', J_space=6, J_time=2)[0])[1]]
+    for mat in mats:
+        n = mat.shape[0]
+        for its in (1, 3):
+            oracle = OracleSmoother(mat, its=its)
+            for cls in (Smoother, PETScSMoother):
+                sm = cls(mat, its)
+                for backward in (False, True):
+                    call = lambda s_, u_, f_: (s_.PostSmooth if backward else s_.PreSmooth)(u_, f_)
+                    u0, f = rng.rand(n), rng.rand(n)
+                    want = u0.copy()
+                    call(oracle, want, f)
+                    got = u0.copy()
+                    call(sm, got, f)
+                    assert relerr(got, want) < 1e-14, (n, its, cls.__name__, backward)
+                    # five right-hand sides at once: NumPy (n, 5) and a device slab (n, 6)
+                    U0, F = rng.rand(n, 5), rng.rand(n, 5)
+                    want = np.ascontiguousarray(U0.T)
+                    call(oracle, want, np.ascontiguousarray(F.T))
+                    got = U0.copy()
+                    call(sm, got, F)
+                    assert relerr(got, want.T) < 1e-14
+                    ud = torch.zeros((n, 6), dtype=torch.float64, device='cuda')
+                    fd = torch.zeros((n, 6), dtype=torch.float64, device='cuda')
+                    ud[:, :5], fd[:, :5] = torch.from_numpy(U0).cuda(), torch.from_numpy(F).cuda()
+                    call(sm, ud, fd)
+                    assert relerr(ud[:, :5].cpu().numpy(), want.T) < 1e-14
+
+
 def test_gauss_seidel_and_multigrid_match_reference_golden(stk, g3):
     from oracle.multigrid import Smoother
     from source.multigrid import MeshHierarchy, MultiGrid, MultiGridFamily
