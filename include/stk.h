@@ -597,6 +597,31 @@ int stk_ell_spmm(void *stream, const stk_ell_rows *ell_host, int32_t n_loc,
                  const double *x, double alpha, double beta, const double *z,
                  double *y);
 
+/* ---- direct inverse of a space matrix (InvLinOp, linop.py:18-26; precond =
+ *      'direct', heateq_mpi.py:155-157) ----------------------------------------
+ * x = A^-1 b for all time steps of a slab from the factors Pr A Pc = L U of
+ * scipy.sparse.linalg.splu (SuperLU), which stays on the host at set-up as in the
+ * reference (`self.inv = splu(mat)`); what `self.inv.solve` does per apply -- row
+ * permutation, two triangular solves, column permutation -- runs on the device,
+ * level-scheduled: wide levels of the elimination tree one launch each, runs of
+ * narrow levels inside one workgroup (csrc/sptrsv.hip).  L and U: CSR on the host
+ * (sorted columns; L unit lower triangular, U upper with its diagonal), perm_r /
+ * perm_c: SuperLU.perm_r / perm_c (NULL = identity).  The sums of a row have one
+ * shape whatever the slab length: the result does not depend on the partition of
+ * the time axis.  work: M * ld device doubles; b may be x. */
+typedef struct stk_lu stk_lu;
+int stk_lu_create(int32_t n, const int32_t *L_indptr, const int32_t *L_indices,
+                  const double *L_data, const int32_t *U_indptr,
+                  const int32_t *U_indices, const double *U_data,
+                  const int32_t *perm_r, const int32_t *perm_c, stk_lu **out);
+int stk_lu_destroy(stk_lu *lu);
+/* Any output may be NULL: dependency levels of the two solves, kernel launches
+ * per stk_lu_solve. */
+int stk_lu_info(const stk_lu *lu, int32_t *levels_L, int32_t *levels_U,
+                int32_t *launches);
+int stk_lu_solve(stk_lu *lu, void *stream, int32_t n_loc, int32_t ld,
+                 const double *b, double *x, double *work);
+
 /* ---- (A_t kron I) for a small sparse time matrix ---------------------------
  * y[., t] = (add_identity ? x[., t] : 0) + sum_e val[e] * src(col[e]) over the
  * CSR row t of the LOCAL rows of the time matrix; col < n_loc addresses the

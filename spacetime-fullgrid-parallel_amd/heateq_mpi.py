@@ -306,7 +306,7 @@ class HeatEquationMPI:
         # (profiles/r03_history_by_level.log) and there by the LAST V-cycle's restricted
         # residual and post-smoothing (profiles/r03_history_by_cycle.log); what comes
         # earlier is damped by what follows it.  The finest level gets both row forms.
-        gs_rows = {'reference': 'full', 'accurate': 'owned', 'fast': None}[arithmetic]
+        gs_rows = {'reference': 'full', 'accurate': self.ACCURATE['gs_rows'], 'fast': None}[arithmetic]
         if precond == 'multigrid' and family == 'reference':
             # one hierarchy per wavelet level from the assembled matrix
             # (reference heateq_mpi.py:147-153)
@@ -413,15 +413,23 @@ class HeatEquationMPI:
         self.setup_time = MPI.Wtime() - start_time
         self.mem_after_mpi = mem()
 
-    @staticmethod
-    def _accurate_options(plans, J, vcycles):
+    # What arithmetic='accurate' switches back to the reference's forms (class-level so
+    # that tools/history_attribution.py can move one knob at a time): the row form of
+    # the Gauss-Seidel copies, up to which level the restricted residual stays fused,
+    # how many leading V-cycles keep the fast forms, and which parts of the last one.
+    ACCURATE = {'gs_rows': 'owned', 'fuse_restrict_below_finest': True, 'fast_leading_cycles': True,
+                'fast_parts': 1}
+
+    @classmethod
+    def _accurate_options(cls, plans, J, vcycles):
         """The plan options of arithmetic='accurate' (gs_rows='owned' plans): the
         restricted residual as R (A u - f) (reference multigrid.py:174-175) on the
         finest level, (R A) u - R f below it; the fast forms in all but the last
         V-cycle and in the last one's pre-smoothing."""
-        plans.set_option('fuse_restrict_max_level', J - 1)
-        plans.set_option('fast_until_cycle', vcycles - 1)
-        plans.set_option('fast_parts', 1)
+        acc = cls.ACCURATE
+        plans.set_option('fuse_restrict_max_level', J - 1 if acc['fuse_restrict_below_finest'] else -1)
+        plans.set_option('fast_until_cycle', vcycles - 1 if acc['fast_leading_cycles'] else 0)
+        plans.set_option('fast_parts', acc['fast_parts'])
 
     def print_time_per_apply(self):
         for name in driver.OPERATORS:

@@ -120,11 +120,14 @@ class InvLinOp(SpaceOp):
     the host at setup, as in the reference.  Up to MAX_ROWS rows the device
     applies the explicit inverse with the same row-gather kernels as any other
     matrix (the sizes the reference's tests use it on: the dense inverse needs
-    M^2 doubles).  Above that the apply is the reference's own: the slab goes to
-    the host (stk_slab_download), SuperLU solves for all time columns at once,
-    and the result comes back (stk_slab_upload) -- slow, PCIe both ways, but
-    size-agnostic like linop.py:24-26."""
+    M^2 doubles).  Above that, what the reference's `self.inv.solve` does per apply
+    -- row permutation, L and U solves, column permutation -- runs on the device on
+    SuperLU's factors, level-scheduled, all time steps at once (stk_lu_solve,
+    csrc/sptrsv.hip): the slab never leaves HBM.  `host_solve = True` keeps the
+    round trip through SuperLU on the host of rounds 1-5 (the comparison partner
+    of the tests)."""
     MAX_ROWS = 8192
+    host_solve = False
 
     def __init__(self, mat):
         mat = sp.csc_matrix(mat)
@@ -134,9 +137,32 @@ class InvLinOp(SpaceOp):
         self.lu = sp.linalg.splu(mat, options={"SymmetricMode": True},
                                  permc_spec="MMD_AT_PLUS_A")
         self._dense = None
+        self._plan = None
+        self._work = None
         if n <= self.MAX_ROWS:
             self._dense = SpaceMatrix(sp.csr_matrix(self.lu.solve(np.eye(n))))
             self.mat = self._dense.mat
+
+    def _device_plan(self):
+        if self._plan is None:
+            L, U = sp.csr_matrix(self.lu.L), sp.csr_matrix(self.lu.U)
+            for T in (L, U):
+                T.sort_indices()
+            i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+            f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+            args = [i32(L.indptr), i32(L.indices), f64(L.data), i32(U.indptr), i32(U.indices),
+                    f64(U.data), i32(self.lu.perm_r), i32(self.lu.perm_c)]
+            plan = ctypes.c_void_p()
+            _lib.check(_lib.lib().stk_lu_create(self.shape[0], *[a.ctypes.data for a in args],
+                                                ctypes.byref(plan)))
+            self._plan = plan
+        return self._plan
+
+    def levels(self):
+        """(dependency levels of the L solve, of the U solve, kernel launches per apply)."""
+        out = [ctypes.c_int32() for _ in range(3)]
+        _lib.check(_lib.lib().stk_lu_info(self._device_plan(), *[ctypes.byref(v) for v in out]))
+        return tuple(v.value for v in out)
 
     def apply(self, x, out=None, n_loc=None, **kw):
         if self._dense is not None:
@@ -146,6 +172,12 @@ class InvLinOp(SpaceOp):
         if out is None:
             out = torch.empty_like(x)
         lib = _lib.lib()
+        if not self.host_solve:
+            if self._work is None or self._work.shape != x.shape or self._work.device != x.device:
+                self._work = torch.empty_like(x)
+            _lib.check(lib.stk_lu_solve(self._device_plan(), _lib.stream(), n_loc, ld, _lib.ptr(x),
+                                        _lib.ptr(out), _lib.ptr(self._work)))
+            return out
         host = np.empty((n_loc, M))
         _lib.check(lib.stk_slab_download(_lib.stream(), M, n_loc, ld, _lib.ptr(x),
                                          host.ctypes.data))
@@ -153,6 +185,13 @@ class InvLinOp(SpaceOp):
         _lib.check(lib.stk_slab_upload(_lib.stream(), M, n_loc, ld,
                                        sol.ctypes.data, _lib.ptr(out)))
         return out
+
+    def __del__(self):
+        try:
+            if self._plan is not None:
+                _lib.lib().stk_lu_destroy(self._plan)
+        except Exception:
+            pass
 
 
 class CompositeLinOp(SpaceOp):

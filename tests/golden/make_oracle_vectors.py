@@ -34,8 +34,8 @@ from source.assembly import (prolongation_matrices, space_load,  # noqa: E402
 from source.problem import problem_helper  # noqa: E402
 
 
-def fixture_name(problem, J_time, J_space):
-    return 'o1_pcg_%s_J%d_J%d.npz' % (problem, J_time, J_space)
+def fixture_name(problem, J_time, J_space, precond='multigrid'):
+    return 'o1_pcg_%s_J%d_J%d%s.npz' % (problem, J_time, J_space, '' if precond == 'multigrid' else '_' + precond)
 
 
 def sample_strides(N, M):
@@ -44,14 +44,14 @@ def sample_strides(N, M):
     return max(1, (N - 1) // 8), max(1, M // 199)
 
 
-def build_oracle(problem, J_time, J_space):
+def build_oracle(problem, J_time, J_space, precond='multigrid'):
     mesh, _, tmesh, data, _ = problem_helper(problem, J_space, J_time)
     A_t, L_t, M_t, G_t, u0_t = time_matrices(tmesh)
     M_x, A_x = space_matrices(mesh, scipy_path=True)  # the generator does not load libstk
     mats = dict(A_t=A_t, L_t=L_t, M_t=M_t, G_t=G_t, M_x=M_x, A_x=A_x,
                 P_mats=prolongation_matrices(mesh), u0_t=u0_t,
                 u0_x=space_load(mesh, data['u0']))
-    return HeatEquationOracle(mats, J_time)
+    return HeatEquationOracle(mats, J_time, precond=precond)
 
 
 def lean_operators(o, chunk=8):
@@ -128,6 +128,9 @@ def main():
     ap.add_argument('--problem', default='square')
     ap.add_argument('--threads', type=int, default=1)
     ap.add_argument('--kmax', type=int, default=100000)
+    ap.add_argument('--precond', default='multigrid',
+                    help="'direct': K and the blocks of P as sparse direct inverses (reference "
+                         "heateq_mpi.py:154-157, heateq_mpi_test.py:66-135); fixture ..._direct.npz")
     ap.add_argument('--no-ops', action='store_true',
                     help='skip the S(X), P(X) samples (memory at the largest sizes)')
     ap.add_argument('--ops-only', action='store_true',
@@ -138,13 +141,13 @@ def main():
                          'the first entries of the history only)')
     args = ap.parse_args()
     omg.THREADS = args.threads
-    o = build_oracle(args.problem, args.J_time, args.J_space)
+    o = build_oracle(args.problem, args.J_time, args.J_space, args.precond)
     t0 = time.time()
 
     def cb(w, r, k):
         print('  iteration %d  (%.0f s)' % (k, time.time() - t0), flush=True)
 
-    path = os.path.join(HERE, fixture_name(args.problem, args.J_time, args.J_space))
+    path = os.path.join(HERE, fixture_name(args.problem, args.J_time, args.J_space, args.precond))
     st, sx = sample_strides(o.N, o.M)
     if args.ops_only:
         have = np.load(path)

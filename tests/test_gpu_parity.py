@@ -2844,27 +2844,63 @@ def test_byte_moving_kernels(stk):
 
 
 def test_direct_inverse_above_the_dense_limit(stk):
-    """InvLinOp on a system too large for a dense inverse (reference linop.py:18-26
-    is size-agnostic SuperLU): the host-SuperLU apply through stk_slab_download /
-    stk_slab_upload, against SciPy's solve."""
+    """InvLinOp on systems too large for a dense inverse (reference linop.py:18-26 is
+    size-agnostic SuperLU): SuperLU's factors applied ON THE DEVICE -- permutations
+    and the two level-scheduled triangular solves of stk_lu_solve, all time steps at
+    once -- against SciPy's solve of the same factorisation; the columns of the result
+    do not depend on the slab length (one shape of every row's sum); the host
+    round trip of rounds 1-5 (host_solve) still returns SciPy's doubles.  Square at
+    J_space = 6 (M = 16 129: config 1's size) and the L-shape (M = 12 033); then the
+    whole solve of config 1 with precond='direct' (reference heateq_mpi.py:154-157,
+    heateq_mpi_test.py:66-135) against the oracle's direct trajectory."""
     from scipy.sparse.linalg import splu
     from source.assembly import space_matrices
     from source.linop import InvLinOp
     from source.problem import problem_helper
-    mesh, _, _, _, _ = problem_helper('square', J_space=6, J_time=1)
-    M_x, A_x = space_matrices(mesh)
-    mat = sp.csr_matrix(4.0 * M_x + 0.3 * A_x)
-    assert mat.shape[0] > InvLinOp.MAX_ROWS
-    op = InvLinOp(mat)
-    assert op._dense is None
     rng = np.random.RandomState(11)
-    n_loc = 5
-    X = rng.rand(n_loc, mat.shape[0])
-    dd = _dd(n_loc, mat.shape[0])
-    x = _vec(dd, X)
-    y = op.apply(x.buf, n_loc=n_loc)
-    got = y[:, :n_loc].t().cpu().numpy()
-    want = splu(sp.csc_matrix(mat), options={"SymmetricMode": True},
-                permc_spec="MMD_AT_PLUS_A").solve(X.T.copy()).T
-    assert np.array_equal(got, want)
-    assert not y[:, n_loc:].cpu().numpy().any()
+    for problem, coef in (('square', 4.0), ('square', 0.0), ('lshape', 1.0)):
+        mesh, _, _, _, _ = problem_helper(problem, J_space=6, J_time=1)
+        M_x, A_x = space_matrices(mesh)
+        mat = sp.csr_matrix(coef * M_x + 0.3 * A_x)
+        M = mat.shape[0]
+        assert M > InvLinOp.MAX_ROWS
+        op = InvLinOp(mat)
+        assert op._dense is None
+        lv_l, lv_u, launches = op.levels()
+        assert lv_l > 100 and lv_u > 100 and launches < 0.2 * (lv_l + lv_u)  # the narrow levels share launches
+        lu = splu(sp.csc_matrix(mat), options={"SymmetricMode": True}, permc_spec="MMD_AT_PLUS_A")
+        cols = {}
+        for n_loc in (5, 2, 9, 33):
+            X = rng.rand(n_loc, M)
+            X[0] = np.linspace(0.0, 1.0, M)  # a column every slab length shares
+            x = _vec(_dd(n_loc, M), X)
+            y = op.apply(x.buf, n_loc=n_loc)
+            got = y[:, :n_loc].t().cpu().numpy()
+            want = lu.solve(X.T.copy()).T
+            assert relerr(got, want) < 1e-13, (problem, n_loc, relerr(got, want))
+            assert relerr((mat @ got.T).T, X) < 1e-12
+            assert not y[:, n_loc:].cpu().numpy().any()
+            cols[n_loc] = got[0].copy()
+            y_in_place = x.buf.clone()
+            op.apply(y_in_place, out=y_in_place, n_loc=n_loc)
+            assert torch.equal(y_in_place, y)
+        assert all(np.array_equal(cols[5], c) for c in cols.values())
+        op.host_solve = True
+        y = op.apply(x.buf, n_loc=n_loc)
+        assert np.array_equal(y[:, :n_loc].t().cpu().numpy(), want)
+    import heateq_mpi as hm
+    from source.linalg import PCG
+    g = load_golden('o1_pcg_square_J3_J6_direct')
+    h = hm.HeatEquationMPI(J_space=6, J_time=3, precond='direct')
+    assert h.Kinv_x._dense is None and not h.Kinv_x.host_solve
+    st, sx = (int(v) for v in g['sample_strides'])
+    x = _vec(h.dofs_distr, _bench_vector(h.N, h.M))
+    assert relerr(_np(h.S @ x)[::st, ::sx], g['SX_sample']) < 1e-11
+    assert relerr(_np(h.P @ x)[::st, ::sx], g['PX_sample']) < 1e-11
+    hist = []
+    w, it = PCG(h.WT_S_W, h.P, h.rhs, history=hist)
+    assert it == int(g['iters']), (it, int(g['iters']))
+    _hist_dev('config1_direct_preconditioner', hist, g['hist'], 1e-10)
+    wn = _np(w)
+    assert abs(np.linalg.norm(wn) - g['w_norm']) < 1e-10 * g['w_norm']
+    assert relerr(wn[::st, ::sx], g['w_sample']) < 1e-10

@@ -46,6 +46,17 @@ VARIANTS = [
      {'mg_fuse_restrict': 0}),
     ('arithmetic=accurate', {'arithmetic': 'accurate'}, True, {}),
     ('arithmetic=reference', {'arithmetic': 'reference'}, True, {}),
+    # round 6 (config 5's margin): which of the two regroupings the default still makes owns
+    # what is left -- the regrouped S or the family's ca RAP + cm RMP coarse matrices
+    ('accurate + schur=reference', {'arithmetic': 'accurate', 'schur': 'reference'}, True, {}),
+    ('accurate + family=reference', {'arithmetic': 'accurate', 'family': 'reference'}, True, {}),
+    ('accurate + gs=full rows on every level', {'arithmetic': 'accurate', 'ACCURATE': {'gs_rows': 'full'}}, True, {}),
+    ('accurate + R(Au-f) on every level', {'arithmetic': 'accurate',
+                                           'ACCURATE': {'fuse_restrict_below_finest': False}}, True, {}),
+    ('accurate + every V-cycle in the reference forms', {'arithmetic': 'accurate',
+                                                         'ACCURATE': {'fast_leading_cycles': False}}, True, {}),
+    ('accurate + pre-smoothing of the last V-cycle in the reference form',
+     {'arithmetic': 'accurate', 'ACCURATE': {'fast_parts': 0}}, True, {}),
 ]
 
 
@@ -72,7 +83,13 @@ def main():
                 _lib.check(_lib.lib().stk_set_tuning(key.encode(), value))
             mg.GS_DIAG_FREE = diag_free
             t0 = time.time()
-            h = hm.HeatEquationMPI(J_space=js, J_time=jt, problem=problem, **dict({'arithmetic': 'fast'}, **kw))
+            kw = dict(kw)
+            default = dict(hm.HeatEquationMPI.ACCURATE)
+            hm.HeatEquationMPI.ACCURATE = dict(default, **kw.pop('ACCURATE', {}))
+            try:
+                h = hm.HeatEquationMPI(J_space=js, J_time=jt, problem=problem, **dict({'arithmetic': 'fast'}, **kw))
+            finally:
+                hm.HeatEquationMPI.ACCURATE = default
             mg.GS_DIAG_FREE = True
             setup = time.time() - t0
             hist = []
