@@ -746,6 +746,26 @@ int stk_mg_set_option(stk_mg *plan, const char *key, int32_t value);
 int stk_mg_apply(stk_mg *mg, void *stream, int32_t n_loc, int32_t ld,
                  double ca, const double *cm, const int32_t *kind,
                  const double *f, double *u);
+/* Member matrices for the coarse end of a plan with a second matrix (cm != NULL):
+ * by default time slice t runs on ca * A_l + cm[t] * M_l on every level l, the two
+ * Galerkin chains combined per slice.  The reference builds one hierarchy per
+ * wavelet level from the ASSEMBLED matrix 2^j M + alpha A (heateq_mpi.py:97-98,
+ * 147-153; Galerkin products multigrid.py:142-145): its coarse matrices carry the
+ * rounding of that one chain, and the difference to the combination grows fourfold
+ * per level down (1e-16 at the top, 1e-12 on level 0 of a ten-level hierarchy) --
+ * on the smallest levels it owns most of the gap between the two r.Pr histories
+ * (profiles/r06_history_by_coarse_level_J7_J10.json).  With member matrices the
+ * levels 1 .. stk_mg_coarse_levels(plan) -- the levels of the fused coarse kernel --
+ * read, for slice t, the entries of matrix kind[t] itself (kind as in stk_mg_apply:
+ * the index of the slice's coarse inverse).  One call per level with the n_kinds
+ * matrices of that level as CSR on the host (sorted columns; a NULL indptr for a
+ * kind no slice names); members take effect once every level 1..coarse_levels has
+ * them.  Entries outside the plan's pattern are ignored. */
+int stk_mg_coarse_levels(const stk_mg *plan);
+int stk_mg_set_member_matrices(stk_mg *plan, int32_t level, int32_t n_kinds,
+                               const int32_t *const *indptr_host,
+                               const int32_t *const *indices_host,
+                               const double *const *data_host);
 /* `its` forward (backward = 0) or backward Gauss-Seidel sweeps on one level
  * (exposed for tests; multigrid.py:116-127). */
 int stk_mg_smooth(stk_mg *mg, void *stream, int32_t level, int32_t n_loc,

@@ -539,6 +539,24 @@ extern "C" int stk_mg_create(int32_t n_levels, const stk_mg_level *levels, int32
     return 0;
 }
 
+extern "C" int stk_mg_coarse_levels(const stk_mg *mg)
+{
+    return mg ? stk_coarse_plan_levels(mg->coarse) : 0;
+}
+
+extern "C" int stk_mg_set_member_matrices(stk_mg *mg, int32_t level, int32_t n_kinds,
+                                          const int32_t *const *indptr_host, const int32_t *const *indices_host,
+                                          const double *const *data_host)
+{
+    STK_REQUIRE(mg && indptr_host && indices_host && data_host, "stk_mg_set_member_matrices: null argument");
+    STK_REQUIRE(n_kinds == mg->n_kinds, "stk_mg_set_member_matrices: %d matrices for a plan of %d kinds", n_kinds,
+                mg->n_kinds);
+    STK_REQUIRE(mg->coarse && level >= 1 && level <= mg->Lc,
+                "stk_mg_set_member_matrices: level %d is not inside the fused coarse end (levels 1..%d)", level, mg->Lc);
+    return stk_coarse_plan_set_members(mg->coarse, level, n_kinds, mg->lv[level].n, indptr_host, indices_host,
+                                       data_host);
+}
+
 void stk_mg_adopt(stk_mg *mg, void *const *dev_ptrs, int n)
 {
     mg->adopted.insert(mg->adopted.end(), dev_ptrs, dev_ptrs + n);

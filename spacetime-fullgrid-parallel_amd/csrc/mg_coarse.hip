@@ -46,6 +46,7 @@ struct Job {
     int32_t use_m;     // entries are ca*va + cm[t]*vm (level matrices) or plain va (transfers)
     int32_t diag_free; // GS: slots hold the off-diagonal entries only, u_i = (f_i - s) / a_ii
     int32_t lx, lz, ly;  // the same three vectors as row offsets into the LDS arena (LDS variant)
+    int32_t level;       // level of the hierarchy the job's matrix belongs to
 };
 
 struct CoarseArgs {
@@ -364,6 +365,11 @@ struct UniArgs {
     const double *va, *vm; // [rows][KU]
     const double *dia_a, *dia_m;  // [rows]
     const int32_t *row;    // [rows] output row of every listed row
+    // MEMBER matrices (stk_mg_set_member_matrices): the level matrices of time slice t are
+    // the entries of matrix kind[t] itself instead of ca*va + cm[t]*vm; NULL: none
+    const double *vmem;    // [n_kinds][rows][KU]
+    const double *dmem;    // [n_kinds][rows]
+    size_t mem_rows;       // rows of the uniform arrays
 };
 
 __global__ void repack_uniform_kernel(int n_rows, int K_src, int KU, const int32_t *__restrict__ idx,
@@ -405,6 +411,10 @@ __global__ __launch_bounds__(UBS) void mg_coarse_uniform_kernel(const CoarseArgs
         cm0 = a.cm[t0];
         if (has1) cm1 = a.cm[t0 + 1];
     }
+    // member matrices: this workgroup's time steps read the entries of their own matrix
+    const bool members = HAS_M && m.vmem != nullptr && a.kind != nullptr;
+    const size_t mem0 = members ? (size_t)a.kind[t0] * m.mem_rows : 0;
+    const size_t mem1 = (members && has1) ? (size_t)a.kind[t0 + 1] * m.mem_rows : mem0;
     {
         const int4 *src = reinterpret_cast<const int4 *>(m.jobs);
         int4 *dst = reinterpret_cast<int4 *>(s_jobs);
@@ -437,14 +447,16 @@ __global__ __launch_bounds__(UBS) void mg_coarse_uniform_kernel(const CoarseArgs
             const int4 v = pi[q];
             S.col[4 * q] = v.x, S.col[4 * q + 1] = v.y, S.col[4 * q + 2] = v.z, S.col[4 * q + 3] = v.w;
         }
-        const double2 *pa = reinterpret_cast<const double2 *>(m.va + e0);
+        const bool mem = members && (j.flags & 1);
+        // (member matrices: S.va / S.vm hold the entries for the first / second time step)
+        const double2 *pa = reinterpret_cast<const double2 *>((mem ? m.vmem + mem0 * KU : m.va) + e0);
 #pragma unroll
         for (int q = 0; q < KU / 2; ++q) {
             const double2 v = pa[q];
             S.va[2 * q] = v.x, S.va[2 * q + 1] = v.y;
         }
         if (HAS_M && (j.flags & 1)) {
-            const double2 *pm = reinterpret_cast<const double2 *>(m.vm + e0);
+            const double2 *pm = reinterpret_cast<const double2 *>((mem ? m.vmem + mem1 * KU : m.vm) + e0);
 #pragma unroll
             for (int q = 0; q < KU / 2; ++q) {
                 const double2 v = pm[q];
@@ -452,8 +464,8 @@ __global__ __launch_bounds__(UBS) void mg_coarse_uniform_kernel(const CoarseArgs
             }
         }
         if (j.kind == JOB_GS) {
-            S.da = m.dia_a[row];
-            if (HAS_M && (j.flags & 1)) S.dm = m.dia_m[row];
+            S.da = mem ? m.dmem[mem0 + row] : m.dia_a[row];
+            if (HAS_M && (j.flags & 1)) S.dm = mem ? m.dmem[mem1 + row] : m.dia_m[row];
         }
         S.orow = m.row[row];
     };
@@ -466,6 +478,7 @@ __global__ __launch_bounds__(UBS) void mg_coarse_uniform_kernel(const CoarseArgs
     };
     auto row_update = [&](const CJob &j, const RowRegs &S) {
         const bool use_m = HAS_M && (j.flags & 1);
+        const bool mem = members && (j.flags & 1);
         const bool diag_free = (j.flags & 2) != 0;
         const double ca = (j.flags & 1) ? a.ca : 1.0;
         const V *vx = sv + j.lx;
@@ -483,7 +496,9 @@ __global__ __launch_bounds__(UBS) void mg_coarse_uniform_kernel(const CoarseArgs
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
             double v0 = ca * S.va[u], v1 = v0;
-            if (use_m) {
+            if (mem) {
+                v0 = S.va[u], v1 = S.vm[u];
+            } else if (use_m) {
                 v0 = fma(cm0, S.vm[u], v0);
                 if (PAIR) v1 = fma(cm1, S.vm[u], v1);
             }
@@ -493,7 +508,9 @@ __global__ __launch_bounds__(UBS) void mg_coarse_uniform_kernel(const CoarseArgs
         double o0, o1 = 0.0;
         if (j.kind == JOB_GS) {
             double d0 = ca * S.da, d1 = d0;
-            if (use_m) {
+            if (mem) {
+                d0 = S.da, d1 = S.dm;
+            } else if (use_m) {
                 d0 = fma(cm0, S.dm, d0);
                 if (PAIR) d1 = fma(cm1, S.dm, d1);
             }
@@ -584,6 +601,14 @@ struct stk_coarse_plan {
     CJob *dev_cjobs = nullptr;
     int32_t *u_idx = nullptr, *u_row = nullptr;
     double *u_va = nullptr, *u_vm = nullptr, *u_da = nullptr, *u_dm = nullptr;
+    // member matrices (stk_coarse_plan_set_members)
+    int Lc = 0;
+    uint32_t u_rows = 0;             // rows of the uniform arrays
+    int32_t *u_level = nullptr;      // [u_rows] level of a level-matrix row, -1 for transfers
+    int n_kinds = 0;
+    double *u_vmem = nullptr, *u_dmem = nullptr;  // [n_kinds][u_rows][KU], [n_kinds][u_rows]
+    std::vector<char> member_level;  // [Lc + 1] members given for the level?
+    bool members_ready = false;      // ... for all of 1..Lc
 };
 
 void stk_coarse_plan_free(stk_coarse_plan *p)
@@ -591,15 +616,16 @@ void stk_coarse_plan_free(stk_coarse_plan *p)
     if (!p) return;
     if (p->dev_jobs) (void)hipFree(p->dev_jobs);
     for (void *q : {(void *)p->dev_cjobs, (void *)p->u_idx, (void *)p->u_row, (void *)p->u_va, (void *)p->u_vm,
-                    (void *)p->u_da, (void *)p->u_dm})
+                    (void *)p->u_da, (void *)p->u_dm, (void *)p->u_level, (void *)p->u_vmem, (void *)p->u_dmem})
         if (q) (void)hipFree(q);
     delete p;
 }
 
 static Job rows_job(int kind, const stk_ell_rows &e, int pos_begin, int pos_end, const double *x, const double *z,
-                    double *y, double alpha, double beta, bool level_matrix)
+                    double *y, double alpha, double beta, bool level_matrix, int level)
 {
     Job j;
+    j.level = level;
     j.kind = kind;
     j.K = e.K;
     j.pos_begin = pos_begin;
@@ -662,7 +688,15 @@ static void build_uniform(stk_coarse_plan *p)
         }
     }
     if (total == 0) return;
-    bool ok = hipMalloc((void **)&p->u_idx, sizeof(int32_t) * (size_t)total * KU) == hipSuccess &&
+    // level of every uniform row that belongs to a level matrix (member matrices)
+    std::vector<int32_t> row_level(total, -1);
+    for (size_t n = 0; n < J.size(); ++n)
+        if ((J[n].kind == JOB_SPMM || J[n].kind == JOB_GS) && J[n].use_m)
+            for (int r = 0; r < cj[n].n_rows; ++r) row_level[cj[n].mat_off + r] = J[n].level;
+    bool ok = hipMalloc((void **)&p->u_level, sizeof(int32_t) * (size_t)total) == hipSuccess &&
+              hipMemcpy(p->u_level, row_level.data(), sizeof(int32_t) * (size_t)total, hipMemcpyHostToDevice) ==
+                  hipSuccess &&
+              hipMalloc((void **)&p->u_idx, sizeof(int32_t) * (size_t)total * KU) == hipSuccess &&
               hipMalloc((void **)&p->u_va, sizeof(double) * (size_t)total * KU) == hipSuccess &&
               hipMalloc((void **)&p->u_da, sizeof(double) * (size_t)total) == hipSuccess &&
               hipMalloc((void **)&p->u_row, sizeof(int32_t) * (size_t)total) == hipSuccess &&
@@ -693,6 +727,113 @@ static void build_uniform(stk_coarse_plan *p)
     }
     p->KU = KU;
     p->uni_has_m = has_m;
+    p->u_rows = total;
+}
+
+// Entries of one member matrix (CSR on the device, sorted columns) at the slots of the
+// uniform rows of `level`: slot (row i, column c) gets C[i, c] -- zero where the matrix
+// has no such entry or the slot is padding (both value arrays zero there) -- and the
+// row's diagonal entry goes to dmem.
+__global__ __launch_bounds__(256) void member_fill_kernel(uint32_t rows, int KU, int level,
+                                                          const int32_t *__restrict__ u_level,
+                                                          const int32_t *__restrict__ u_idx,
+                                                          const int32_t *__restrict__ u_row,
+                                                          const double *__restrict__ u_va,
+                                                          const double *__restrict__ u_vm,
+                                                          const int32_t *__restrict__ indptr,
+                                                          const int32_t *__restrict__ indices,
+                                                          const double *__restrict__ data, double *vmem, double *dmem,
+                                                          int32_t *missing)
+{
+    const uint32_t item = blockIdx.x * 256u + threadIdx.x;
+    if (item >= rows * (uint32_t)(KU + 1)) return;
+    const uint32_t r = item / (KU + 1);
+    const int u = (int)(item - r * (KU + 1));
+    if (u_level[r] != level) return;
+    const int i = u_row[r];
+    const bool is_diag = u == KU;
+    const size_t e = (size_t)r * KU + (is_diag ? 0 : u);
+    const bool real = is_diag || u_va[e] != 0.0 || (u_vm != nullptr && u_vm[e] != 0.0);
+    double v = 0.0;
+    if (real) {
+        const int c = is_diag ? i : u_idx[e];
+        int lo = indptr[i], hi = indptr[i + 1];
+        while (lo < hi) {  // first entry with column >= c
+            const int mid = (lo + hi) >> 1;
+            if (indices[mid] < c)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        if (lo < indptr[i + 1] && indices[lo] == c)
+            v = data[lo];
+        else if (is_diag)
+            atomicAdd(missing, 1);  // a member matrix without a diagonal entry
+    }
+    if (is_diag)
+        dmem[r] = v;
+    else
+        vmem[e] = v;
+}
+
+// Levels 1..Lc of the plan take member matrices (0: the plan has no uniform form).
+int stk_coarse_plan_levels(const stk_coarse_plan *p) { return (p && p->KU != 0 && p->uni_has_m) ? p->Lc : 0; }
+
+int stk_coarse_plan_set_members(stk_coarse_plan *p, int level, int n_kinds, int32_t n, const int32_t *const *indptr,
+                                const int32_t *const *indices, const double *const *data)
+{
+    STK_REQUIRE(p && p->KU != 0 && p->uni_has_m, "stk_mg_set_member_matrices: the plan has no uniform coarse form");
+    STK_REQUIRE(level >= 1 && level <= p->Lc, "stk_mg_set_member_matrices: level %d is not one of 1..%d", level, p->Lc);
+    STK_REQUIRE(n_kinds >= 1 && (p->n_kinds == 0 || p->n_kinds == n_kinds),
+                "stk_mg_set_member_matrices: %d matrices, %d at the first call", n_kinds, p->n_kinds);
+    if (p->u_vmem == nullptr) {
+        const size_t nv = (size_t)n_kinds * p->u_rows * p->KU, nd = (size_t)n_kinds * p->u_rows;
+        STK_HIP(hipMalloc((void **)&p->u_vmem, sizeof(double) * nv));
+        STK_HIP(hipMalloc((void **)&p->u_dmem, sizeof(double) * nd));
+        STK_HIP(hipMemset(p->u_vmem, 0, sizeof(double) * nv));
+        STK_HIP(hipMemset(p->u_dmem, 0, sizeof(double) * nd));
+        p->n_kinds = n_kinds;
+        p->member_level.assign(p->Lc + 1, 0);
+    }
+    int32_t *missing = nullptr;
+    STK_HIP(hipMalloc((void **)&missing, sizeof(int32_t)));
+    STK_HIP(hipMemset(missing, 0, sizeof(int32_t)));
+    int rc = 0;
+    for (int k = 0; k < n_kinds && rc == 0; ++k) {
+        if (indptr[k] == nullptr) continue;  // a kind no time slice names (the family's kind 0)
+        const int64_t nnz = indptr[k][n];
+        int32_t *d_ptr = nullptr, *d_idx = nullptr;
+        double *d_val = nullptr;
+        if (hipMalloc((void **)&d_ptr, sizeof(int32_t) * (size_t)(n + 1)) != hipSuccess ||
+            hipMalloc((void **)&d_idx, sizeof(int32_t) * (size_t)std::max<int64_t>(nnz, 1)) != hipSuccess ||
+            hipMalloc((void **)&d_val, sizeof(double) * (size_t)std::max<int64_t>(nnz, 1)) != hipSuccess ||
+            hipMemcpy(d_ptr, indptr[k], sizeof(int32_t) * (size_t)(n + 1), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_idx, indices[k], sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_val, data[k], sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice) != hipSuccess) {
+            stk_set_error("stk_mg_set_member_matrices: device copy of matrix %d failed", k);
+            rc = 1;
+        } else {
+            const uint32_t items = p->u_rows * (uint32_t)(p->KU + 1);
+            hipLaunchKernelGGL(member_fill_kernel, dim3((items + 255) / 256), dim3(256), 0, 0, p->u_rows, p->KU, level,
+                               p->u_level, p->u_idx, p->u_row, p->u_va, p->u_vm, d_ptr, d_idx, d_val,
+                               p->u_vmem + (size_t)k * p->u_rows * p->KU, p->u_dmem + (size_t)k * p->u_rows, missing);
+            if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+                stk_set_error("stk_mg_set_member_matrices: fill kernel failed");
+                rc = 1;
+            }
+        }
+        (void)hipFree(d_ptr), (void)hipFree(d_idx), (void)hipFree(d_val);
+    }
+    int32_t n_missing = 0;
+    if (rc == 0 && hipMemcpy(&n_missing, missing, sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) rc = 1;
+    (void)hipFree(missing);
+    if (rc) return rc;
+    STK_REQUIRE(n_missing == 0, "stk_mg_set_member_matrices: %d rows of level %d lack their diagonal entry", n_missing,
+                level);
+    p->member_level[level] = 1;
+    p->members_ready = true;
+    for (int l = 1; l <= p->Lc; ++l) p->members_ready = p->members_ready && p->member_level[l];
+    return 0;
 }
 
 stk_coarse_plan *stk_coarse_plan_build(const stk_coarse_level *lv, int Lc, int smoothsteps)
@@ -707,13 +848,13 @@ stk_coarse_plan *stk_coarse_plan_build(const stk_coarse_level *lv, int Lc, int s
         for (int it = 0; it < smoothsteps; ++it)
             for (int g = 0; g < ng; ++g)
                 if (pos[g + 1] > pos[g])
-                    J.push_back(rows_job(JOB_GS, e, pos[g], pos[g + 1], L.u, L.f, L.u, 0.0, 0.0, true));
+                    J.push_back(rows_job(JOB_GS, e, pos[g], pos[g + 1], L.u, L.f, L.u, 0.0, 0.0, true, j));
     };
     for (int j = Lc; j >= 1; --j) {
         const stk_coarse_level &L = lv[j], &C = lv[j - 1];
         smooth(j, false);
-        J.push_back(rows_job(JOB_SPMM, L.a, 0, L.a.n_pos, L.u, L.f, L.res, 1.0, -1.0, true));   // r = A u - f
-        J.push_back(rows_job(JOB_SPMM, L.r, 0, L.r.n_pos, L.res, nullptr, C.f, 1.0, 0.0, false));  // d = R r
+        J.push_back(rows_job(JOB_SPMM, L.a, 0, L.a.n_pos, L.u, L.f, L.res, 1.0, -1.0, true, j));   // r = A u - f
+        J.push_back(rows_job(JOB_SPMM, L.r, 0, L.r.n_pos, L.res, nullptr, C.f, 1.0, 0.0, false, j));  // d = R r
         Job z;
         z.kind = JOB_ZERO;
         z.K = 0;
@@ -726,6 +867,7 @@ stk_coarse_plan *stk_coarse_plan_build(const stk_coarse_level *lv, int Lc, int s
         z.alpha = z.beta = 0.0;
         z.use_m = z.diag_free = 0;
         z.lx = z.lz = z.ly = -1;
+        z.level = j - 1;
         if (j - 1 >= 1) J.push_back(z);  // level 0 is overwritten by the exact solve
     }
     {
@@ -742,11 +884,12 @@ stk_coarse_plan *stk_coarse_plan_build(const stk_coarse_level *lv, int Lc, int s
         c.alpha = c.beta = 0.0;
         c.use_m = c.diag_free = 0;
         c.lx = c.lz = c.ly = -1;
+        c.level = 0;
         J.push_back(c);
     }
     for (int j = 1; j <= Lc; ++j) {
         const stk_coarse_level &L = lv[j], &C = lv[j - 1];
-        J.push_back(rows_job(JOB_SPMM, L.p, 0, L.p.n_pos, C.u, L.u, L.u, -1.0, 1.0, false));  // u -= P u_c
+        J.push_back(rows_job(JOB_SPMM, L.p, 0, L.p.n_pos, C.u, L.u, L.u, -1.0, 1.0, false, j));  // u -= P u_c
         smooth(j, true);
     }
     // LDS arena offsets of every global workspace the jobs name
@@ -776,6 +919,7 @@ stk_coarse_plan *stk_coarse_plan_build(const stk_coarse_level *lv, int Lc, int s
         p->top_u = lv[Lc].u;
     }
     p->n_jobs = (int)J.size();
+    p->Lc = Lc;
     if (hipMalloc((void **)&p->dev_jobs, sizeof(Job) * J.size()) != hipSuccess ||
         hipMemcpy(p->dev_jobs, J.data(), sizeof(Job) * J.size(), hipMemcpyHostToDevice) != hipSuccess) {
         stk_coarse_plan_free(p);
@@ -883,6 +1027,9 @@ int stk_coarse_plan_run(const stk_coarse_plan *p, hipStream_t st, int n_loc, int
             m.dia_a = p->u_da;
             m.dia_m = p->u_dm;
             m.row = p->u_row;
+            m.vmem = p->members_ready ? p->u_vmem : nullptr;
+            m.dmem = p->members_ready ? p->u_dmem : nullptr;
+            m.mem_rows = p->u_rows;
             const size_t lds_u = lds + (pair ? 0 : sizeof(double) * (p->lds_rows & 1)) + sizeof(CJob) * (size_t)p->n_jobs;
             if (lds_u <= 160 * 1024 - 512) return launch_uniform(p->KU, cm != nullptr, pair, grid, lds_u, st, a, m);
         }

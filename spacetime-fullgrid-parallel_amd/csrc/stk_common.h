@@ -79,6 +79,9 @@ struct stk_coarse_level {
 stk_coarse_plan *stk_coarse_plan_build(const stk_coarse_level *lv, int Lc, int smoothsteps);
 void stk_coarse_plan_free(stk_coarse_plan *p);
 bool stk_coarse_plan_in_lds(const stk_coarse_plan *p);
+int stk_coarse_plan_levels(const stk_coarse_plan *p);
+int stk_coarse_plan_set_members(stk_coarse_plan *p, int level, int n_kinds, int32_t n, const int32_t *const *indptr,
+                                const int32_t *const *indices, const double *const *data);
 int stk_coarse_plan_run(const stk_coarse_plan *p, hipStream_t st, int n_loc, int ld, double ca, const double *cm,
                         const int32_t *kind, const double *coarse_inv);
 

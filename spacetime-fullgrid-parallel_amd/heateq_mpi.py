@@ -343,7 +343,8 @@ class HeatEquationMPI:
                 members = pool.submit(
                     on_dev(MultiGridFamily), self.A_x, self.M_x, hierarchy, ca=alpha,
                     cms=[2**j for j in range(self.J_time + 1)],
-                    smoothsteps=smoothsteps, vcycles=vcycles, gs_rows=gs_rows, band_merge=merge)
+                    smoothsteps=smoothsteps, vcycles=vcycles, gs_rows=gs_rows, band_merge=merge,
+                    exact_coarse=(arithmetic == 'accurate' and self.ACCURATE['member_coarse_matrices']))
                 self.Kinv_x, self.C_family = kinv.result(), members.result()
             if arithmetic == 'accurate':
                 for plans in (self.Kinv_x._dev, self.C_family._dev):
@@ -418,7 +419,7 @@ class HeatEquationMPI:
     # the Gauss-Seidel copies, up to which level the restricted residual stays fused,
     # how many leading V-cycles keep the fast forms, and which parts of the last one.
     ACCURATE = {'gs_rows': 'owned', 'fuse_restrict_below_finest': True, 'fast_leading_cycles': True,
-                'fast_parts': 1}
+                'fast_parts': 1, 'member_coarse_matrices': True}
 
     @classmethod
     def _accurate_options(cls, plans, J, vcycles):

@@ -142,6 +142,8 @@ _PROTOTYPES = {
         c_p, c_i64, OPERATOR_FN, c_p, OPERATOR_FN, c_p, ALLREDUCE_FN, c_p, c_p,
         c_i32, c_f64, c_f64, c_p, c_p, c_p, c_p, c_p, c_p, c_p
     ]),
+    'stk_mg_coarse_levels': (ctypes.c_int, [c_p]),
+    'stk_mg_set_member_matrices': (ctypes.c_int, [c_p, c_i32, c_i32, c_p, c_p, c_p]),
     'stk_lu_create': (ctypes.c_int, [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.POINTER(c_p)]),
     'stk_lu_destroy': (ctypes.c_int, [c_p]),
     'stk_lu_info': (ctypes.c_int, [c_p, c_p, c_p, c_p]),

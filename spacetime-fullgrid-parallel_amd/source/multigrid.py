@@ -157,6 +157,11 @@ def _drop_roundoff(mat, rel=1e-14):
     return mat
 
 
+# Experiments only: callable(fine matrix, Galerkin chain coarse -> fine) -> chain, applied to
+# every chain a plan builds (which coarse levels own a deviation: replace them and look).
+CHAIN_HOOK = None
+
+
 def galerkin_product(R, A, P, cache=None):
     """R A P (reference multigrid.py:142-145) as a SciPy CSR matrix with sorted
     rows.  On a GPU the product is formed by libstk (stk_csr_galerkin: one coarse
@@ -211,6 +216,94 @@ def galerkin_product(R, A, P, cache=None):
                         shape=(nc, A.shape[1] if P is None else P.shape[1]))
     out.has_sorted_indices = True
     return out
+
+
+def _dev_csr(m):
+    return (_lib.to_dev(np.asarray(m.indptr, dtype=np.int32)), _lib.to_dev(np.asarray(m.indices, dtype=np.int32)),
+            _lib.to_dev(np.asarray(m.data, dtype=np.float64)))
+
+
+def member_chains(hierarchy, mat_a, mat_m, ca, cms, keep_rows=8192):
+    """Galerkin chains (reference multigrid.py:142-145) of the ASSEMBLED matrices
+    cm_k M + ca A, k = 0 .. K-1 -- what the reference builds one MultiGrid per wavelet
+    level from (heateq_mpi.py:97-98, 147-153) -- formed on the device, values only:
+    the fine matrices differ in their values alone (one union pattern), every product
+    R C P is stk_csr_galerkin's (SciPy's order and roundings: bit for bit `R @ C @ P`,
+    as galerkin_product), the rounding noise is dropped as _drop_roundoff does, and
+    nothing but the small levels ever reaches the host.
+
+    A preconditioner family (MultiGridFamily) combines TWO chains per time slice,
+    ca (R A P) + cm (R M P).  In exact arithmetic that is the chain above; in floating
+    point the assembled chain carries ITS roundings from level to level, and what
+    separates the two grows fourfold per level down -- 2e-16 relative on the first
+    coarse level, 1e-12 on level 0 of a ten-level hierarchy (a rounding residue that is
+    the same in every stencil acts like a multiple of the mass matrix, which scales
+    with h^2).  On the smallest levels that difference owns most of the gap between the
+    family's r.Pr history and the reference's
+    (profiles/r06_history_by_coarse_level_J7_J10.json), so the family hands the
+    reference's matrices to the coarse end of its plan (stk_mg_set_member_matrices).
+
+    Returns chains[k][level] = SciPy CSR for the levels of at most `keep_rows` rows,
+    or None where a product has rows longer than the kernel holds (the caller keeps
+    the combination)."""
+    mat_a, mat_m = sp.csr_matrix(mat_a), sp.csr_matrix(mat_m)
+    scaled = sp.csr_matrix(float(ca) * mat_a)  # fl(ca a), as in `cm * M + ca * A`
+    indptr, indices, (va, vm) = union_pattern([scaled, mat_m])
+    J = hierarchy.J
+    d_ptr, d_idx = _lib.to_dev(np.asarray(indptr, dtype=np.int32)), _lib.to_dev(np.asarray(indices, dtype=np.int32))
+    d_va, d_vm = _lib.to_dev(np.asarray(va, dtype=np.float64)), _lib.to_dev(np.asarray(vm, dtype=np.float64))
+    dev = d_ptr.device
+    cap = 16
+    lanes = torch.arange(cap, device=dev, dtype=torch.int32)[None, :]
+
+    def host_csr(ptr, idx, data, shape):
+        out = sp.csr_matrix((data.cpu().numpy(), idx.cpu().numpy(), ptr.cpu().numpy()), shape=shape)
+        out.has_sorted_indices = True
+        return out
+
+    chains = []
+    for cm in cms:
+        # SciPy: fl(fl(cm m) + fl(ca a)) on the union pattern (entries of one matrix alone: copied)
+        data = d_vm * float(cm) + d_va
+        ptr, idx, n_cols = d_ptr, d_idx, mat_a.shape[1]
+        kept = {}
+        for j in reversed(range(J)):
+            R, P = sp.csr_matrix(hierarchy.R_mats[j]), sp.csr_matrix(hierarchy.P_mats[j])
+            nc = R.shape[0]
+            if nc < 64:  # galerkin_product forms these on the host: so here
+                C = host_csr(ptr, idx, data, (R.shape[1], n_cols))
+                for jj in reversed(range(j + 1)):
+                    Rj, Pj = sp.csr_matrix(hierarchy.R_mats[jj]), sp.csr_matrix(hierarchy.P_mats[jj])
+                    C = sp.csr_matrix(Rj @ C @ Pj)
+                    C.sort_indices()
+                    kept[jj] = C = _drop_roundoff(C)
+                break
+            held = _shared(hierarchy, ('galerkin_rp', j), dict)
+            with held.setdefault('lock', threading.Lock()):
+                for key, m in (('R', R), ('P', P)):
+                    if key not in held:
+                        held[key] = _dev_csr(m)
+            dR, dP = held['R'], held['P']
+            counts = torch.empty(nc, dtype=torch.int32, device=dev)
+            oidx = torch.empty((nc, cap), dtype=torch.int32, device=dev)
+            oval = torch.empty((nc, cap), dtype=torch.float64, device=dev)
+            overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+            _lib.check(_lib.lib().stk_csr_galerkin(
+                _lib.stream(), nc, *[_lib.ptr(t) for t in dR + (ptr, idx, data) + dP], cap, _lib.ptr(counts),
+                _lib.ptr(oidx), _lib.ptr(oval), _lib.ptr(overflow)))
+            if int(overflow.item()) != 0:
+                return None
+            valid = lanes < counts[:, None]
+            mag = oval.abs()
+            biggest = torch.where(valid, mag, torch.zeros_like(mag)).max()
+            keep = valid & (mag >= 1e-14 * biggest) & (oval != 0.0)  # _drop_roundoff + eliminate_zeros
+            ptr = torch.zeros(nc + 1, dtype=torch.int32, device=dev)
+            ptr[1:] = torch.cumsum(keep.sum(dim=1), dim=0).to(torch.int32)
+            idx, data, n_cols = oidx[keep].contiguous(), oval[keep].contiguous(), P.shape[1]
+            if nc <= keep_rows:
+                kept[j] = host_csr(ptr, idx, data, (nc, n_cols))
+        chains.append(kept)
+    return chains
 
 
 def _depth_on_device(n, d_indptr, d_indices, backward):
@@ -345,7 +438,7 @@ GS_ALT_COPIES = False
 class _DeviceHierarchy:
     """Everything one libstk multigrid plan needs, resident on the device."""
     def __init__(self, mat_a, mat_m, hierarchy, smoothsteps, vcycles,
-                 coarse_mats, gs_rows=None, band_merge=None):
+                 coarse_mats, gs_rows=None, band_merge=None, member_mats=None):
         # row form of the Gauss-Seidel copies: 'free' (diagonal-free on every level),
         # 'full' (the reference's form on every level), 'owned' (the reference's form
         # on the finest level, which also gets the diagonal-free copies as its
@@ -371,6 +464,8 @@ class _DeviceHierarchy:
                     R, P = hierarchy.R_mats[j], hierarchy.P_mats[j]
                     held = _shared(hierarchy, ('galerkin_rp', j), dict)  # device copies of R, P
                     mats.insert(0, _drop_roundoff(galerkin_product(R, mats[0], P, held)))
+                if CHAIN_HOOK is not None:  # experiments: tools/history_by_coarse_level.py
+                    mats = CHAIN_HOOK(fine, mats)
                 return mats
 
             return list(_shared(hierarchy, ('galerkin', _mat_key(fine)), make))
@@ -392,6 +487,24 @@ class _DeviceHierarchy:
                         for m in coarse_mats(A[0], Mm[0] if Mm else None)])
         self.coarse_inv = _lib.to_dev(np.ascontiguousarray(inv))
         self.n_kinds = inv.shape[0]
+        # member_mats[k][level]: the level matrices of member k itself (member_chains) for
+        # the coarse end of the plan; coarse-inverse kind k + 1 names member k
+        self.member_mats = member_mats
+        self.member_levels = 0  # levels 1 .. member_levels of the plans run on them
+        if member_mats is not None:
+            # entries outside the plan's pattern would be lost: keep the combination then
+            def pattern(m):
+                m = sp.csr_matrix(m)
+                return sp.csr_matrix((np.ones(m.nnz), m.indices, m.indptr), shape=m.shape)
+
+            for kept in member_mats:
+                for level, C in kept.items():
+                    if 1 <= level < self.J:
+                        have = pattern(abs(A[level]) + abs(Mm[level]))
+                        outside = pattern(C) - pattern(C).multiply(have)
+                        outside.eliminate_zeros()
+                        if outside.nnz:
+                            self.member_mats = None
         self.plan = None
         self.plan_ld = 0
         self.twin = None  # a second plan on the same matrices with workspaces of its own
@@ -581,7 +694,29 @@ class _DeviceHierarchy:
             ctypes.byref(handle)))
         for key, value in self.options.items():
             _lib.check(_lib.lib().stk_mg_set_option(handle, key.encode(), int(value)))
+        if self.member_mats is not None:
+            self._hand_over_members(handle)
         return handle
+
+    def _hand_over_members(self, handle):
+        lib = _lib.lib()
+        Lc = int(lib.stk_mg_coarse_levels(handle))
+        if Lc < 1 or not all(l in kept for kept in self.member_mats for l in range(1, Lc + 1)):
+            return
+        n_kinds = self.n_kinds
+        assert n_kinds == len(self.member_mats) + 1  # kind 0: A alone
+        for level in range(1, Lc + 1):
+            ptrs = [(ctypes.c_void_p * n_kinds)() for _ in range(3)]
+            keep = []
+            for k, kept in enumerate(self.member_mats):
+                C = kept[level]
+                arrs = (np.ascontiguousarray(C.indptr, dtype=np.int32), np.ascontiguousarray(C.indices, dtype=np.int32),
+                        np.ascontiguousarray(C.data, dtype=np.float64))
+                keep.append(arrs)
+                for which in range(3):
+                    ptrs[which][k + 1] = arrs[which].ctypes.data
+            _lib.check(lib.stk_mg_set_member_matrices(handle, level, n_kinds, *ptrs))
+        self.member_levels = Lc
 
     def ensure_plan(self, ld, twin=False):
         """The plan for slabs up to `ld` columns.  twin=True: a second plan on the
@@ -766,17 +901,31 @@ class MultiGridFamily:
     BlockDiagMPI recognises members of one family and runs all time slices in
     one batched V-cycle."""
     def __init__(self, mat_a, mat_m, hierarchy, ca, cms, smoothsteps=2,
-                 vcycles=1, fuse_restrict=None, gs_rows=None, band_merge=None):
+                 vcycles=1, fuse_restrict=None, gs_rows=None, band_merge=None, exact_coarse=False):
+        """exact_coarse: the coarse end of the plan (the levels of the fused coarse
+        kernel, and the exact solve on level 0) runs on the Galerkin chain of every
+        member's ASSEMBLED matrix cm_k M + ca A, as the reference's one-hierarchy-per-
+        wavelet-level does, instead of the combination ca (R A P) + cm_k (R M P) of the
+        two shared chains: see member_chains."""
         self.ca = float(ca)
         self.cms = [float(c) for c in cms]
         self.hierarchy = hierarchy
+        chains = None
+        if exact_coarse and hierarchy.J >= 1 and _lib.compute_device().type == 'cuda':
+            chains = member_chains(hierarchy, mat_a, mat_m, self.ca, self.cms)
+            if chains is not None and not all(0 in kept for kept in chains):
+                chains = None
+        self.member_chains = chains
 
         def coarse(a0, m0):
             # kind 0: A alone (unused by members); kind 1+k: member k
+            if chains is not None:
+                return [a0] + [kept[0] for kept in chains]
             return [a0] + [self.ca * a0 + c * m0 for c in self.cms]
 
         self._dev = _DeviceHierarchy(mat_a, mat_m, hierarchy, smoothsteps,
-                                     vcycles, coarse, gs_rows=gs_rows, band_merge=band_merge)
+                                     vcycles, coarse, gs_rows=gs_rows, band_merge=band_merge,
+                                     member_mats=chains)
         if fuse_restrict is not None:
             self._dev.set_option('fuse_restrict', bool(fuse_restrict))
         self.shape = self._dev.shape

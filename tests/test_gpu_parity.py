@@ -2264,6 +2264,102 @@ def test_strip_wise_sweeps_are_exact(stk):
             assert np.array_equal(Pv, res[0][0]) and np.array_equal(Sv, res[0][1])
 
 
+def test_band_merge_does_not_change_a_bit(stk):
+    """Bands of several mesh rows for the strip-wise sweeps (MultiGridFamily(band_merge),
+    tuning key mg_band_merge for the C planner): coarser bands keep "coupled
+    rows at most one band apart", so the V-cycle is the same to the bit for merge = 1, 6
+    and 64, at two slab lengths, from the Python planner and from the C planner -- and
+    the fine levels still run strip by strip (launch counter) unless the merge leaves
+    fewer than two bands."""
+    from source.assembly import space_matrices
+    from source.multigrid import MeshHierarchy, MultiGridFamily
+    from source.problem import problem_helper
+    mesh = problem_helper('square', J_space=6, J_time=2)[0]
+    M_x, A_x = space_matrices(mesh)
+    hier = MeshHierarchy(mesh)
+    cms = [1.0, 2.0, 4.0, 8.0]
+    rng = np.random.RandomState(21)
+    lib = stk.lib()
+    try:
+        stk.check(lib.stk_set_tuning(b'mg_strip_mb', 1))  # several strips on a 16 129-row level
+        stk.check(lib.stk_set_tuning(b'mg_strip_width', 0))
+        for n_loc in (9, 34):
+            X = rng.rand(A_x.shape[0], n_loc)
+            x = torch.zeros((A_x.shape[0], n_loc + (n_loc & 1)), dtype=torch.float64, device='cuda')
+            x[:, :n_loc] = torch.from_numpy(X).cuda()
+            members = [k % len(cms) for k in range(n_loc)]
+            out = {}
+            for merge in (1, 6, 64):
+                fam = MultiGridFamily(A_x, M_x, hier, ca=0.3, cms=cms, smoothsteps=3, vcycles=2, band_merge=merge)
+                cm, kind = fam.slice_tables(members)
+                stk.check(lib.stk_set_tuning(b'mg_strips_used', 0))
+                out[merge] = fam.apply(x, n_loc=n_loc, cm=cm, kind=kind).clone()
+                if merge <= 6:  # 127 mesh rows: 127 / 21 bands, strips of several bands
+                    assert lib.stk_set_tuning(b'mg_strips_used', 6) == 0, (merge, lib.stk_last_error().decode())
+            assert torch.equal(out[1], out[6]) and torch.equal(out[1], out[64]), n_loc
+    finally:
+        stk.check(lib.stk_set_tuning(b'mg_strip_mb', 250))
+        stk.check(lib.stk_set_tuning(b'mg_strip_width', 2))
+
+
+def test_family_members_run_on_their_own_coarse_matrices(stk):
+    """MultiGridFamily(exact_coarse=True): the coarse end of the batched V-cycle runs, for
+    every time slice, on the Galerkin chain of THAT slice's assembled matrix cm M + ca A
+    -- what the reference builds one MultiGrid per wavelet level from
+    (heateq_mpi.py:97-98, 147-153) -- instead of the combination of the two shared
+    chains (member_chains, stk_mg_set_member_matrices).  The chains formed on the device
+    are bit for bit SciPy's R @ C @ P chains (after the noise drop); with them a member's
+    V-cycle agrees with MultiGrid(assembled matrix) far better than with the combination
+    wherever the hierarchy is deep enough for the difference to show (it grows fourfold
+    per level down)."""
+    from source.assembly import space_matrices
+    from source.multigrid import (MeshHierarchy, MultiGrid, MultiGridFamily, _drop_roundoff,
+                                  member_chains)
+    from source.problem import problem_helper
+    rng = np.random.RandomState(4)
+    for problem, J_space in (('square', 5), ('lshape', 5), ('square', 7)):
+        mesh = problem_helper(problem, J_space=J_space, J_time=2)[0]
+        M_x, A_x = space_matrices(mesh)
+        hier = MeshHierarchy(mesh)
+        ca, cms = 0.3, [1.0, 8.0, 128.0]
+        chains = member_chains(hier, A_x, M_x, ca, cms)
+        assert chains is not None
+        for k, cm in enumerate(cms):
+            C = sp.csr_matrix(cm * M_x + ca * A_x)
+            for j in reversed(range(hier.J)):
+                C = sp.csr_matrix(hier.R_mats[j] @ C @ hier.P_mats[j])
+                C.sort_indices()
+                C = _drop_roundoff(C)
+                if j in chains[k]:
+                    got = chains[k][j]
+                    assert np.array_equal(got.indptr, C.indptr) and np.array_equal(got.indices, C.indices)
+                    assert np.array_equal(got.data, C.data), (problem, k, j)
+            assert 0 in chains[k] and 1 in chains[k]
+        n = A_x.shape[0]
+        x = torch.zeros((n, 6), dtype=torch.float64, device='cuda')
+        x[:, :5] = torch.from_numpy(rng.rand(n, 5)).cuda()
+        devs = {}
+        for exact in (False, True):
+            fam = MultiGridFamily(A_x, M_x, hier, ca=ca, cms=cms, smoothsteps=3, vcycles=2,
+                                  fuse_restrict=False, gs_rows='full', exact_coarse=exact)
+            worst = 0.0
+            for k, cm in enumerate(cms):
+                ref = MultiGrid(sp.csr_matrix(cm * M_x + ca * A_x), hier, smoothsteps=3, vcycles=2,
+                                fuse_restrict=False, gs_rows='full')
+                y = fam.members[k].apply(x, n_loc=5)
+                yr = ref.apply(x, n_loc=5)
+                worst = max(worst, float((y - yr).abs().max() / yr.abs().max()))
+            assert fam._dev.member_levels == (min(hier.J - 1, 5) if exact else 0), fam._dev.member_levels
+            devs[exact] = worst
+        # every coarse level inside the fused kernel: nothing but the members' own matrices
+        # is left below the finest level, which is the assembled matrix in both
+        if hier.J - 1 <= 5:
+            assert devs[True] == 0.0, (problem, J_space, devs)
+        else:
+            assert devs[True] < 0.3 * devs[False], (problem, J_space, devs)
+        _scalar_dev('family_member_vs_assembled_%s_J%d' % (problem, J_space), devs[True], 1e-12)
+
+
 def test_coupling_bands_are_verified(stk):
     """The bands the strip-wise smoothing relies on (coupled rows at most one
     band apart) are checked on the pattern: a matrix with a long-range entry

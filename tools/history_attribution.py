@@ -64,10 +64,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--configs', default='square:3:6,square:5:8,square:6:9,lshape:5:8')
     ap.add_argument('--variants', default='')
+    ap.add_argument('--accurate-knobs', action='store_true',
+                    help="the default arithmetic, the reference arithmetic and the default with one more "
+                         "of the reference's forms each (round 6: who owns config 5's 9.6e-11)")
     ap.add_argument('--out', default=os.path.join(REPO, 'gpurun_out', 'history_attribution.json'))
     args = ap.parse_args()
     import torch
     want = set(filter(None, args.variants.split(',')))
+    if args.accurate_knobs:
+        want = {v[0] for v in VARIANTS if v[0].startswith('accurate') or v[0] in ('arithmetic=accurate',
+                                                                                  'arithmetic=reference')}
     out = {}
     for spec in args.configs.split(','):
         problem, jt, js = spec.split(':')
