@@ -816,7 +816,11 @@ typedef struct {
  * inverse: the two planners' V-cycles are then equal bit for bit, not to 1e-13.
  * fn(n, a, inv, user): a and inv are n x n, row-major, HOST; returns 0 on success.
  * fn = NULL restores the built-in inverse.  Called on the thread that calls
- * stk_mg_create_from_csr. */
+ * stk_mg_create_from_csr.  The hook and the tuning key "mg_band_merge" are
+ * process-wide; a plan construction reads both once, under a mutex, when it starts,
+ * so a setter on another thread takes effect for constructions that start later and
+ * never half way through one.  A caller that wants a hook for ONE construction while
+ * other threads build plans must serialise those constructions itself. */
 typedef int (*stk_dense_inverse_fn)(int32_t n, const double *a, double *inv,
                                     void *user);
 int stk_mg_set_coarse_inverse(stk_dense_inverse_fn fn, void *user);

@@ -63,6 +63,7 @@
 //    x), so a term costs the traffic of the time steps it really reads.  The sums are
 //    accumulated in the order of the one-input form, term by term.
 #include <cstring>
+#include <vector>
 
 #include "stk_common.h"
 
@@ -646,6 +647,7 @@ int g_pack_block = 512;                   // threads per workgroup: 512 or 256
 int g_pack_multi_lanes = 1;               // inputs per term: 0 = the terms take turns in one lane (round 4)
 int g_pack_multi_wg_per_cu = 0;           // inputs per term: workgroups per CU (0: as the one-input form)
 int g_pack_multi_r = 0;                   // inputs per term: cap on the slot rows of a group (0: none)
+int g_pack_check_steps = 0;               // inputs per term: verify the stated time steps against the factors (tests)
 unsigned long long *g_pack_diag = nullptr;  // set: the next headline-shape launch runs the DIAG instantiation
 
 template <int NT, int K, bool GHOST, int BS, int RP>
@@ -816,6 +818,10 @@ int stk_kron_pack_set_tuning(const char *key, int32_t value)
         g_pack_multi_lanes = value;
         return 0;
     }
+    if (std::strcmp(key, "pack_check_steps") == 0) {
+        g_pack_check_steps = value;
+        return 0;
+    }
     if (std::strcmp(key, "pack_block") == 0) {
         g_pack_block = value == 256 ? 256 : 512;
         return 0;
@@ -906,6 +912,31 @@ extern "C" int stk_kron_pack_apply_multi_steps(void *stream, const stk_pack_patt
     }
     STK_REQUIRE(((uintptr_t)y & 15) == 0, "stk_kron_pack_apply_multi: y must be 16-byte aligned");
     hipStream_t st = stk_stream(stream);
+    if (g_pack_check_steps && t_begin_host) {
+        // Tuning key "pack_check_steps" (tests, debugging): a stated range that omits a
+        // time step the factor reads would silently drop its contribution (the lanes of
+        // that step are never launched).  Column s of a factor is read through sub[s + 1],
+        // dia[s] and super[s - 1]: fetch the three diagonals and look (a stream
+        // synchronisation per call: not for production runs).
+        std::vector<double> tri(3 * (size_t)n_loc);
+        for (int k = 0; k < n_terms; ++k) {
+            if (!t[k].tri) {
+                STK_REQUIRE(t_begin_host[k] == 0 && t_end_host[k] == n_loc,
+                            "stk_kron_pack_apply_multi_steps: term %d has an identity time factor but states the "
+                            "steps [%d, %d) of %d", k, t_begin_host[k], t_end_host[k], n_loc);
+                continue;
+            }
+            STK_HIP(hipMemcpyAsync(tri.data(), t[k].tri, sizeof(double) * tri.size(), hipMemcpyDeviceToHost, st));
+            STK_HIP(hipStreamSynchronize(st));
+            for (int s_ = 0; s_ < n_loc; ++s_) {
+                const bool read = tri[n_loc + s_] != 0.0 || (s_ + 1 < n_loc && tri[s_ + 1] != 0.0) ||
+                                  (s_ >= 1 && tri[2 * (size_t)n_loc + s_ - 1] != 0.0);
+                STK_REQUIRE(!read || (s_ >= t_begin_host[k] && s_ < t_end_host[k]),
+                            "stk_kron_pack_apply_multi_steps: term %d reads time step %d, outside the stated [%d, %d)",
+                            k, s_, t_begin_host[k], t_end_host[k]);
+            }
+        }
+    }
     // A lane group per term pays where the slab is long or does not fit the Infinity
     // Cache; on short slabs of small problems the turn-taking lanes are level or ahead in
     // a loop of launches and level inside S (profiles/r05_multi_lanes_vs_turns.log).

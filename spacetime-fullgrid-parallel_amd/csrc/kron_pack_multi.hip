@@ -364,7 +364,11 @@ int dispatch(hipStream_t st, const stk_pack_pattern *pat, int32_t n_loc, int32_t
     }
     a.lane0[NT] = lanes;
     a.W = lanes;
-    if (a.W > BS) return -1;  // too many lanes for one slot row: the caller takes the turn form
+    // fewer than two slot rows per workgroup (more than 256 lanes per slot row: three
+    // full-range terms from about 171 time steps on): up to half the lanes of the
+    // workgroup would idle behind a barrier pair per slot row -- the caller takes the
+    // turn form (nothing was ever measured in that regime)
+    if (BS / a.W < 2) return -1;
     return pat->rows_per_unit == 2 ? launch<NT, 2>(st, a, pat->K) : launch<NT, 1>(st, a, pat->K);
 }
 
@@ -388,7 +392,7 @@ int stk_kron_pack_terms_set_tuning(const char *key, int32_t value)
 }
 
 // Shared with kron_pack.hip (stk_kron_pack_apply_multi): arguments already checked there.
-// Returns -1 when a slot row would need more than 512 lanes.
+// Returns -1 when fewer than two slot rows would fit a workgroup (more than 256 lanes per slot row).
 int stk_kron_pack_terms_launch(hipStream_t st, const stk_pack_pattern *pat, int32_t n_loc, int32_t ld, int32_t n_terms,
                                const stk_kron_pack_term *t, const double *const *xs, const int32_t *t_begin,
                                const int32_t *t_end, double beta, double *y)

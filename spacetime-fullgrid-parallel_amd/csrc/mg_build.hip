@@ -440,14 +440,31 @@ bool ell_rows(Builder &B, const Union &u, const std::vector<int32_t> &order, boo
 
 Union union_of(const Csr &m) { return make_union(m, nullptr); }
 
-// The caller's own dense inverse (stk_mg_set_coarse_inverse), or none.
+// The caller's own dense inverse (stk_mg_set_coarse_inverse), or none; the mesh rows per
+// band (tuning key "mg_band_merge").  Both are process-wide settings that a plan
+// construction reads ONCE, under the mutex, when it starts (PlannerSettings): a setter
+// running on another thread while plans are being built (this repository builds K's and
+// the family's plan side by side) cannot change a construction half way.
 stk_dense_inverse_fn g_inverse_fn = nullptr;
 void *g_inverse_user = nullptr;
+std::mutex g_planner_mutex;
+
+struct PlannerSettings {
+    stk_dense_inverse_fn inverse_fn;
+    void *inverse_user;
+    int band_merge;
+};
+
+PlannerSettings planner_settings()
+{
+    std::lock_guard<std::mutex> lock(g_planner_mutex);
+    return PlannerSettings{g_inverse_fn, g_inverse_user, g_mg_band_merge};
+}
 
 // dense inverse by Gauss-Jordan elimination with partial pivoting (level 0 is tiny)
-bool dense_inverse(std::vector<double> a, int n, double *out)
+bool dense_inverse(std::vector<double> a, int n, double *out, const PlannerSettings &set)
 {
-    if (g_inverse_fn != nullptr) return g_inverse_fn(n, a.data(), out, g_inverse_user) == 0;
+    if (set.inverse_fn != nullptr) return set.inverse_fn(n, a.data(), out, set.inverse_user) == 0;
     std::vector<double> inv((size_t)n * n, 0.0);
     for (int i = 0; i < n; ++i) inv[(size_t)i * n + i] = 1.0;
     for (int c = 0; c < n; ++c) {
@@ -483,6 +500,7 @@ bool dense_inverse(std::vector<double> a, int n, double *out)
 
 extern "C" int stk_mg_set_coarse_inverse(stk_dense_inverse_fn fn, void *user)
 {
+    std::lock_guard<std::mutex> lock(g_planner_mutex);
     g_inverse_fn = fn;
     g_inverse_user = user;
     return 0;
@@ -502,6 +520,7 @@ extern "C" int stk_mg_create_from_csr(int32_t n_levels, const stk_csr_host *A_fi
                 "stk_mg_create_from_csr: coefficients cms need the second matrix");
     STK_REQUIRE(!coords_host || (dim >= 1 && dim <= 3), "stk_mg_create_from_csr: dim=%d not in 1..3", dim);
     const int J = n_levels - 1;
+    const PlannerSettings settings = planner_settings();  // one consistent view for this construction
     // STK_PLAN_TIMING=1: seconds per stage of the planner on stderr
     static const bool timing = getenv("STK_PLAN_TIMING") != nullptr;
     std::map<std::string, double> spent;
@@ -631,7 +650,7 @@ extern "C" int stk_mg_create_from_csr(int32_t n_levels, const stk_csr_host *A_fi
         // cm[t] M, 1 otherwise -- source/multigrid.py BAND_MERGE has the measurements):
         // coarser bands keep "coupled rows at most one band apart", results do not change
         if (coords_host && !band.empty()) {
-            const int merge = g_mg_band_merge > 0 ? g_mg_band_merge : (M_fine ? 6 : 1);
+            const int merge = settings.band_merge > 0 ? settings.band_merge : (M_fine ? 6 : 1);
             if (merge > 1)
                 for (auto &b : band) b /= merge;
         }
@@ -787,11 +806,11 @@ extern "C" int stk_mg_create_from_csr(int32_t n_levels, const stk_csr_host *A_fi
             if (M_fine)
                 for (int e = Mm[0].ptr[i]; e < Mm[0].ptr[i + 1]; ++e) m0[(size_t)i * n0 + Mm[0].idx[e]] += Mm[0].val[e];
         }
-        STK_REQUIRE(dense_inverse(a0, n0, inv.data()), "stk_mg_create_from_csr: coarsest matrix is singular");
+        STK_REQUIRE(dense_inverse(a0, n0, inv.data(), settings), "stk_mg_create_from_csr: coarsest matrix is singular");
         for (int k = 0; k < n_kinds - 1; ++k) {
             std::vector<double> c((size_t)n0 * n0);
             for (size_t q = 0; q < c.size(); ++q) c[q] = ca * a0[q] + cms_host[k] * m0[q];
-            STK_REQUIRE(dense_inverse(c, n0, inv.data() + (size_t)(k + 1) * n0 * n0),
+            STK_REQUIRE(dense_inverse(c, n0, inv.data() + (size_t)(k + 1) * n0 * n0, settings),
                         "stk_mg_create_from_csr: coarsest matrix of kind %d is singular", k + 1);
         }
     }

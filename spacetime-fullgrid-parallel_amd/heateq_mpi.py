@@ -480,7 +480,12 @@ def main(argv=None):
     record.update(solve_time=MPI.Wtime() - began, mem_after_solve=mem(),
                   iters=iters, r_dot_Pr=list(history),
                   allreduce_calls=comm.allreduce_calls,
-                  allreduce_host_s=comm.allreduce_host_s)
+                  allreduce_host_s=comm.allreduce_host_s,
+                  # as the reference's time_applies (mpi_kron.py:23-31) every apply is
+                  # bracketed by a device synchronisation, and on several ranks every
+                  # scalar all-reduce by two: solve_time is taken WITH them (bench.py
+                  # times its iterations without)
+                  solve_time_includes='per-apply and per-all-reduce timing synchronisations')
     type(comm).timing = False
     for name in driver.OPERATORS + ('WT_S_W',):
         record[name] = driver.counters(getattr(heat, name))

@@ -65,6 +65,20 @@ def _hist_dev(tag, hist, ref, tol):
     return dev
 
 
+class _combination_of_two_chains:
+    """HeatEquationMPI built inside runs its preconditioner family on the combination ca (R A
+    P) + cm (R M P) on every level -- rounds 1-5's default -- instead of handing the members'
+    own Galerkin chains to the coarse end (round 6, MultiGridFamily(exact_coarse=True)): for
+    tests that compare forms of one arithmetic with each other."""
+    def __enter__(self):
+        import heateq_mpi as hm
+        self.hm, self.default = hm, dict(hm.HeatEquationMPI.ACCURATE)
+        hm.HeatEquationMPI.ACCURATE = dict(self.default, member_coarse_matrices=False)
+
+    def __exit__(self, *exc):
+        self.hm.HeatEquationMPI.ACCURATE = self.default
+
+
 def _scalar_dev(tag, dev, tol):
     """One measured deviation, recorded like _hist_dev's and then asserted."""
     import json
@@ -694,7 +708,11 @@ def test_coarse_subcycle_variants_agree(stk):
     import heateq_mpi as hm
     outs = []
     for problem, J_space in (('square', 5), ('square', 6), ('lshape', 4), ('cube', 2)):
-        h = hm.HeatEquationMPI(J_space=J_space, J_time=3, problem=problem)
+        # (the members' own coarse matrices of the default arithmetic are served by the
+        # uniform form alone -- the other forms are A/B switches and run the combination
+        # of the two chains: the forms are compared on the combination)
+        with _combination_of_two_chains():
+            h = hm.HeatEquationMPI(J_space=J_space, J_time=3, problem=problem)
         X = np.random.RandomState(11).rand(h.N, h.M)
         x = _vec(h.dofs_distr, X)
         res = []
@@ -1308,7 +1326,8 @@ def test_reference_forms_only_where_the_gap_is_owned(stk):
             dev.set_option('fuse_restrict_max_level', whole.hierarchy.J - 1)
         want_whole = (_np(whole.P @ x), _np(whole.S @ x))
         del whole
-        h = hm.HeatEquationMPI(J_space=J_space, J_time=3, problem=problem)  # arithmetic='accurate'
+        with _combination_of_two_chains():  # (the fast arithmetic's coarse matrices)
+            h = hm.HeatEquationMPI(J_space=J_space, J_time=3, problem=problem)  # arithmetic='accurate'
         plans = (h.Kinv_x._dev, h.C_family._dev)
         default = (_np(h.P @ x), _np(h.S @ x))
 
@@ -1857,6 +1876,28 @@ def test_kron_pack_inputs_per_term(stk):
                         assert float((y - y_plain).abs().max()) <= 1e-13 * float(y_plain.abs().max()), tag
                     if ld > n_loc:
                         assert float(y[:, n_loc:].abs().max()) == 0.0
+    # The stated time steps are trusted: a range that omits a step a factor reads
+    # silently drops that step's contribution.  The tuning key "pack_check_steps" makes
+    # the entry point fetch the factors and refuse such a range -- and lets
+    # the honest ranges of time_factor_steps through.
+    name, mats = families[0]
+    ell = EllMatrices(mats, [mats[0]])
+    M, n_loc, ld = ell.M, 9, 10
+    g = np.zeros((3, n_loc))
+    g[1, 0], g[0, 5] = 1.0, 2.0  # reads the steps 0 and 4
+    tri = _lib_dev(g)
+    xs = [torch.from_numpy(np.ascontiguousarray(np.pad(rng.rand(M, n_loc), ((0, 0), (0, 1))))).cuda() for _ in range(3)]
+    specs_ = [(None, 0, xs[0]), (None, 1, xs[1]), (tri, 0, xs[2])]
+    y = torch.zeros((M, ld), dtype=torch.float64, device='cuda')
+    form = ell.packed_variant(2)
+    assert time_factor_steps(g) == (0, 5)
+    try:
+        _lib.check(_lib.lib().stk_set_tuning(b'pack_check_steps', 1))
+        form.apply_multi(specs_, n_loc, ld, 0.0, y, steps=[None, None, (0, 5)])
+        with pytest.raises(_lib.StkError, match='reads time step 4'):
+            form.apply_multi(specs_, n_loc, ld, 0.0, y, steps=[None, None, (0, 2)])
+    finally:
+        _lib.check(_lib.lib().stk_set_tuning(b'pack_check_steps', 0))
 
 
 def test_kron_pack_explicit_value_pairs(stk):
