@@ -621,6 +621,19 @@ int stk_lu_info(const stk_lu *lu, int32_t *levels_L, int32_t *levels_U,
                 int32_t *launches);
 int stk_lu_solve(stk_lu *lu, void *stream, int32_t n_loc, int32_t ld,
                  const double *b, double *x, double *work);
+/* The top of the elimination tree as a dense block (optional).  The narrow levels are
+ * the separators near the root: a few thousand rows, one dependent row after the other
+ * (770 of the 802 levels of A_x at J_space = 6 hold 2 578 of its 16 129 rows).  The plan
+ * names them -- S = the rows from the first narrow level of L on, ascending
+ * (stk_lu_top_rows; n_top = 0: no such block, or U's rows of S reach outside S) -- and a
+ * caller that hands over the inverses of the two diagonal blocks L[S, S] and U[S, S]
+ * (n_top x n_top, row-major, DEVICE; the plan copies them) turns every solve into
+ *   head levels, d_S = (Pr b)_S - L[S, H] y_H, y_S = L_SS^-1 d_S;   z_S = U_SS^-1 y_S, head levels
+ * with the dense products as one launch each.  Without the call the plan walks every
+ * level (a run of narrow levels in one workgroup). */
+int stk_lu_top_rows(const stk_lu *lu, int32_t *n_top, int32_t *rows_host);
+int stk_lu_set_top_inverse(stk_lu *lu, const double *L_inv_dev,
+                           const double *U_inv_dev);
 
 /* ---- (A_t kron I) for a small sparse time matrix ---------------------------
  * y[., t] = (add_identity ? x[., t] : 0) + sum_e val[e] * src(col[e]) over the

@@ -40,6 +40,7 @@ struct TriDev {
     double *val = nullptr;
     double *dinv = nullptr;  // [n] 1 / diagonal of the sorted rows
     std::vector<int32_t> lvl_rows;  // host: rows per level
+    std::vector<int32_t> depth;     // host: level of every row of the matrix
     // segments: consecutive levels [a, b) per launch; wide levels stand alone
     std::vector<std::pair<int32_t, int32_t>> segments;
 };
@@ -121,11 +122,16 @@ void release(TriDev &t)
     t = TriDev();
 }
 
-// Level-sorted device copy of a triangular CSR matrix (sorted column indices; the
-// diagonal entry present in every row, or `unit` for an implicit / explicit 1).
+// Level-sorted device copy of (a part of) a triangular CSR matrix with sorted column
+// indices: the rows i with take(i), their entries j with keep(j); the dependency depth
+// of a row counts its entries with deps(j) only.  one_level: all rows in one level
+// (none of the kept entries is a dependency among them).  unit: diagonal 1, implicit
+// or explicit.  no_diag: the rows divide by 1 (a product, not a solve).
+template <class Take, class Keep, class Deps>
 int build(int32_t n, const int32_t *indptr, const int32_t *indices, const double *data, bool lower, bool unit,
-          TriDev *out)
+          Take take, Keep keep, Deps deps, bool one_level, bool no_diag, TriDev *out)
 {
+    const char *name = lower ? "L" : "U";
     std::vector<int32_t> depth(n, 0);
     std::vector<double> diag(n, unit ? 1.0 : 0.0);
     auto visit = [&](int i) {
@@ -135,68 +141,69 @@ int build(int32_t n, const int32_t *indptr, const int32_t *indices, const double
             if (j == i) {
                 if (!unit) diag[i] = data[e];
             } else if (lower ? j < i : j > i) {
-                d = std::max(d, depth[j] + 1);
+                if (deps(j)) d = std::max(d, depth[j] + 1);
             } else {
                 return -1;  // an entry on the wrong side of the diagonal
             }
         }
-        depth[i] = d;
+        depth[i] = one_level ? 0 : d;
         return 0;
     };
+    bool bad = false;
     if (lower) {
-        for (int i = 0; i < n; ++i)
-            if (visit(i)) goto bad;
+        for (int i = 0; i < n && !bad; ++i)
+            if (take(i)) bad = visit(i) != 0;
     } else {
-        for (int i = n - 1; i >= 0; --i)
-            if (visit(i)) goto bad;
+        for (int i = n - 1; i >= 0 && !bad; --i)
+            if (take(i)) bad = visit(i) != 0;
     }
-    {
-        int n_levels = 0;
-        for (int i = 0; i < n; ++i) {
-            STK_REQUIRE(diag[i] != 0.0, "stk_lu_create: zero diagonal in row %d of %s", i, lower ? "L" : "U");
-            n_levels = std::max(n_levels, depth[i] + 1);
-        }
-        std::vector<int32_t> lvl_ptr(n_levels + 1, 0);
-        for (int i = 0; i < n; ++i) ++lvl_ptr[depth[i] + 1];
-        for (int l = 0; l < n_levels; ++l) lvl_ptr[l + 1] += lvl_ptr[l];
-        std::vector<int32_t> fill(lvl_ptr.begin(), lvl_ptr.end() - 1), row(n), ptr(n + 1, 0);
-        for (int i = 0; i < n; ++i) row[fill[depth[i]]++] = i;  // increasing row index inside a level
-        std::vector<int32_t> col;
-        std::vector<double> val, dinv(n);
-        col.reserve(indptr[n]), val.reserve(indptr[n]);
-        for (int q = 0; q < n; ++q) {
-            const int i = row[q];
-            for (int e = indptr[i]; e < indptr[i + 1]; ++e)
-                if (indices[e] != i) col.push_back(indices[e]), val.push_back(data[e]);
-            ptr[q + 1] = (int32_t)col.size();
-            dinv[q] = 1.0 / diag[i];
-        }
-        TriDev t;
-        t.n = n, t.n_levels = n_levels;
-        t.lvl_rows.resize(n_levels);
-        for (int l = 0; l < n_levels; ++l) t.lvl_rows[l] = lvl_ptr[l + 1] - lvl_ptr[l];
-        for (int l = 0; l < n_levels;) {
-            if (t.lvl_rows[l] >= WIDE) {
-                t.segments.push_back({l, l + 1});
-                ++l;
-                continue;
-            }
-            int b = l;
-            while (b < n_levels && t.lvl_rows[b] < WIDE) ++b;
-            t.segments.push_back({l, b});
-            l = b;
-        }
-        if (upload(lvl_ptr, &t.lvl_ptr) || upload(row, &t.row) || upload(ptr, &t.ptr) || upload(col, &t.col) ||
-            upload(val, &t.val) || upload(dinv, &t.dinv)) {
-            release(t);
-            return 1;
-        }
-        *out = t;
-        return 0;
+    STK_REQUIRE(!bad, "stk_lu_create: %s has an entry on the wrong side of its diagonal", name);
+    int n_levels = 0, n_rows = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!take(i)) continue;
+        STK_REQUIRE(diag[i] != 0.0, "stk_lu_create: zero diagonal in row %d of %s", i, name);
+        n_levels = std::max(n_levels, depth[i] + 1);
+        ++n_rows;
     }
-bad:
-    stk_set_error("stk_lu_create: %s has an entry on the wrong side of its diagonal", lower ? "L" : "U");
-    return 1;
+    std::vector<int32_t> lvl_ptr(n_levels + 1, 0);
+    for (int i = 0; i < n; ++i)
+        if (take(i)) ++lvl_ptr[depth[i] + 1];
+    for (int l = 0; l < n_levels; ++l) lvl_ptr[l + 1] += lvl_ptr[l];
+    std::vector<int32_t> fill(lvl_ptr.begin(), lvl_ptr.end() - 1), row(n_rows), ptr(n_rows + 1, 0);
+    for (int i = 0; i < n; ++i)
+        if (take(i)) row[fill[depth[i]]++] = i;  // increasing row index inside a level
+    std::vector<int32_t> col;
+    std::vector<double> val, dinv(n_rows);
+    for (int q = 0; q < n_rows; ++q) {
+        const int i = row[q];
+        for (int e = indptr[i]; e < indptr[i + 1]; ++e)
+            if (indices[e] != i && keep(indices[e])) col.push_back(indices[e]), val.push_back(data[e]);
+        ptr[q + 1] = (int32_t)col.size();
+        dinv[q] = no_diag ? 1.0 : 1.0 / diag[i];
+    }
+    TriDev t;
+    t.n = n_rows, t.n_levels = n_levels;
+    t.lvl_rows.resize(n_levels);
+    for (int l = 0; l < n_levels; ++l) t.lvl_rows[l] = lvl_ptr[l + 1] - lvl_ptr[l];
+    for (int l = 0; l < n_levels;) {
+        if (t.lvl_rows[l] >= WIDE || one_level) {
+            t.segments.push_back({l, l + 1});
+            ++l;
+            continue;
+        }
+        int b = l;
+        while (b < n_levels && t.lvl_rows[b] < WIDE) ++b;
+        t.segments.push_back({l, b});
+        l = b;
+    }
+    t.depth = depth;
+    if (upload(lvl_ptr, &t.lvl_ptr) || upload(row, &t.row) || upload(ptr, &t.ptr) || upload(col, &t.col) ||
+        upload(val, &t.val) || upload(dinv, &t.dinv)) {
+        release(t);
+        return 1;
+    }
+    *out = t;
+    return 0;
 }
 
 int solve(hipStream_t st, const TriDev &t, int32_t n_loc, int32_t ld, const int32_t *src_perm, const double *rhs,
@@ -220,21 +227,78 @@ int solve(hipStream_t st, const TriDev &t, int32_t n_loc, int32_t ld, const int3
     return 0;
 }
 
+// ---- the top of the elimination tree as a dense block ------------------------------
+// The narrow levels are the separators near the root: a few thousand rows that depend on
+// each other almost densely, one row after the other.  Their diagonal blocks L_SS and
+// U_SS (S = the rows from the first narrow level of L on; ancestors of a row of S are in
+// S) are inverted once (stk_lu_set_top_inverse: the caller inverts, e.g. with a dense
+// triangular solve on the device), and the hundreds of dependent levels become
+//   forward:  head levels;  d_S = (Pr b)_S - L_SH y_H  (one launch);  y_S = L_SS^-1 d_S
+//   backward: z_S = U_SS^-1 y_S;  head levels (their rows read z_S like any column)
+// with the dense products as one launch each: out[i] = sum_j inv[i][j] in[S[j]], SP lanes
+// per (row, time step), lane s taking j = s, s + SP, ... -- a fixed shape again.
+__global__ __launch_bounds__(256) void dense_top_kernel(int32_t n_top, const int32_t *__restrict__ rows,
+                                                        const double *__restrict__ inv, int lower, int32_t n_loc,
+                                                        int32_t ld, const double *__restrict__ in,
+                                                        double *__restrict__ scratch)
+{
+    const int lane_s = threadIdx.x & (SP - 1);
+    const int64_t item = ((int64_t)blockIdx.x * 256 + threadIdx.x) / SP;  // whole lane groups are in or out
+    if (item >= (int64_t)n_top * n_loc) return;
+    const int i = (int)(item / n_loc), t = (int)(item - (int64_t)i * n_loc);
+    const int j0 = lower ? 0 : i, j1 = lower ? i + 1 : n_top;
+    const double *r = inv + (size_t)i * n_top;
+    double acc = 0.0;
+    for (int j = j0 + lane_s; j < j1; j += SP) acc = fma(r[j], in[(size_t)rows[j] * ld + t], acc);
+#pragma unroll
+    for (int off = SP / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off, SP);
+    if (lane_s == 0) scratch[(size_t)i * n_loc + t] = acc;
+}
+
+// u[S[i]] = scratch[i] (and out[dst[S[i]]] with its padding, for the backward solve)
+__global__ __launch_bounds__(256) void scatter_top_kernel(int32_t n_top, const int32_t *__restrict__ rows,
+                                                          int32_t n_loc, int32_t ld,
+                                                          const double *__restrict__ scratch, double *u,
+                                                          const int32_t *__restrict__ dst_perm, double *out)
+{
+    const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (item >= (int64_t)n_top * n_loc) return;
+    const int i = (int)(item / n_loc), t = (int)(item - (int64_t)i * n_loc);
+    const double v = scratch[item];
+    const int k = rows[i];
+    u[(size_t)k * ld + t] = v;
+    if (dst_perm) {
+        double *o = out + (size_t)dst_perm[k] * ld;
+        o[t] = v;
+        if (t == n_loc - 1)
+            for (int tt = n_loc; tt < ld; ++tt) o[tt] = 0.0;
+    }
+}
+
 }  // namespace
 
 struct stk_lu {
     int32_t n = 0;
-    TriDev L, U;
+    TriDev L, U;                  // all rows, level by level (no dense top)
     int32_t *src_perm = nullptr;  // row of b that row k of L y = Pr b reads
     int32_t *dst_perm = nullptr;  // row of x that receives row k of z = U^-1 y
+    // dense top: S and the three pieces of each solve that are not the dense products
+    int32_t n_top = 0;
+    std::vector<int32_t> top_rows_host;
+    int32_t *top_rows = nullptr;
+    TriDev L_head, L_top, U_head;  // L_top: rows of S, entries outside S (one level, a product)
+    double *L_inv = nullptr, *U_inv = nullptr;  // [n_top][n_top] row-major, set by the caller
+    double *scratch = nullptr;
+    int64_t scratch_doubles = 0;
 };
 
 extern "C" int stk_lu_destroy(stk_lu *lu)
 {
     if (!lu) return 0;
-    release(lu->L), release(lu->U);
-    (void)hipFree(lu->src_perm);
-    (void)hipFree(lu->dst_perm);
+    release(lu->L), release(lu->U), release(lu->L_head), release(lu->L_top), release(lu->U_head);
+    for (void *p : {(void *)lu->src_perm, (void *)lu->dst_perm, (void *)lu->top_rows, (void *)lu->L_inv,
+                    (void *)lu->U_inv, (void *)lu->scratch})
+        (void)hipFree(p);
     delete lu;
     return 0;
 }
@@ -259,13 +323,68 @@ extern "C" int stk_lu_create(int32_t n, const int32_t *L_indptr, const int32_t *
     }
     stk_lu *lu = new stk_lu;
     lu->n = n;
-    if (build(n, L_indptr, L_indices, L_data, true, true, &lu->L) ||
-        build(n, U_indptr, U_indices, U_data, false, false, &lu->U) || upload(src, &lu->src_perm) ||
-        upload(dst, &lu->dst_perm)) {
+    auto all = [](int) { return true; };
+    if (build(n, L_indptr, L_indices, L_data, true, true, all, all, all, false, false, &lu->L) ||
+        build(n, U_indptr, U_indices, U_data, false, false, all, all, all, false, false, &lu->U) ||
+        upload(src, &lu->src_perm) || upload(dst, &lu->dst_perm)) {
         stk_lu_destroy(lu);
         return 1;
     }
+    // S: the rows from the first narrow level of L on -- if there are enough levels to
+    // save, the blocks stay affordable (two n_top^2 arrays), and the rows of S depend in U
+    // on rows of S alone (true for the symmetric patterns of SymmetricMode; checked)
+    {
+        const TriDev &T = lu->L;
+        int d0 = 0;
+        while (d0 < T.n_levels && T.lvl_rows[d0] >= WIDE) ++d0;
+        std::vector<char> in_top(n, 0);
+        int n_top = 0;
+        for (int i = 0; i < n; ++i)
+            if (T.depth[i] >= d0) in_top[i] = 1, ++n_top;
+        bool closed = true;
+        for (int i = 0; i < n && closed; ++i)
+            if (in_top[i])
+                for (int e = U_indptr[i]; e < U_indptr[i + 1]; ++e)
+                    if (!in_top[U_indices[e]]) closed = false;
+        if (T.n_levels - d0 >= 16 && n_top >= 2 && n_top <= 40000 && closed) {
+            auto top = [&](int i) { return in_top[i] != 0; };
+            auto head = [&](int i) { return in_top[i] == 0; };
+            if (build(n, L_indptr, L_indices, L_data, true, true, head, all, all, false, false, &lu->L_head) ||
+                build(n, L_indptr, L_indices, L_data, true, true, top, head, head, true, true, &lu->L_top) ||
+                build(n, U_indptr, U_indices, U_data, false, false, head, all, head, false, false, &lu->U_head)) {
+                stk_lu_destroy(lu);
+                return 1;
+            }
+            lu->n_top = n_top;
+            for (int i = 0; i < n; ++i)
+                if (in_top[i]) lu->top_rows_host.push_back(i);
+            if (upload(lu->top_rows_host, &lu->top_rows)) {
+                stk_lu_destroy(lu);
+                return 1;
+            }
+        }
+    }
     *out = lu;
+    return 0;
+}
+
+extern "C" int stk_lu_top_rows(const stk_lu *lu, int32_t *n_top, int32_t *rows_host)
+{
+    STK_REQUIRE(lu && n_top, "stk_lu_top_rows: null argument");
+    *n_top = lu->n_top;
+    if (rows_host)
+        for (int i = 0; i < lu->n_top; ++i) rows_host[i] = lu->top_rows_host[i];
+    return 0;
+}
+
+extern "C" int stk_lu_set_top_inverse(stk_lu *lu, const double *L_inv_dev, const double *U_inv_dev)
+{
+    STK_REQUIRE(lu && lu->n_top > 0 && L_inv_dev && U_inv_dev, "stk_lu_set_top_inverse: the plan has no dense top");
+    const size_t bytes = sizeof(double) * (size_t)lu->n_top * lu->n_top;
+    if (!lu->L_inv) STK_HIP(hipMalloc((void **)&lu->L_inv, bytes));
+    if (!lu->U_inv) STK_HIP(hipMalloc((void **)&lu->U_inv, bytes));
+    STK_HIP(hipMemcpy(lu->L_inv, L_inv_dev, bytes, hipMemcpyDeviceToDevice));
+    STK_HIP(hipMemcpy(lu->U_inv, U_inv_dev, bytes, hipMemcpyDeviceToDevice));
     return 0;
 }
 
@@ -274,7 +393,13 @@ extern "C" int stk_lu_info(const stk_lu *lu, int32_t *levels_L, int32_t *levels_
     STK_REQUIRE(lu, "stk_lu_info: null plan");
     if (levels_L) *levels_L = lu->L.n_levels;
     if (levels_U) *levels_U = lu->U.n_levels;
-    if (launches) *launches = (int32_t)(lu->L.segments.size() + lu->U.segments.size());
+    if (launches) {
+        if (lu->L_inv && lu->U_inv)
+            *launches = (int32_t)(lu->L_head.segments.size() + lu->L_top.segments.size() +
+                                  lu->U_head.segments.size() + 4);
+        else
+            *launches = (int32_t)(lu->L.segments.size() + lu->U.segments.size());
+    }
     return 0;
 }
 
@@ -286,8 +411,33 @@ extern "C" int stk_lu_solve(stk_lu *lu, void *stream, int32_t n_loc, int32_t ld,
     STK_REQUIRE(n_loc > 0 && ld >= n_loc, "stk_lu_solve: bad sizes n_loc=%d ld=%d", n_loc, ld);
     STK_REQUIRE(work != b && work != x, "stk_lu_solve: work aliases b or x");
     hipStream_t st = stk_stream(stream);
-    // L y = Pr b into work; U z = y in place on work, every row also to its place in x
-    int rc = solve(st, lu->L, n_loc, ld, lu->src_perm, b, work, nullptr, nullptr);
+    if (!(lu->L_inv && lu->U_inv)) {
+        // L y = Pr b into work; U z = y in place on work, every row also to its place in x
+        int rc = solve(st, lu->L, n_loc, ld, lu->src_perm, b, work, nullptr, nullptr);
+        if (rc) return rc;
+        return solve(st, lu->U, n_loc, ld, nullptr, work, work, lu->dst_perm, x);
+    }
+    const int64_t need = (int64_t)lu->n_top * n_loc;
+    if (lu->scratch_doubles < need) {
+        if (lu->scratch) STK_HIP(hipFree(lu->scratch));
+        lu->scratch = nullptr, lu->scratch_doubles = 0;
+        STK_HIP(hipMalloc((void **)&lu->scratch, sizeof(double) * (size_t)need));
+        lu->scratch_doubles = need;
+    }
+    const unsigned g_dense = (unsigned)((need * SP + 255) / 256), g_copy = (unsigned)((need + 255) / 256);
+    // forward
+    int rc = solve(st, lu->L_head, n_loc, ld, lu->src_perm, b, work, nullptr, nullptr);
+    if (rc == 0) rc = solve(st, lu->L_top, n_loc, ld, lu->src_perm, b, work, nullptr, nullptr);  // d_S into work
     if (rc) return rc;
-    return solve(st, lu->U, n_loc, ld, nullptr, work, work, lu->dst_perm, x);
+    hipLaunchKernelGGL(dense_top_kernel, dim3(g_dense), dim3(256), 0, st, lu->n_top, lu->top_rows, lu->L_inv, 1, n_loc,
+                       ld, work, lu->scratch);
+    hipLaunchKernelGGL(scatter_top_kernel, dim3(g_copy), dim3(256), 0, st, lu->n_top, lu->top_rows, n_loc, ld,
+                       lu->scratch, work, (const int32_t *)nullptr, (double *)nullptr);
+    // backward
+    hipLaunchKernelGGL(dense_top_kernel, dim3(g_dense), dim3(256), 0, st, lu->n_top, lu->top_rows, lu->U_inv, 0, n_loc,
+                       ld, work, lu->scratch);
+    hipLaunchKernelGGL(scatter_top_kernel, dim3(g_copy), dim3(256), 0, st, lu->n_top, lu->top_rows, n_loc, ld,
+                       lu->scratch, work, lu->dst_perm, x);
+    STK_LAUNCH_CHECK();
+    return solve(st, lu->U_head, n_loc, ld, nullptr, work, work, lu->dst_perm, x);
 }

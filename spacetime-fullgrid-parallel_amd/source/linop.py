@@ -128,6 +128,13 @@ class InvLinOp(SpaceOp):
     of the tests)."""
     MAX_ROWS = 8192
     host_solve = False
+    # The narrow levels near the root of the elimination tree (a few thousand rows, one
+    # dependent row after the other) as ONE dense block whose triangular factors are
+    # inverted at set-up: hundreds of dependent levels become two dense products
+    # (csrc/sptrsv.hip).  False: every level by itself (the comparison partner of the tests).
+    dense_top = True
+    DENSE_TOP_MAX = 8192  # rows of the block (its two inverses: 2 x 512 MiB at most)
+    n_top = 0
 
     def __init__(self, mat):
         mat = sp.csc_matrix(mat)
@@ -142,6 +149,8 @@ class InvLinOp(SpaceOp):
         if n <= self.MAX_ROWS:
             self._dense = SpaceMatrix(sp.csr_matrix(self.lu.solve(np.eye(n))))
             self.mat = self._dense.mat
+        elif not self.host_solve and _lib.compute_device().type == 'cuda':
+            self._device_plan()  # set-up work belongs to the set-up
 
     def _device_plan(self):
         if self._plan is None:
@@ -153,8 +162,26 @@ class InvLinOp(SpaceOp):
             args = [i32(L.indptr), i32(L.indices), f64(L.data), i32(U.indptr), i32(U.indices),
                     f64(U.data), i32(self.lu.perm_r), i32(self.lu.perm_c)]
             plan = ctypes.c_void_p()
-            _lib.check(_lib.lib().stk_lu_create(self.shape[0], *[a.ctypes.data for a in args],
-                                                ctypes.byref(plan)))
+            lib = _lib.lib()
+            _lib.check(lib.stk_lu_create(self.shape[0], *[a.ctypes.data for a in args],
+                                         ctypes.byref(plan)))
+            # the top of the elimination tree as a dense block: the plan names the rows,
+            # the two triangular blocks are inverted here (dense solves on the device)
+            n_top = ctypes.c_int32()
+            _lib.check(lib.stk_lu_top_rows(plan, ctypes.byref(n_top), None))
+            if 0 < n_top.value <= self.DENSE_TOP_MAX and self.dense_top:
+                from scipy.linalg.lapack import dtrtri
+                rows = np.empty(n_top.value, dtype=np.int32)
+                _lib.check(lib.stk_lu_top_rows(plan, ctypes.byref(n_top), rows.ctypes.data))
+                blocks = []
+                for T, lower, unit in ((L, 1, 1), (U, 0, 0)):
+                    # LAPACK's triangular inverse on the host, at set-up like the
+                    # factorisation itself (hipBLAS' trsm fails to allocate on this image)
+                    inv, info = dtrtri(np.asfortranarray(T[rows][:, rows].toarray()), lower=lower, unitdiag=unit)
+                    assert info == 0, info
+                    blocks.append(_lib.to_dev(np.ascontiguousarray(inv)))
+                _lib.check(lib.stk_lu_set_top_inverse(plan, _lib.ptr(blocks[0]), _lib.ptr(blocks[1])))
+                self.n_top = int(n_top.value)
             self._plan = plan
         return self._plan
 
