@@ -111,9 +111,12 @@ class SchurMPI(LinearOperatorMPI):
             # (csrc/kron_pack.hip); the halo has to be there first
             ghosts = None
             first = [(self.tA, 0), (self.tL, 1)]
-            if self.dofs_distr.size > 1 and not vec_in.communicated_bdr:
+            from source.mpi_kron import _FusedKronSum
+            if (self.dofs_distr.size > 1 and not vec_in.communicated_bdr
+                    and _FusedKronSum.overlap and n_loc >= _FusedKronSum.OVERLAP_FROM):
                 # the pass over the slab without the ghost steps while the halo is
-                # in flight (reference mpi_kron.py:193-200), their share afterwards
+                # in flight (reference mpi_kron.py:193-200), the two boundary steps
+                # afterwards (long slabs only: see _FusedKronSum.OVERLAP_FROM)
                 self.time_communication = vec_in.communicate_bdr(
                     callback=lambda: packed.apply(first, x, None, n_loc, ld, 0.0, u))
                 packed.apply_ghost(first, x, vec_in.X_lo, vec_in.X_hi, n_loc, ld, u)

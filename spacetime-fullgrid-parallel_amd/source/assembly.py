@@ -7,6 +7,8 @@ Conventions follow NGSolve / the reference:
   (ngsolve_helper.py:38-45);
 * dtypes are float64 data, int32 indices/indptr (mpi_shared_mem.py:46-48).
 """
+import os
+
 import numpy as np
 import scipy.sparse as sp
 
@@ -168,6 +170,13 @@ def tile_order_from_coords(coords, rows_per_tile=None, small_lexsort=True):
     side = (np.prod(ext) / ntiles)**(1.0 / d)
     tiles = tuple(np.floor((p[:, k] - lo[k]) / side).astype(np.int64)
                   for k in range(d))
+    if os.environ.get('STK_TILE_WALK') == 'snake' and d == 2:
+        # EXPERIMENT (measured and not adopted):
+        # a boustrophedon walk inside a tile -- every other mesh row of a tile from right to
+        # left, so that the two readers of a gathered row above / below sit closer together
+        ys = np.unique(p[:, 1])
+        row = np.searchsorted(ys, p[:, 1])
+        lex = (np.where(row & 1, -p[:, 0], p[:, 0]), p[:, 1])
     return np.lexsort(lex + tiles).astype(np.int32)
 
 

@@ -461,7 +461,14 @@ class _FusedKronSum:
     # wait for the halo, then one pass with the ghost steps as an extra lane per
     # row.  A halo that is already there (cached) always takes the one-pass form.
     # Both forms, and the one-rank kernel, round every entry the same way.
+    # Round 6: recomputing the two boundary steps (what makes the forms bit-equal)
+    # gathers 16 bytes per 128-byte line of the slab and costs 0.069 / 0.130 / 0.079 ms
+    # at 9 / 17 / 33 steps of 1 046 529 rows where adding a share cost 0.042 / 0.052 /
+    # 0.041 ms: beside a wire of 0.109 ms the overlapped form only wins on slabs whose
+    # pass is long enough to hide the wire, from OVERLAP_FROM steps on
+    # (profiles/r06_slab_shapes_J9.log, _J10.log).
     overlap = True
+    OVERLAP_FROM = 24
 
     @classmethod
     def max_terms(cls):
@@ -505,7 +512,7 @@ class _FusedKronSum:
             specs = [(self.tri[k], k) for k in range(self.n_terms)]
             halo = self.dofs_distr.size > 1 and (self.needs_lo or self.needs_hi)
             if (halo and type(self).overlap and not vec_in.communicated_bdr
-                    and beta == 0.0):
+                    and beta == 0.0 and vec_in.n_loc >= type(self).OVERLAP_FROM):
                 # (the boundary steps are REWRITTEN afterwards: a beta != 0 would
                 # need the old values the pass has replaced -- one-pass form then)
                 time_comm = vec_in.communicate_bdr(callback=lambda: packed.apply(
