@@ -26,6 +26,7 @@ int stk_rows_ell_set_tuning(const char *key, int32_t value);  // rows_ell.hip
 int stk_wavelet_set_tuning(const char *key, int32_t value);   // wavelet.hip
 extern int g_mg_gs_diag_free;  // mg_build.hip
 extern int g_mg_restrict_one_pass;  // mg.hip
+extern int g_mg_coarse_static_fetch;  // mg_coarse.hip
 extern int g_mg_fuse_coarse, g_mg_coarse_max_rows, g_mg_fuse_restrict, g_mg_zero_start, g_mg_strip_mb, g_mg_strips_used, g_mg_strip_width;  // mg.hip
 extern int g_mg_coarse_pairs, g_mg_coarse_lds, g_mg_coarse_uniform;  // mg_coarse.hip
 
@@ -446,6 +447,10 @@ extern "C" int stk_set_tuning(const char *key, int32_t value)
     }
     if (std::strcmp(key, "mg_strip_width") == 0) {
         g_mg_strip_width = value;
+        return 0;
+    }
+    if (std::strcmp(key, "mg_coarse_static_fetch") == 0) {
+        g_mg_coarse_static_fetch = value;
         return 0;
     }
     if (std::strcmp(key, "mg_strips_used") == 0) {  // tests: reset (0) / require at least `value` strip launches

@@ -393,7 +393,7 @@ __global__ void repack_uniform_kernel(int n_rows, int K_src, int KU, const int32
     }
 }
 
-template <int KU, bool HAS_M, bool PAIR, int UBS>
+template <int KU, bool HAS_M, bool PAIR, int UBS, bool SF>
 __global__ __launch_bounds__(UBS) void mg_coarse_uniform_kernel(const CoarseArgs a, const UniArgs m)
 {
     typedef TimeElem<PAIR> E;
@@ -455,7 +455,14 @@ __global__ __launch_bounds__(UBS) void mg_coarse_uniform_kernel(const CoarseArgs
             const double2 v = pa[q];
             S.va[2 * q] = v.x, S.va[2 * q + 1] = v.y;
         }
-        if (HAS_M && (j.flags & 1)) {
+        // Every array is read whatever the job needs of it (the second value array and the
+        // diagonals of a transfer are zeros in the uniform copies): the SAME loads for every
+        // row, so that the compiler's wait counters know how many loads lie between a set of
+        // registers and the next one.  With loads behind branches it waited for vmcnt(0)
+        // before the first use of a prefetched row -- i.e. also for the set it had just issued
+        // for the job after next -- and a job took one L2 round trip, 1.35 us, whatever its
+        // rows (round 6).
+        if (HAS_M && (SF || (j.flags & 1))) {
             const double2 *pm = reinterpret_cast<const double2 *>((mem ? m.vmem + mem1 * KU : m.vm) + e0);
 #pragma unroll
             for (int q = 0; q < KU / 2; ++q) {
@@ -463,15 +470,22 @@ __global__ __launch_bounds__(UBS) void mg_coarse_uniform_kernel(const CoarseArgs
                 S.vm[2 * q] = v.x, S.vm[2 * q + 1] = v.y;
             }
         }
-        if (j.kind == JOB_GS) {
-            S.da = mem ? m.dmem[mem0 + row] : m.dia_a[row];
-            if (HAS_M && (j.flags & 1)) S.dm = mem ? m.dmem[mem1 + row] : m.dia_m[row];
+        if (SF || j.kind == JOB_GS) {
+            S.da = (mem ? m.dmem + mem0 : m.dia_a)[row];
+            if (HAS_M && (SF || (j.flags & 1))) S.dm = (mem ? m.dmem + mem1 : m.dia_m)[row];
         }
         S.orow = m.row[row];
     };
-    // the first row of a thread in job jn, if that is a row job
+    // the first row of a thread in job jn -- or, where there is none (no row job, a thread
+    // beyond the job's rows, past the last job), row 0 of the uniform arrays: same loads
+    // (SF = false: loads only where there is a row -- round 4's form, kept for the A/B)
     auto fetch = [&](int jn, RowRegs &S) {
-        if (jn < a.n_jobs) {
+        if constexpr (SF) {
+            CJob nj = s_jobs[min(jn, a.n_jobs - 1)];
+            const bool rows = jn < a.n_jobs && (nj.kind == JOB_SPMM || nj.kind == JOB_GS) && tid < nj.n_rows;
+            if (!rows) nj.mat_off = 0, nj.flags = 0;
+            load_row(nj, rows ? tid : 0, S);
+        } else if (jn < a.n_jobs) {
             const CJob nj = s_jobs[jn];
             if ((nj.kind == JOB_SPMM || nj.kind == JOB_GS) && tid < nj.n_rows) load_row(nj, tid, S);
         }
@@ -937,18 +951,27 @@ bool stk_coarse_plan_in_lds(const stk_coarse_plan *p)
     return g_mg_coarse_lds && g_mg_coarse_pairs <= 1 && sizeof(double) * (size_t)p->lds_rows <= 144 * 1024;
 }
 
-template <int KU, bool HAS_M, bool PAIR, int UBS>
-static int launch_uniform_one(dim3 grid, size_t lds, hipStream_t st, const CoarseArgs &a, const UniArgs &m)
+int g_mg_coarse_static_fetch = 0;  // tuning key "mg_coarse_static_fetch": the same loads for every row (A/B)
+
+template <int KU, bool HAS_M, bool PAIR, int UBS, bool SF>
+static int launch_uniform_sf(dim3 grid, size_t lds, hipStream_t st, const CoarseArgs &a, const UniArgs &m)
 {
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
-        STK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mg_coarse_uniform_kernel<KU, HAS_M, PAIR, UBS>),
+        STK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mg_coarse_uniform_kernel<KU, HAS_M, PAIR, UBS, SF>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((mg_coarse_uniform_kernel<KU, HAS_M, PAIR, UBS>), grid, dim3(UBS), lds, st, a, m);
+    hipLaunchKernelGGL((mg_coarse_uniform_kernel<KU, HAS_M, PAIR, UBS, SF>), grid, dim3(UBS), lds, st, a, m);
     STK_LAUNCH_CHECK();
     return 0;
+}
+
+template <int KU, bool HAS_M, bool PAIR, int UBS>
+static int launch_uniform_one(dim3 grid, size_t lds, hipStream_t st, const CoarseArgs &a, const UniArgs &m)
+{
+    return g_mg_coarse_static_fetch ? launch_uniform_sf<KU, HAS_M, PAIR, UBS, true>(grid, lds, st, a, m)
+                                    : launch_uniform_sf<KU, HAS_M, PAIR, UBS, false>(grid, lds, st, a, m);
 }
 
 // 1024 threads per time step where the registers allow: a level-5 job is then one or

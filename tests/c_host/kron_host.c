@@ -4,7 +4,10 @@
  * A_x)]) @ x (reference source/mpi_kron.py:77-90, 204-222):
  *   plan from the CSR arrays the reference holds (stk_kron_plan_create), slab storage
  *   (stk_slab_alloc / _upload / _download: the reference's time-major X_loc[t][i] in,
- *   the same out), the apply (stk_kron_plan_apply), a dot product (stk_dot) --
+ *   the same out), the apply (stk_kron_plan_apply), a dot product -- flat (stk_dot)
+ *   and as KronVectorMPI.dot takes it since round 6, per time step in a fixed shape
+ *   (stk_slab_dot, stk_sum_steps: one value on any partition of the time axis; the slab
+ *   is also summed as two slabs of a two-rank partition, the sums must be EQUAL) --
  * checked here against the triple loop of the definition, on the host.
  * Test infrastructure: built and run by tests/test_c_host.py.
  *   usage: kron_host [nx ny n_loc]      prints "kron_host ok ..." and exits 0 on success */
@@ -127,6 +130,35 @@ int main(int argc, char **argv)
     CHECK(stk_dot(NULL, (int64_t)M * ld, x, y, work, dot_dev));
     double dot = 0.0;
     HIP(hipMemcpy(&dot, dot_dev, sizeof(double), hipMemcpyDeviceToHost));
+    /* the same inner product per time step (mpi_vector.py:205-210 without its dependence on
+       the number of ranks): as one slab, and as the two slabs [0, h) and [h, n_loc) of a
+       two-rank partition whose per-step sums an all-reduce would add entry by entry */
+    double *sd_work, *steps_dev, *steps = (double *)malloc(sizeof(double) * 3 * (size_t)n_loc);
+    HIP(hipMalloc((void **)&sd_work, sizeof(double) * (size_t)stk_slab_dot_work_size(M, n_loc)));
+    HIP(hipMalloc((void **)&steps_dev, sizeof(double) * (size_t)n_loc));
+    CHECK(stk_slab_dot(NULL, M, n_loc, ld, x, y, sd_work, n_loc, 0, steps_dev));
+    HIP(hipMemcpy(steps, steps_dev, sizeof(double) * (size_t)n_loc, hipMemcpyDeviceToHost));
+    const double dot_steps = stk_sum_steps(steps, n_loc);
+    int parts_equal = 1;
+    if (n_loc >= 2) {
+        const int h = n_loc / 2, n_part[2] = {h, n_loc - h}, t0_part[2] = {0, h};
+        for (int q = 0; q < n_loc; ++q) steps[n_loc + q] = 0.0;
+        for (int part = 0; part < 2; ++part) {
+            double *xp, *yp;
+            int32_t ldp;
+            CHECK(stk_slab_alloc(M, n_part[part], &ldp, &xp));
+            CHECK(stk_slab_alloc(M, n_part[part], &ldp, &yp));
+            CHECK(stk_slab_upload(NULL, M, n_part[part], ldp, X + (size_t)t0_part[part] * M, xp));
+            CHECK(stk_slab_upload(NULL, M, n_part[part], ldp, Y + (size_t)t0_part[part] * M, yp));
+            CHECK(stk_slab_dot(NULL, M, n_part[part], ldp, xp, yp, sd_work, n_loc, t0_part[part], steps_dev));
+            HIP(hipMemcpy(steps + 2 * n_loc, steps_dev, sizeof(double) * (size_t)n_loc, hipMemcpyDeviceToHost));
+            for (int q = 0; q < n_loc; ++q) steps[n_loc + q] += steps[2 * n_loc + q];
+            CHECK(stk_slab_free(xp));
+            CHECK(stk_slab_free(yp));
+        }
+        for (int q = 0; q < n_loc; ++q) parts_equal = parts_equal && steps[q] == steps[n_loc + q];
+        parts_equal = parts_equal && stk_sum_steps(steps + n_loc, n_loc) == dot_steps;
+    }
 
     /* ---- the definition, on the host ------------------------------------------------ */
     double *Z = (double *)malloc(sizeof(double) * (size_t)n_loc * M);
@@ -159,7 +191,11 @@ int main(int argc, char **argv)
     CHECK(stk_slab_free(x));
     CHECK(stk_slab_free(y));
     const double rel = err / big, rel_dot = fabs(dot - dot_ref) / fabs(dot_ref);
-    printf("kron_host %s: M=%d n_loc=%d ld=%d K=%d codes=%d packed=%d rows_per_unit=%d  max rel err %.2e  dot rel err %.2e\n",
-           (rel < 1e-13 && rel_dot < 1e-12) ? "ok" : "FAILED", M, n_loc, ld, K, codes, packed, rpu, rel, rel_dot);
-    return (rel < 1e-13 && rel_dot < 1e-12) ? 0 : 1;
+    const double rel_steps = fabs(dot_steps - dot_ref) / fabs(dot_ref);
+    const int ok = rel < 1e-13 && rel_dot < 1e-12 && rel_steps < 1e-12 && parts_equal;
+    printf("kron_host %s: M=%d n_loc=%d ld=%d K=%d codes=%d packed=%d rows_per_unit=%d  max rel err %.2e  dot rel err %.2e  "
+           "per-step dot rel err %.2e, two slabs %s\n",
+           ok ? "ok" : "FAILED", M, n_loc, ld, K, codes, packed, rpu, rel, rel_dot, rel_steps,
+           parts_equal ? "equal" : "DIFFER");
+    return ok ? 0 : 1;
 }

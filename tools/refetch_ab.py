@@ -23,7 +23,7 @@ from source import _lib  # noqa: E402
 
 DEFAULTS = {'rows_nt_store': 0, 'rows_wg_per_cu': 0, 'rows_alternate': 1, 'pack_wg_per_cu': 0,
             'pack_flags': 3, 'pack_multi_wg_per_cu': 0, 'pack_multi_r': 0, 'pack_multi_lanes': 1,
-            'terms_wg_per_cu': 0, 'terms_flags': 3, 'terms_r': 0}
+            'terms_wg_per_cu': 0, 'terms_flags': 3, 'terms_r': 0, 'mg_coarse_static_fetch': 0}
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--J_time', type=int, default=6)
