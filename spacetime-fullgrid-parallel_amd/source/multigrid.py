@@ -488,7 +488,10 @@ class _DeviceHierarchy:
         self.coarse_inv = _lib.to_dev(np.ascontiguousarray(inv))
         self.n_kinds = inv.shape[0]
         # member_mats[k][level]: the level matrices of member k itself (member_chains) for
-        # the coarse end of the plan; coarse-inverse kind k + 1 names member k
+        # the coarse end of the plan; coarse-inverse kind k + 1 names member k (a callable:
+        # the chains are formed beside this constructor and joined by coarse_mats above)
+        if callable(member_mats):
+            member_mats = member_mats()
         self.member_mats = member_mats
         self.member_levels = 0  # levels 1 .. member_levels of the plans run on them
         if member_mats is not None:
@@ -910,22 +913,40 @@ class MultiGridFamily:
         self.ca = float(ca)
         self.cms = [float(c) for c in cms]
         self.hierarchy = hierarchy
-        chains = None
+        # the members' chains are device work (Galerkin kernels, compactions) that needs
+        # nothing of the plan: formed in a thread of their own beside the planner's host
+        # work, joined where the coarsest matrices are inverted
+        box = {}
+        worker = None
         if exact_coarse and hierarchy.J >= 1 and _lib.compute_device().type == 'cuda':
-            chains = member_chains(hierarchy, mat_a, mat_m, self.ca, self.cms)
-            if chains is not None and not all(0 in kept for kept in chains):
-                chains = None
-        self.member_chains = chains
+            def run():
+                try:
+                    got = member_chains(hierarchy, mat_a, mat_m, self.ca, self.cms)
+                    box['chains'] = got if got is not None and all(0 in kept for kept in got) else None
+                except BaseException as err:  # re-raised by the planner's thread
+                    box['error'] = err
+
+            worker = threading.Thread(target=_lib.in_device_context(run), daemon=True)
+            worker.start()
+
+        def chains_now():
+            if worker is not None:
+                worker.join()
+                if 'error' in box:
+                    raise box['error']
+            return box.get('chains')
 
         def coarse(a0, m0):
             # kind 0: A alone (unused by members); kind 1+k: member k
+            chains = chains_now()
             if chains is not None:
                 return [a0] + [kept[0] for kept in chains]
             return [a0] + [self.ca * a0 + c * m0 for c in self.cms]
 
         self._dev = _DeviceHierarchy(mat_a, mat_m, hierarchy, smoothsteps,
                                      vcycles, coarse, gs_rows=gs_rows, band_merge=band_merge,
-                                     member_mats=chains)
+                                     member_mats=chains_now)
+        self.member_chains = chains_now()
         if fuse_restrict is not None:
             self._dev.set_option('fuse_restrict', bool(fuse_restrict))
         self.shape = self._dev.shape
