@@ -793,6 +793,26 @@ class MultiGrid(SpaceOp):
         self.num_applies += 1
         return self._dev.apply(x, out, n_loc, 1.0, None, None, twin=twin)
 
+    def _matvec(self, b):
+        """The reference's entry point (multigrid.py:184-193): a NumPy vector in, `vcycles`
+        V-cycles from zero, a NumPy vector out, wall time (device drained) added to
+        time_applies.  The hot path calls apply() on device slabs and does not stop
+        the clock for it."""
+        import time
+        torch.cuda.synchronize()
+        began = time.perf_counter()
+        x = SpaceOp.__matmul__(self, np.asarray(b, dtype=np.float64).reshape(-1))
+        torch.cuda.synchronize()
+        self.time_applies += time.perf_counter() - began
+        return x
+
+    matvec = _matvec
+
+    def time_per_apply(self):
+        """reference multigrid.py:195-197 (of the applies that went through _matvec)."""
+        assert (self.time_applies)
+        return self.time_applies / self.num_applies
+
     def apply_pair(self, x1, x2, n_loc=None, shared=()):
         """(K x1, K x2) with the two independent V-cycle chains side by side on two
         HIP streams (a twin plan owns the second set of level workspaces).  Two

@@ -314,6 +314,10 @@ def test_gauss_seidel_and_multigrid_match_reference_golden(stk, g3):
         for vc in (1, 2):
             mg = MultiGrid(m['A_x'], hier, smoothsteps=ss, vcycles=vc)
             assert relerr(mg @ b, g3['mg_Ax_s%d_v%d' % (ss, vc)]) < 1e-11
+            # the reference's own entry point and its counters (multigrid.py:184-197)
+            before = mg.num_applies
+            assert np.array_equal(mg._matvec(b), mg @ b)
+            assert mg.num_applies == before + 2 and mg.time_per_apply() > 0
     fam = MultiGridFamily(m['A_x'], m['M_x'], hier, ca=0.3,
                           cms=[2**j for j in range(4)], smoothsteps=3,
                           vcycles=2)
@@ -3006,9 +3010,12 @@ def test_direct_inverse_above_the_dense_limit(stk):
         lv_l, lv_u, launches = op.levels()
         # the narrow levels near the root are one dense block: a few dozen launches
         assert lv_l > 100 and lv_u > 100 and op.n_top > 100 and launches < 0.1 * (lv_l + lv_u), (lv_l, lv_u, launches)
-        by_levels = InvLinOp(mat)
-        by_levels.dense_top = False
-        assert by_levels.levels()[2] > launches
+        InvLinOp.dense_top = False  # (the plan is built at construction)
+        try:
+            by_levels = InvLinOp(mat)
+        finally:
+            InvLinOp.dense_top = True
+        assert by_levels.n_top == 0 and by_levels.levels()[2] > launches
         lu = splu(sp.csc_matrix(mat), options={"SymmetricMode": True}, permc_spec="MMD_AT_PLUS_A")
         cols = {}
         for n_loc in (5, 2, 9, 33):
