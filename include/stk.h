@@ -626,14 +626,18 @@ int stk_lu_solve(stk_lu *lu, void *stream, int32_t n_loc, int32_t ld,
  * (770 of the 802 levels of A_x at J_space = 6 hold 2 578 of its 16 129 rows).  The plan
  * names them -- S = the rows from the first narrow level of L on, ascending
  * (stk_lu_top_rows; n_top = 0: no such block, or U's rows of S reach outside S) -- and a
- * caller that hands over the inverses of the two diagonal blocks L[S, S] and U[S, S]
- * (n_top x n_top, row-major, DEVICE; the plan copies them) turns every solve into
- *   head levels, d_S = (Pr b)_S - L[S, H] y_H, y_S = L_SS^-1 d_S;   z_S = U_SS^-1 y_S, head levels
- * with the dense products as one launch each.  Without the call the plan walks every
- * level (a run of narrow levels in one workgroup). */
+ * caller that hands over the two blocks L[S, S] and U[S, S] as dense matrices (n_top x
+ * n_top, row-major, DEVICE; the plan copies them) whose DIAGONAL BLOCKS of `block` rows
+ * are replaced by their inverses turns every solve into
+ *   head levels, d_S = (Pr b)_S - L[S, H] y_H, per block k ascending: y_k = inv(L_kk) (d_k - L[k, <k] y_<k);
+ *   per block k descending: z_k = inv(U_kk) (y_k - U[k, >k] z_>k), head levels
+ * with one launch per block.  block = n_top: the explicit inverses of the whole blocks
+ * (two launches per solve, five to ten times the rounding error of substitution); 256
+ * keeps the accuracy of substitution.  Without the call the plan walks every level (a
+ * run of narrow levels in one workgroup). */
 int stk_lu_top_rows(const stk_lu *lu, int32_t *n_top, int32_t *rows_host);
-int stk_lu_set_top_inverse(stk_lu *lu, const double *L_inv_dev,
-                           const double *U_inv_dev);
+int stk_lu_set_top_inverse(stk_lu *lu, const double *L_blocks_dev,
+                           const double *U_blocks_dev, int32_t block);
 
 /* ---- (A_t kron I) for a small sparse time matrix ---------------------------
  * y[., t] = (add_identity ? x[., t] : 0) + sum_e val[e] * src(col[e]) over the

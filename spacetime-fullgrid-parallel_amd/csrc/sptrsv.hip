@@ -229,47 +229,54 @@ int solve(hipStream_t st, const TriDev &t, int32_t n_loc, int32_t ld, const int3
 
 // ---- the top of the elimination tree as a dense block ------------------------------
 // The narrow levels are the separators near the root: a few thousand rows that depend on
-// each other almost densely, one row after the other.  Their diagonal blocks L_SS and
-// U_SS (S = the rows from the first narrow level of L on; ancestors of a row of S are in
-// S) are inverted once (stk_lu_set_top_inverse: the caller inverts, e.g. with a dense
-// triangular solve on the device), and the hundreds of dependent levels become
-//   forward:  head levels;  d_S = (Pr b)_S - L_SH y_H  (one launch);  y_S = L_SS^-1 d_S
-//   backward: z_S = U_SS^-1 y_S;  head levels (their rows read z_S like any column)
-// with the dense products as one launch each: out[i] = sum_j inv[i][j] in[S[j]], SP lanes
-// per (row, time step), lane s taking j = s, s + SP, ... -- a fixed shape again.
-__global__ __launch_bounds__(256) void dense_top_kernel(int32_t n_top, const int32_t *__restrict__ rows,
-                                                        const double *__restrict__ inv, int lower, int32_t n_loc,
-                                                        int32_t ld, const double *__restrict__ in,
-                                                        double *__restrict__ scratch)
+// each other almost densely, one row after the other.  S = the rows from the first narrow
+// level of L on (ancestors of a row of S are in S).  The caller hands the blocks L[S, S] and
+// U[S, S] over as dense matrices whose DIAGONAL BLOCKS of `block` rows are replaced by their
+// inverses (stk_lu_set_top_inverse), and the hundreds of dependent levels become
+//   forward:  head levels;  d_S = (Pr b)_S - L_SH y_H  (one launch);
+//             per block k, ascending:   t = d_k - L[k, <k] y_<k;   y_k = inv(L_kk) t
+//   backward: per block k, descending:  t = y_k - U[k, >k] z_>k;   z_k = inv(U_kk) t;
+//             head levels (their rows read z_S like any column)
+// two launches per block (the product with the solved part, the block's inverse), each spread
+// over the chip.
+// Blocks of 256 rows keep the accuracy of substitution (an explicit inverse of the whole
+// 2 578-row block is 5-10 times less accurate, 1.4e-15 against 2e-16 -- enough to move the
+// last entry of a converged r.Pr history by 6e-11).  SP lanes per
+// row, lane s taking the columns s, s + SP, ...: one summation shape whatever the slab.
+// phase 0: scratch[i - a][t] = u[S[i]][t] - sum_{j outside the block, on its solved side} mat[i][j] u[S[j]][t]
+// phase 1: u[S[i]][t] = sum_{j in the block} inv_block[i][j] scratch[j - a][t]
+// one (row, time step) item per SP lanes, the items of a launch spread over the chip.
+__global__ __launch_bounds__(256) void block_top_kernel(int32_t n_top, const int32_t *__restrict__ rows,
+                                                        const double *__restrict__ mat, int32_t a, int32_t e,
+                                                        int lower, int phase, int32_t n_loc, int32_t ld, double *u,
+                                                        double *scratch, const int32_t *__restrict__ dst_perm,
+                                                        double *out)
 {
     const int lane_s = threadIdx.x & (SP - 1);
     const int64_t item = ((int64_t)blockIdx.x * 256 + threadIdx.x) / SP;  // whole lane groups are in or out
-    if (item >= (int64_t)n_top * n_loc) return;
-    const int i = (int)(item / n_loc), t = (int)(item - (int64_t)i * n_loc);
-    const int j0 = lower ? 0 : i, j1 = lower ? i + 1 : n_top;
-    const double *r = inv + (size_t)i * n_top;
+    if (item >= (int64_t)(e - a) * n_loc) return;
+    const int i = a + (int)(item / n_loc), t = (int)(item - (int64_t)(i - a) * n_loc);
+    const double *r = mat + (size_t)i * n_top;
     double acc = 0.0;
-    for (int j = j0 + lane_s; j < j1; j += SP) acc = fma(r[j], in[(size_t)rows[j] * ld + t], acc);
+    if (phase == 0) {
+        const int j0 = lower ? 0 : e, j1 = lower ? a : n_top;
+        for (int j = j0 + lane_s; j < j1; j += SP) acc = fma(r[j], u[(size_t)rows[j] * ld + t], acc);
+    } else {
+        const int j0 = lower ? a : i, j1 = lower ? i + 1 : e;
+        for (int j = j0 + lane_s; j < j1; j += SP) acc = fma(r[j], scratch[(size_t)(j - a) * n_loc + t], acc);
+    }
 #pragma unroll
     for (int off = SP / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off, SP);
-    if (lane_s == 0) scratch[(size_t)i * n_loc + t] = acc;
-}
-
-// u[S[i]] = scratch[i] (and out[dst[S[i]]] with its padding, for the backward solve)
-__global__ __launch_bounds__(256) void scatter_top_kernel(int32_t n_top, const int32_t *__restrict__ rows,
-                                                          int32_t n_loc, int32_t ld,
-                                                          const double *__restrict__ scratch, double *u,
-                                                          const int32_t *__restrict__ dst_perm, double *out)
-{
-    const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (item >= (int64_t)n_top * n_loc) return;
-    const int i = (int)(item / n_loc), t = (int)(item - (int64_t)i * n_loc);
-    const double v = scratch[item];
+    if (lane_s != 0) return;
     const int k = rows[i];
-    u[(size_t)k * ld + t] = v;
+    if (phase == 0) {
+        scratch[(size_t)(i - a) * n_loc + t] = u[(size_t)k * ld + t] - acc;
+        return;
+    }
+    u[(size_t)k * ld + t] = acc;
     if (dst_perm) {
         double *o = out + (size_t)dst_perm[k] * ld;
-        o[t] = v;
+        o[t] = acc;
         if (t == n_loc - 1)
             for (int tt = n_loc; tt < ld; ++tt) o[tt] = 0.0;
     }
@@ -288,7 +295,8 @@ struct stk_lu {
     int32_t *top_rows = nullptr;
     TriDev L_head, L_top, U_head;  // L_top: rows of S, entries outside S (one level, a product)
     double *L_inv = nullptr, *U_inv = nullptr;  // [n_top][n_top] row-major, set by the caller
-    double *scratch = nullptr;
+    int32_t top_block = 0;                       // rows of a diagonal block (inverted in place)
+    double *scratch = nullptr;                   // [top_block][n_loc] between the two launches of a block
     int64_t scratch_doubles = 0;
 };
 
@@ -377,9 +385,11 @@ extern "C" int stk_lu_top_rows(const stk_lu *lu, int32_t *n_top, int32_t *rows_h
     return 0;
 }
 
-extern "C" int stk_lu_set_top_inverse(stk_lu *lu, const double *L_inv_dev, const double *U_inv_dev)
+extern "C" int stk_lu_set_top_inverse(stk_lu *lu, const double *L_inv_dev, const double *U_inv_dev, int32_t block)
 {
     STK_REQUIRE(lu && lu->n_top > 0 && L_inv_dev && U_inv_dev, "stk_lu_set_top_inverse: the plan has no dense top");
+    STK_REQUIRE(block >= 1 && block <= 8192, "stk_lu_set_top_inverse: blocks of %d rows (1 .. 8192)", block);
+    lu->top_block = block < lu->n_top ? block : lu->n_top;
     const size_t bytes = sizeof(double) * (size_t)lu->n_top * lu->n_top;
     if (!lu->L_inv) STK_HIP(hipMalloc((void **)&lu->L_inv, bytes));
     if (!lu->U_inv) STK_HIP(hipMalloc((void **)&lu->U_inv, bytes));
@@ -396,7 +406,8 @@ extern "C" int stk_lu_info(const stk_lu *lu, int32_t *levels_L, int32_t *levels_
     if (launches) {
         if (lu->L_inv && lu->U_inv)
             *launches = (int32_t)(lu->L_head.segments.size() + lu->L_top.segments.size() +
-                                  lu->U_head.segments.size() + 4);
+                                  lu->U_head.segments.size() +
+                                  4 * ((lu->n_top + lu->top_block - 1) / lu->top_block));
         else
             *launches = (int32_t)(lu->L.segments.size() + lu->U.segments.size());
     }
@@ -417,27 +428,28 @@ extern "C" int stk_lu_solve(stk_lu *lu, void *stream, int32_t n_loc, int32_t ld,
         if (rc) return rc;
         return solve(st, lu->U, n_loc, ld, nullptr, work, work, lu->dst_perm, x);
     }
-    const int64_t need = (int64_t)lu->n_top * n_loc;
+    const int nb = lu->top_block, n_blocks = (lu->n_top + nb - 1) / nb;
+    const int64_t need = (int64_t)nb * n_loc;
     if (lu->scratch_doubles < need) {
         if (lu->scratch) STK_HIP(hipFree(lu->scratch));
         lu->scratch = nullptr, lu->scratch_doubles = 0;
         STK_HIP(hipMalloc((void **)&lu->scratch, sizeof(double) * (size_t)need));
         lu->scratch_doubles = need;
     }
-    const unsigned g_dense = (unsigned)((need * SP + 255) / 256), g_copy = (unsigned)((need + 255) / 256);
+    auto block = [&](int k, int lower, const double *mat, const int32_t *dst, double *out) {
+        const int a = k * nb, e = std::min((k + 1) * nb, (int)lu->n_top);
+        const unsigned grid = (unsigned)(((int64_t)(e - a) * n_loc * SP + 255) / 256);
+        for (int phase = 0; phase < 2; ++phase)
+            hipLaunchKernelGGL(block_top_kernel, dim3(grid), dim3(256), 0, st, lu->n_top, lu->top_rows, mat, a, e, lower,
+                               phase, n_loc, ld, work, lu->scratch, phase ? dst : nullptr, out);
+    };
     // forward
     int rc = solve(st, lu->L_head, n_loc, ld, lu->src_perm, b, work, nullptr, nullptr);
     if (rc == 0) rc = solve(st, lu->L_top, n_loc, ld, lu->src_perm, b, work, nullptr, nullptr);  // d_S into work
     if (rc) return rc;
-    hipLaunchKernelGGL(dense_top_kernel, dim3(g_dense), dim3(256), 0, st, lu->n_top, lu->top_rows, lu->L_inv, 1, n_loc,
-                       ld, work, lu->scratch);
-    hipLaunchKernelGGL(scatter_top_kernel, dim3(g_copy), dim3(256), 0, st, lu->n_top, lu->top_rows, n_loc, ld,
-                       lu->scratch, work, (const int32_t *)nullptr, (double *)nullptr);
+    for (int k = 0; k < n_blocks; ++k) block(k, 1, lu->L_inv, nullptr, nullptr);
     // backward
-    hipLaunchKernelGGL(dense_top_kernel, dim3(g_dense), dim3(256), 0, st, lu->n_top, lu->top_rows, lu->U_inv, 0, n_loc,
-                       ld, work, lu->scratch);
-    hipLaunchKernelGGL(scatter_top_kernel, dim3(g_copy), dim3(256), 0, st, lu->n_top, lu->top_rows, n_loc, ld,
-                       lu->scratch, work, lu->dst_perm, x);
+    for (int k = n_blocks - 1; k >= 0; --k) block(k, 0, lu->U_inv, lu->dst_perm, x);
     STK_LAUNCH_CHECK();
     return solve(st, lu->U_head, n_loc, ld, nullptr, work, work, lu->dst_perm, x);
 }

@@ -148,7 +148,7 @@ _PROTOTYPES = {
     'stk_lu_destroy': (ctypes.c_int, [c_p]),
     'stk_lu_info': (ctypes.c_int, [c_p, c_p, c_p, c_p]),
     'stk_lu_top_rows': (ctypes.c_int, [c_p, c_p, c_p]),
-    'stk_lu_set_top_inverse': (ctypes.c_int, [c_p, c_p, c_p]),
+    'stk_lu_set_top_inverse': (ctypes.c_int, [c_p, c_p, c_p, c_i32]),
     'stk_lu_solve': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_p, c_p, c_p]),
     'stk_lanczos_slab_work_size': (c_i64, [c_i32, c_i32, c_i32, c_i32]),
     'stk_lanczos_slab': (ctypes.c_int, [

@@ -133,7 +133,15 @@ class InvLinOp(SpaceOp):
     # inverted at set-up: hundreds of dependent levels become two dense products
     # (csrc/sptrsv.hip).  False: every level by itself (the comparison partner of the tests).
     dense_top = True
-    DENSE_TOP_MAX = 8192  # rows of the block (its two inverses: 2 x 512 MiB at most)
+    DENSE_TOP_MAX = 8192  # rows of the block (its two dense copies: 2 x 512 MiB at most)
+    # Rows of a diagonal block that is inverted: substitution from block to block, an explicit
+    # inverse inside one.  The whole block (the default: TOP_BLOCK >= n_top) is two launches per
+    # solve direction -- K^-1 0.35 ms at M = 16 129 -- with 5-10 times the rounding error of
+    # substitution (1.4e-15 against 2e-16), which moves the LAST entry of a converged r.Pr
+    # history, 1e-13 of the first, by 5.8e-11; blocks of 256 rows keep the accuracy of
+    # substitution (3.1e-11 there) for 79 launches and 0.93 ms
+    # (profiles/r06_direct_parity_forms*.log, r06_direct_solve_time*.log).
+    TOP_BLOCK = 8192
     n_top = 0
 
     def __init__(self, mat):
@@ -174,13 +182,19 @@ class InvLinOp(SpaceOp):
                 rows = np.empty(n_top.value, dtype=np.int32)
                 _lib.check(lib.stk_lu_top_rows(plan, ctypes.byref(n_top), rows.ctypes.data))
                 blocks = []
+                nb = min(self.TOP_BLOCK, n_top.value)
                 for T, lower, unit in ((L, 1, 1), (U, 0, 0)):
-                    # LAPACK's triangular inverse on the host, at set-up like the
-                    # factorisation itself (hipBLAS' trsm fails to allocate on this image)
-                    inv, info = dtrtri(np.asfortranarray(T[rows][:, rows].toarray()), lower=lower, unitdiag=unit)
-                    assert info == 0, info
-                    blocks.append(_lib.to_dev(np.ascontiguousarray(inv)))
-                _lib.check(lib.stk_lu_set_top_inverse(plan, _lib.ptr(blocks[0]), _lib.ptr(blocks[1])))
+                    # the block as a dense matrix with its DIAGONAL BLOCKS of nb rows inverted
+                    # (LAPACK's triangular inverse on the host, at set-up like the
+                    # factorisation itself; hipBLAS' trsm fails to allocate on this image)
+                    dense = np.ascontiguousarray(T[rows][:, rows].toarray())
+                    for a in range(0, n_top.value, nb):
+                        e = min(a + nb, n_top.value)
+                        inv, info = dtrtri(np.asfortranarray(dense[a:e, a:e]), lower=lower, unitdiag=unit)
+                        assert info == 0, info
+                        dense[a:e, a:e] = inv
+                    blocks.append(_lib.to_dev(dense))
+                _lib.check(lib.stk_lu_set_top_inverse(plan, _lib.ptr(blocks[0]), _lib.ptr(blocks[1]), nb))
                 self.n_top = int(n_top.value)
             self._plan = plan
         return self._plan

@@ -15,13 +15,16 @@ from source.linop import InvLinOp  # noqa: E402
 
 g = np.load(os.path.join(REPO, 'tests', 'golden', 'o1_pcg_square_J3_J6_direct.npz'))
 ref = np.asarray(g['hist'])
-for name, dense_top, host in (('dense top block', True, False), ('every level by itself', False, False),
-                              ('SuperLU on the host', True, True)):
-    InvLinOp.dense_top, InvLinOp.host_solve = dense_top, host
+default_block = InvLinOp.TOP_BLOCK
+for name, dense_top, host, block in (('dense top, whole block inverted', True, False, default_block),
+                                     ('dense top, blocks of 256', True, False, 256),
+                                     ('every level by itself', False, False, default_block),
+                                     ('SuperLU on the host', True, True, default_block)):
+    InvLinOp.dense_top, InvLinOp.host_solve, InvLinOp.TOP_BLOCK = dense_top, host, block
     try:
         h = hm.HeatEquationMPI(J_space=6, J_time=3, precond='direct')
     finally:
-        InvLinOp.dense_top, InvLinOp.host_solve = True, False
+        InvLinOp.dense_top, InvLinOp.host_solve, InvLinOp.TOP_BLOCK = True, False, default_block
     for op in [h.Kinv_x] + list(h.C_j):
         op.host_solve = host
     hist = []
