@@ -570,6 +570,131 @@ __global__ __launch_bounds__(256) void kron_pack_ghost_kernel(const PackArgs<NT>
     }
 }
 
+// The same two boundary steps from COMPACT operands (round 6): the pack kernel that
+// extracts the rows a rank sends (stk_halo_pack_records) also leaves, per spatial dof j,
+// rec[j] = (x[j][0], x[j][1], x[j][n_loc-2], x[j][n_loc-1]) -- 32 bytes -- and the received
+// rows arrive interleaved, gh[j] = (x_lo[j], x_hi[j]).  A lane then serves BOTH sides of a
+// slot row with three 16-byte loads per slot from two lines, where the kernel above issues
+// six 8-byte gathers per slot (two lanes) over four to six lines of the slab: the gathers
+// of this kernel are bound by their number, not by their bytes (0.069 / 0.130 / 0.079 ms at 9
+// / 17 / 33 steps of 1 046 529 rows against the times in DESIGN.md section 4).  Same sums,
+// same order: bit for bit the kernel above and the one-pass form.
+template <int NT, int K, int RP>
+__global__ __launch_bounds__(256) void kron_pack_boundary_kernel(const PackArgs<NT> a, const double4 *__restrict__ rec,
+                                                                 const double2 *__restrict__ gh, int has_lo,
+                                                                 int has_hi)
+{
+    extern __shared__ double sm[];
+    double *s_dict = sm;  // [n_codes][RP][NT]
+    if (a.vals == nullptr) {
+        for (int i = threadIdx.x; i < a.n_codes * RP * NT; i += 256) {
+            const int c = i / NT, k = i - c * NT;
+            s_dict[i] = a.dict[k][c];
+        }
+    }
+    __syncthreads();
+    const int n = a.n_loc;
+    double sub0[NT], dia0[NT], sup0[NT], sub1[NT], dia1[NT], sup1[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        const double *t = a.tri[k];
+        sub0[k] = t ? t[0] : 0.0, dia0[k] = t ? t[n] : 1.0, sup0[k] = t ? t[2 * n] : 0.0;
+        sub1[k] = t ? t[n - 1] : 0.0, dia1[k] = t ? t[n + n - 1] : 1.0, sup1[k] = t ? t[2 * n + n - 1] : 0.0;
+    }
+    const uint32_t col_mask = (1u << a.col_bits) - 1u;
+    const int stride = gridDim.x * 256;
+    for (int u = blockIdx.x * 256 + threadIdx.x; u < a.n_units; u += stride) {
+        uint32_t sl[K];
+#pragma unroll
+        for (int q = 0; q < K; ++q) sl[q] = a.slots[(size_t)u * K + q];
+        // z[side-step][row of the pair][term]: 0 = lo, 1 = x0, 2 = x1, 3 = x_{n-2}, 4 = x_{n-1}, 5 = hi
+        double z[6][RP][NT];
+#pragma unroll
+        for (int w = 0; w < 6; ++w)
+#pragma unroll
+            for (int j = 0; j < RP; ++j)
+#pragma unroll
+                for (int k = 0; k < NT; ++k) z[w][j][k] = 0.0;
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            const size_t col = sl[q] & col_mask;
+            const double4 r = rec[col];
+            const double2 g = gh[col];
+            const double xs[6] = {g.x, r.x, r.y, r.z, r.w, g.y};
+            const double *dv = a.vals ? a.vals + ((size_t)u * K + q) * RP * NT
+                                      : s_dict + (sl[q] >> a.col_bits) * (RP * NT);
+#pragma unroll
+            for (int j = 0; j < RP; ++j)
+#pragma unroll
+                for (int k = 0; k < NT; ++k) {
+                    const double v = dv[j * NT + k];
+#pragma unroll
+                    for (int w = 0; w < 6; ++w) z[w][j][k] = fma(v, xs[w], z[w][j][k]);
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < RP; ++j) {
+            const int row = a.row_ids ? a.row_ids[(size_t)u * RP + j] : u;
+            if (row < 0) continue;
+            double y_lo = 0.0, y_hi = 0.0;
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                if (a.tri[k] != nullptr) {
+                    // one step: both received rows meet in it (z[5] is its upper neighbour)
+                    double v = dia0[k] * z[1][j][k];
+                    v = fma(sub0[k], z[0][j][k], v);
+                    v = fma(sup0[k], n > 1 ? z[2][j][k] : z[5][j][k], v);
+                    y_lo += v;
+                    double w = dia1[k] * z[4][j][k];
+                    w = fma(sub1[k], z[3][j][k], w);
+                    w = fma(sup1[k], z[5][j][k], w);
+                    y_hi += w;
+                } else {
+                    y_lo += z[1][j][k];
+                    y_hi += z[4][j][k];
+                }
+            }
+            double *yr = a.y + (size_t)row * a.ld;
+            if (has_lo || n == 1) yr[0] = y_lo;
+            if (has_hi && n > 1) yr[n - 1] = y_hi;
+        }
+    }
+}
+
+template <int NT, int RP>
+int launch_boundary(hipStream_t st, const PackArgs<NT> &a, int K, const double *rec, const double *gh, int has_lo,
+                    int has_hi)
+{
+    const size_t lds = sizeof(double) * (a.vals ? 0 : (size_t)a.n_codes * RP * NT) + 16;
+    const unsigned grid = stk_flat_grid(a.n_units, 256);
+#define STK_BOUNDARY_CASE(KK)                                                                                     \
+    case KK:                                                                                                      \
+        hipLaunchKernelGGL((kron_pack_boundary_kernel<NT, KK, RP>), dim3(grid), dim3(256), lds, st, a,            \
+                           reinterpret_cast<const double4 *>(rec), reinterpret_cast<const double2 *>(gh), has_lo, \
+                           has_hi);                                                                               \
+        break;
+    if constexpr (RP == 1) {
+        switch (K) {
+            STK_BOUNDARY_CASE(5)
+            STK_BOUNDARY_CASE(7)
+            STK_BOUNDARY_CASE(9)
+            STK_BOUNDARY_CASE(12)
+            STK_BOUNDARY_CASE(16)
+            default: stk_set_error("stk_kron_pack_boundary_apply: K=%d is not one of 5, 7, 9, 12, 16", K); return 2;
+        }
+    } else {
+        switch (K) {
+            STK_BOUNDARY_CASE(8)
+            STK_BOUNDARY_CASE(10)
+            STK_BOUNDARY_CASE(12)
+            default: stk_set_error("stk_kron_pack_boundary_apply: K=%d is not one of 8, 10, 12 (row pairs)", K); return 2;
+        }
+    }
+#undef STK_BOUNDARY_CASE
+    STK_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int NT, int RP>
 int launch_ghost_only(hipStream_t st, const PackArgs<NT> &a, int K, const double *lo, const double *hi)
 {
@@ -630,6 +755,33 @@ int dispatch_ghost_only(hipStream_t st, const stk_pack_pattern *pat, int32_t n_l
     }
     return pat->rows_per_unit == 2 ? launch_ghost_only<NT, 2>(st, a, pat->K, lo, hi)
                                    : launch_ghost_only<NT, 1>(st, a, pat->K, lo, hi);
+}
+
+template <int NT>
+int dispatch_boundary(hipStream_t st, const stk_pack_pattern *pat, int32_t n_loc, int32_t ld,
+                      const stk_kron_pack_term *t, const double *rec, const double *gh, int has_lo, int has_hi,
+                      double *y)
+{
+    PackArgs<NT> a;
+    std::memset(&a, 0, sizeof(a));
+    a.slots = pat->slots;
+    a.row_ids = pat->row_ids;
+    a.y = y;
+    a.M = pat->M;
+    a.n_units = pat->n_units;
+    a.n_loc = n_loc;
+    a.ld = ld;
+    a.col_bits = pat->col_bits;
+    a.n_codes = pat->n_codes;
+    a.vals = pat->vals;
+    a.n_mats = pat->n_mats;
+    for (int k = 0; k < NT; ++k) {
+        a.dict[k] = pat->vals ? nullptr : pat->dict + (size_t)t[k].mat * pat->n_codes * pat->rows_per_unit;
+        a.tri[k] = t[k].tri;
+        a.mat[k] = t[k].mat;
+    }
+    return pat->rows_per_unit == 2 ? launch_boundary<NT, 2>(st, a, pat->K, rec, gh, has_lo, has_hi)
+                                   : launch_boundary<NT, 1>(st, a, pat->K, rec, gh, has_lo, has_hi);
 }
 
 __global__ __launch_bounds__(256) void interleave_ghosts_kernel(int32_t M, const double *__restrict__ lo,
@@ -1007,5 +1159,40 @@ extern "C" int stk_kron_pack_ghost_apply(void *stream, const stk_pack_pattern *p
         case 1: return dispatch_ghost_only<1>(st, pat, n_loc, ld, t, x, x_lo, x_hi, y);
         case 2: return dispatch_ghost_only<2>(st, pat, n_loc, ld, t, x, x_lo, x_hi, y);
         default: return dispatch_ghost_only<3>(st, pat, n_loc, ld, t, x, x_lo, x_hi, y);
+    }
+}
+
+extern "C" int stk_kron_pack_boundary_apply(void *stream, const stk_pack_pattern *pat, int32_t n_loc, int32_t ld,
+                                            int32_t n_terms, const stk_kron_pack_term *t, const double *records,
+                                            const double *ghosts, int32_t has_lo, int32_t has_hi, double *y)
+{
+    const stk_timed timed_(STK_OP_KRON, stream);
+    STK_REQUIRE(pat && t && records && ghosts && y, "stk_kron_pack_boundary_apply: null pointer");
+    if (!has_lo && !has_hi) return 0;
+    STK_REQUIRE(pat->M > 0 && pat->K >= 1 && pat->slots && (pat->dict || pat->vals) && pat->n_units > 0,
+                "stk_kron_pack_boundary_apply: bad pattern");
+    STK_REQUIRE(pat->rows_per_unit == 1 || (pat->rows_per_unit == 2 && pat->row_ids),
+                "stk_kron_pack_boundary_apply: rows_per_unit=%d", pat->rows_per_unit);
+    STK_REQUIRE(n_loc > 0 && ld >= n_loc, "stk_kron_pack_boundary_apply: bad sizes n_loc=%d ld=%d", n_loc, ld);
+    STK_REQUIRE(n_terms >= 1 && n_terms <= 3, "stk_kron_pack_boundary_apply: n_terms=%d not in 1..3", n_terms);
+    STK_REQUIRE((((uintptr_t)records & 31) | ((uintptr_t)ghosts & 15)) == 0,
+                "stk_kron_pack_boundary_apply: records must be 32-byte, ghosts 16-byte aligned");
+    STK_REQUIRE(pat->vals || sizeof(double) * (size_t)pat->n_codes * pat->rows_per_unit * n_terms <= 60 * 1024,
+                "stk_kron_pack_boundary_apply: dictionary too large");
+    if (pat->vals) {
+        STK_REQUIRE(pat->n_mats == n_terms, "stk_kron_pack_boundary_apply: explicit values list %d matrices for %d terms",
+                    pat->n_mats, n_terms);
+        for (int k = 0; k < n_terms; ++k)
+            STK_REQUIRE(t[k].mat == k, "stk_kron_pack_boundary_apply: with explicit values term %d must name matrix %d",
+                        k, k);
+    }
+    for (int k = 0; k < n_terms; ++k)
+        STK_REQUIRE(t[k].mat >= 0 && t[k].mat < pat->n_mats,
+                    "stk_kron_pack_boundary_apply: term %d names matrix %d of %d", k, t[k].mat, pat->n_mats);
+    hipStream_t st = stk_stream(stream);
+    switch (n_terms) {
+        case 1: return dispatch_boundary<1>(st, pat, n_loc, ld, t, records, ghosts, has_lo, has_hi, y);
+        case 2: return dispatch_boundary<2>(st, pat, n_loc, ld, t, records, ghosts, has_lo, has_hi, y);
+        default: return dispatch_boundary<3>(st, pat, n_loc, ld, t, records, ghosts, has_lo, has_hi, y);
     }
 }

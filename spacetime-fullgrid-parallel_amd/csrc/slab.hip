@@ -65,6 +65,25 @@ __global__ __launch_bounds__(256) void halo_pack_kernel(int32_t M, int32_t n_loc
     }
 }
 
+// ... and the four entries of every row that the boundary steps of a Kronecker apply read once the halo is
+// there (stk_kron_pack_boundary_apply): rec[j] = (x[j][0], x[j][1], x[j][n_loc-2], x[j][n_loc-1]), from the same
+// two lines of the row (slabs of one step repeat it)
+__global__ __launch_bounds__(256) void halo_pack_records_kernel(int32_t M, int32_t n_loc, int32_t ld,
+                                                                const double *__restrict__ x, double *first,
+                                                                int32_t s_first, double *last, int32_t s_last,
+                                                                double4 *__restrict__ rec)
+{
+    const int stride = gridDim.x * 256;
+    const int t1 = n_loc > 1 ? 1 : 0, t2 = n_loc > 1 ? n_loc - 2 : 0;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < M; j += stride) {
+        const double *row = x + (size_t)j * ld;
+        const double a = row[0], b = row[t1], c = row[t2], d = row[n_loc - 1];
+        if (first) first[(size_t)j * s_first] = a;
+        if (last) last[(size_t)j * s_last] = d;
+        rec[j] = make_double4(a, b, c, d);
+    }
+}
+
 // out[k * ld_out + j] = x[j][t_idx[k]]: the time rows `communicate_dofs` sends
 // (mpi_vector.py:189-203), all of them from one pass over the slab
 __global__ __launch_bounds__(256) void extract_rows_kernel(int32_t M, int32_t n_rows, const int32_t *__restrict__ t_idx,
@@ -196,6 +215,18 @@ extern "C" int stk_halo_pack(void *stream, int32_t M, int32_t n_loc, int32_t ld,
                 "stk_halo_pack: no destination, or a stride below 1");
     hipLaunchKernelGGL(halo_pack_kernel, dim3(stk_flat_grid(M, 256)), dim3(256), 0, stk_stream(stream), M, n_loc, ld,
                        x, first, stride_first, last, stride_last);
+    STK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int stk_halo_pack_records(void *stream, int32_t M, int32_t n_loc, int32_t ld, const double *x, double *first,
+                                     int32_t stride_first, double *last, int32_t stride_last, double *records)
+{
+    STK_REQUIRE(M > 0 && n_loc > 0 && ld >= n_loc && x && records, "stk_halo_pack_records: bad arguments");
+    STK_REQUIRE((!first || stride_first >= 1) && (!last || stride_last >= 1), "stk_halo_pack_records: a stride below 1");
+    STK_REQUIRE(((uintptr_t)records & 31) == 0, "stk_halo_pack_records: records must be 32-byte aligned");
+    hipLaunchKernelGGL(halo_pack_records_kernel, dim3(stk_flat_grid(M, 256)), dim3(256), 0, stk_stream(stream), M,
+                       n_loc, ld, x, first, stride_first, last, stride_last, reinterpret_cast<double4 *>(records));
     STK_LAUNCH_CHECK();
     return 0;
 }

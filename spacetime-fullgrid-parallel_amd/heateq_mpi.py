@@ -116,11 +116,12 @@ class SchurMPI(LinearOperatorMPI):
                     and _FusedKronSum.overlap and n_loc >= _FusedKronSum.OVERLAP_FROM):
                 # the pass over the slab without the ghost steps while the halo is
                 # in flight (reference mpi_kron.py:193-200), the two boundary steps
-                # afterwards (long slabs only: see _FusedKronSum.OVERLAP_FROM)
+                # afterwards, from the compact records the pack leaves (_FusedKronSum.OVERLAP_FROM)
                 self.time_communication = vec_in.communicate_bdr(
-                    callback=lambda: packed.apply(first, x, None, n_loc, ld, 0.0, u))
-                packed.apply_ghost(first, x, vec_in.X_lo, vec_in.X_hi, n_loc, ld, u)
+                    callback=lambda: packed.apply(first, x, None, n_loc, ld, 0.0, u), records=True)
                 ghosts = vec_in.ghost_interleaved()
+                packed.apply_boundary(first, vec_in.boundary_records(), ghosts, vec_in.X_lo is not None,
+                                      vec_in.X_hi is not None, n_loc, ld, u)
             else:
                 if self.dofs_distr.size > 1:
                     self.time_communication = vec_in.communicate_bdr()

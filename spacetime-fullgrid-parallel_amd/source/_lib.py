@@ -180,6 +180,11 @@ _PROTOTYPES = {
         c_p, ctypes.POINTER(PackPattern), c_i32, c_i32, c_i32,
         ctypes.POINTER(KronPackTerm), c_p, c_p, c_p, c_p
     ]),
+    'stk_kron_pack_boundary_apply': (ctypes.c_int, [
+        c_p, ctypes.POINTER(PackPattern), c_i32, c_i32, c_i32,
+        ctypes.POINTER(KronPackTerm), c_p, c_p, c_i32, c_i32, c_p
+    ]),
+    'stk_halo_pack_records': (ctypes.c_int, [c_p, c_i32, c_i32, c_i32, c_p, c_p, c_i32, c_p, c_i32, c_p]),
     'stk_kron_pack_apply_multi': (ctypes.c_int, [
         c_p, ctypes.POINTER(PackPattern), c_i32, c_i32, c_i32,
         ctypes.POINTER(KronPackTerm), ctypes.POINTER(c_p), c_f64, c_p

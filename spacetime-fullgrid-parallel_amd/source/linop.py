@@ -918,6 +918,17 @@ class PackedEllMatrices:
             _lib.stream(), ctypes.byref(self._pattern_for(specs)), n_loc, ld, len(specs),
             self._terms(specs), _lib.ptr(x), _lib.ptr(x_lo), _lib.ptr(x_hi), _lib.ptr(out)))
 
+    def apply_boundary(self, specs, records, ghosts, has_lo, has_hi, n_loc, ld, out):
+        """apply_ghost from compact operands (stk_kron_pack_boundary_apply): `records` (M, 4) as
+        KronVectorMPI.communicate_bdr(records=True) leaves them, `ghosts` (M, 2) interleaved
+        received rows; the same doubles, 1.5-2 x faster."""
+        if not (has_lo or has_hi):
+            return
+        _lib.check(_lib.lib().stk_kron_pack_boundary_apply(
+            _lib.stream(), ctypes.byref(self._pattern_for(specs)), n_loc, ld, len(specs),
+            self._terms(specs), _lib.ptr(records), _lib.ptr(ghosts), int(bool(has_lo)), int(bool(has_hi)),
+            _lib.ptr(out)))
+
     def apply_multi(self, specs, n_loc, ld, beta, out, steps=None):
         """y = beta*y + sum over specs (tri, matrix index, x): every term reads a
         slab of its own, no ghost time steps (stk_kron_pack_apply_multi_steps); the

@@ -461,14 +461,15 @@ class _FusedKronSum:
     # wait for the halo, then one pass with the ghost steps as an extra lane per
     # row.  A halo that is already there (cached) always takes the one-pass form.
     # Both forms, and the one-rank kernel, round every entry the same way.
-    # Round 6: recomputing the two boundary steps (what makes the forms bit-equal)
-    # gathers 16 bytes per 128-byte line of the slab and costs 0.069 / 0.130 / 0.079 ms
-    # at 9 / 17 / 33 steps of 1 046 529 rows where adding a share cost 0.042 / 0.052 /
-    # 0.041 ms: beside a wire of 0.109 ms the overlapped form only wins on slabs whose
-    # pass is long enough to hide the wire, from OVERLAP_FROM steps on
+    # Round 6: the two boundary steps are RECOMPUTED (what makes the forms bit-equal).
+    # From the slab itself that gathers 16 bytes per 128-byte line and costs 0.069 / 0.130
+    # / 0.079 ms at 9 / 17 / 33 steps of 1 046 529 rows where adding a share cost 0.042 /
+    # 0.052 / 0.041 ms; from the compact records the pack kernel leaves beside the rows it
+    # extracts (stk_halo_pack_records, stk_kron_pack_boundary_apply) 0.038 / 0.038 / 0.035
+    # ms: the overlapped form wins on every slab length again
     # (profiles/r06_slab_shapes_J9.log, _J10.log).
     overlap = True
-    OVERLAP_FROM = 24
+    OVERLAP_FROM = 1
 
     @classmethod
     def max_terms(cls):
@@ -517,11 +518,13 @@ class _FusedKronSum:
                 # need the old values the pass has replaced -- one-pass form then)
                 time_comm = vec_in.communicate_bdr(callback=lambda: packed.apply(
                     specs, vec_in.buf, None, vec_in.n_loc, vec_in.ld, 0.0,
-                    vec_out.buf))
-                packed.apply_ghost(specs, vec_in.buf,
-                                   vec_in.X_lo if self.needs_lo else None,
-                                   vec_in.X_hi if self.needs_hi else None,
-                                   vec_in.n_loc, vec_in.ld, vec_out.buf)
+                    vec_out.buf), records=True)
+                # the two boundary steps from the compact records the pack left and the
+                # interleaved received rows: both sides in one lane per slot row
+                packed.apply_boundary(specs, vec_in.boundary_records(), vec_in.ghost_interleaved(),
+                                      self.needs_lo and vec_in.X_lo is not None,
+                                      self.needs_hi and vec_in.X_hi is not None,
+                                      vec_in.n_loc, vec_in.ld, vec_out.buf)
                 return time_comm
             if halo:
                 time_comm = vec_in.communicate_bdr()

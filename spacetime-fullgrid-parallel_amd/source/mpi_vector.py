@@ -299,7 +299,7 @@ class KronVectorMPI:
     def reset(self, initial_data=None):
         self.communicated_bdr = False
         # ghost time rows (the reference's X_loc_bdr[0] and X_loc_bdr[-1])
-        self.X_lo = self.X_hi = self._ghost = self._ghost_il = self._halo_send = None
+        self.X_lo = self.X_hi = self._ghost = self._ghost_il = self._halo_send = self._records = None
         self._notify_pending()
         dev = _lib.compute_device()
         if initial_data is None:
@@ -321,7 +321,7 @@ class KronVectorMPI:
         cpy.__dict__.update(self.__dict__)
         cpy._pending = None
         cpy.communicated_bdr = False
-        cpy.X_lo = cpy.X_hi = cpy._ghost = cpy._ghost_il = cpy._halo_send = None
+        cpy.X_lo = cpy.X_hi = cpy._ghost = cpy._ghost_il = cpy._halo_send = cpy._records = None
         cpy._buf = self.buf.clone()
         return cpy
 
@@ -330,7 +330,7 @@ class KronVectorMPI:
         out.__dict__.update(self.__dict__)
         out._pending = None
         out.communicated_bdr = False
-        out.X_lo = out.X_hi = out._ghost = out._ghost_il = out._halo_send = None
+        out.X_lo = out.X_hi = out._ghost = out._ghost_il = out._halo_send = out._records = None
         out._buf = torch.empty_like(self.buf)
         return out
 
@@ -493,7 +493,7 @@ class KronVectorMPI:
             comm.wait_all(comm.exchange([(mine.to(comm._device()), 0)], []))
 
     # -- communication -----------------------------------------------------------
-    def communicate_bdr(self, callback=None):
+    def communicate_bdr(self, callback=None, records=False):
         """Fetches the ghost time rows t_begin-1 and t_end from the neighbour
         ranks into X_lo / X_hi while `callback` computes what does not need
         them; cached until the vector is mutated
@@ -518,7 +518,16 @@ class KronVectorMPI:
                                               device=self.buf.device)
             first = self._halo_send[0] if rank > 0 else None
             last = self._halo_send[1] if rank + 1 < size else None
-            if self.buf.is_cuda:
+            if self.buf.is_cuda and records:
+                # ... and, from the same pass, per spatial dof the four entries the boundary
+                # steps of the overlapped Kronecker apply read (boundary_records)
+                if getattr(self, '_records', None) is None:
+                    self._records = torch.empty((self.M, 4), dtype=torch.float64,
+                                                device=self.buf.device)
+                _lib.check(_lib.lib().stk_halo_pack_records(
+                    _lib.stream(), self.M, self.n_loc, self.ld, _lib.ptr(self.buf),
+                    _lib.ptr(first), 1, _lib.ptr(last), 1, _lib.ptr(self._records)))
+            elif self.buf.is_cuda:
                 _lib.check(_lib.lib().stk_halo_pack(
                     _lib.stream(), self.M, self.n_loc, self.ld, _lib.ptr(self.buf),
                     _lib.ptr(first), 1, _lib.ptr(last), 1))
@@ -600,6 +609,12 @@ class KronVectorMPI:
         self.communicated_bdr = True
         self._ghost_il_stale = True
         return waited
+
+    def boundary_records(self):
+        """(M, 4) rows (x[j][0], x[j][1], x[j][n_loc-2], x[j][n_loc-1]) left by
+        communicate_bdr(records=True) -- valid until the vector changes."""
+        assert self.communicated_bdr and getattr(self, '_records', None) is not None
+        return self._records
 
     def ghost_pair(self):
         """(2, M) buffer [X_lo; X_hi] filled by communicate_bdr."""
@@ -713,7 +728,7 @@ class _ScaledVector(KronVectorMPI):
         self.__dict__.update(src.__dict__)
         self._pending = None
         self.communicated_bdr = False
-        self.X_lo = self.X_hi = self._ghost = self._halo_send = None
+        self.X_lo = self.X_hi = self._ghost = self._halo_send = self._records = None
         self._alpha, self._src, self._lazy = alpha, src, True
         self.__dict__.pop('_buf', None)
         if src._pending is None:

@@ -38,8 +38,9 @@ J_SPACE = int(os.environ.get('STK_TEST_J_SPACE', '8'))
 PROBLEM = os.environ.get('STK_TEST_PROBLEM', 'square')
 SETUP = threading.Lock()  # plan construction reads process-wide tuning keys: one rank at a time
 # The overlapped halo form (pass without the ghost steps beside the exchange, boundary
-# steps recomputed afterwards) is the default from 24 steps on; these runs take it on every
-# slab unless told otherwise: bit for bit the one-pass form and the one-rank kernel.
+# steps recomputed afterwards from the records the pack leaves) is the default; one case of
+# the test asks for the other form (STK_TEST_OVERLAP_FROM above every slab length: wait, one
+# pass with ghost lanes): both are bit for bit the one-rank kernel.
 from source.mpi_kron import _FusedKronSum  # noqa: E402
 _FusedKronSum.OVERLAP_FROM = int(os.environ.get('STK_TEST_OVERLAP_FROM', '1'))
 _X = {}

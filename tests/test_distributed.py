@@ -96,8 +96,8 @@ def test_baseline_config_in_its_eight_rank_shape_equals_the_one_rank_solve(J_tim
     17 steps of 4 190 209 rows (72 s on the box; eight sets of plans on the one card)."""
     env = dict(os.environ, STK_TEST_THREAD_RANKS=str(ranks), STK_TEST_J_TIME=str(J_time),
                STK_TEST_J_SPACE=str(J_space), OMP_NUM_THREADS='1')
-    if ranks == 3:  # the default choice of the halo form (one pass with ghost lanes below 24 steps)
-        env['STK_TEST_OVERLAP_FROM'] = '24'
+    if ranks == 3:  # the OTHER halo form: wait for the rows, one pass with ghost lanes
+        env['STK_TEST_OVERLAP_FROM'] = '1000'
     res = subprocess.run([sys.executable, os.path.join(HERE, 'mp_parity_worker.py')], env=env,
                          capture_output=True, text=True, timeout=1500)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]

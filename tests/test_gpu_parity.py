@@ -1672,6 +1672,24 @@ def test_kron_apply_does_not_depend_on_the_partition(stk):
                     assert torch.equal(y2[:, :n_loc], ref), (name, 'overlapped', N, size, b, e)
                     if ldl > n_loc:
                         assert float(y2[:, n_loc:].abs().max()) == 0.0
+                    # ... and from the compact records of the pack kernel and the interleaved
+                    # received rows (stk_halo_pack_records, stk_kron_pack_boundary_apply): what
+                    # the operator classes run
+                    if gh is not None:
+                        rec = torch.empty((M, 4), dtype=torch.float64, device='cuda')
+                        first = torch.empty(M, dtype=torch.float64, device='cuda')
+                        last = torch.empty(M, dtype=torch.float64, device='cuda')
+                        stk.check(stk.lib().stk_halo_pack_records(
+                            stk.stream(), M, n_loc, ldl, stk.ptr(xs), stk.ptr(first), 1, stk.ptr(last), 1,
+                            stk.ptr(rec)))
+                        assert torch.equal(first, xs[:, 0]) and torch.equal(last, xs[:, n_loc - 1])
+                        assert torch.equal(rec[:, 0], xs[:, 0]) and torch.equal(rec[:, 3], xs[:, n_loc - 1])
+                        assert torch.equal(rec[:, 1], xs[:, min(1, n_loc - 1)])
+                        assert torch.equal(rec[:, 2], xs[:, max(n_loc - 2, 0)])
+                        y2b = slab(rng.rand(M, n_loc))
+                        form.apply(specs, xs, None, n_loc, ldl, 0.0, y2b)
+                        form.apply_boundary(specs, rec, gh, lo is not None, hi is not None, n_loc, ldl, y2b)
+                        assert torch.equal(y2b, y2), (name, 'records', N, size, b, e)
                 y3 = slab(rng.rand(M, n_loc))
                 ell.apply([(local[k], k, xs, lo, hi) for k in range(nt)], n_loc, ldl, 0.0, y3)
                 assert torch.equal(y3[:, :n_loc], whole['plain'][:, b:e]), ('plain', N, size, b, e)

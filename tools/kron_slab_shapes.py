@@ -109,6 +109,28 @@ for shape in args.shapes.split(','):
         ms_a, ms_b = timed(one_pass), timed(overlapped)
         ms_main = timed(lambda: pk.apply(pspecs, x, None, n_loc, ld, 0.0, y2))
         ms_go = timed(lambda: pk.apply_ghost(pspecs, x, g[0] if lo else None, g[1] if hi else None, n_loc, ld, y2))
+        # round 6: the boundary steps from compact records (left by the pack) and interleaved received rows
+        rec = torch.empty((M, 4), dtype=torch.float64, device='cuda')
+
+        def pack_records():
+            _lib.check(lib.stk_halo_pack_records(st, M, n_loc, ld, _lib.ptr(x), _lib.ptr(send[0]) if lo else None, 1,
+                                                 _lib.ptr(send[1]) if hi else None, 1, _lib.ptr(rec)))
+
+        def interleave():
+            _lib.check(lib.stk_interleave_ghosts(st, M, _lib.ptr(g[0] if lo else None),
+                                                 _lib.ptr(g[1] if hi else None), _lib.ptr(gh)))
+
+        pack_records()
+        interleave()
+        y3 = torch.empty_like(y2)
+        pk.apply(pspecs, x, None, n_loc, ld, 0.0, y3)
+        pk.apply_boundary(pspecs, rec, gh, lo, hi, n_loc, ld, y3)
+        same = torch.equal(y3, y2)
+        ms_pr, ms_il = timed(pack_records), timed(interleave)
+        ms_rec = timed(lambda: pk.apply_boundary(pspecs, rec, gh, lo, hi, n_loc, ld, y3))
+        print('                     boundary steps from compact records: pack with records %.3f ms; interleave %.3f ms; '
+              'boundary kernel %.3f ms (slab gathers: %.3f ms)  %s' % (ms_pr, ms_il, ms_rec, ms_go,
+                                                                        'bit-identical' if same else 'DIFFERENT'))
         overlapped()
         ell.apply(specs, n_loc, ld, 0.0, y)
         err = float((y2 - y).abs().max() / y.abs().max())
