@@ -425,6 +425,85 @@ def test_c_partition_matches_reference_tables():
     assert b'more ranks' in lib.stk_last_error()
 
 
+def test_host_side_of_the_partition_independent_dot():
+    """What of KronVectorMPI.dot's round-6 form runs on the host (no GPU needed): the N
+    per-step sums are added in increasing t with plain additions (stk_sum_steps), the
+    scratch of stk_slab_dot is a function of the slab shape alone, and the all-reduce of an
+    N-vector in which every entry has ONE non-zero contributor is exact whatever the order
+    of the ranks -- so the sum over the ranks followed by the sum over t is one double for
+    every partition of the time axis."""
+    import ctypes
+    from source import _lib
+    lib = _lib.lib()
+    lib.stk_sum_steps.restype = ctypes.c_double
+    rng = np.random.RandomState(6)
+    for N in (1, 2, 9, 65, 129, 300):
+        steps = np.ascontiguousarray(rng.randn(N) * 10.0**rng.randint(-8, 8, size=N))
+        want = 0.0
+        for v in steps:
+            want += v
+        assert lib.stk_sum_steps(steps.ctypes.data_as(ctypes.c_void_p), N) == want
+        for size in (2, 3, 4, 8):
+            if size > N:
+                continue
+            base, extra = divmod(N, size)
+            parts, start = [], 0
+            for p in range(size):
+                stop = start + base + (1 if p >= size - extra else 0)
+                mine = np.zeros(N)
+                mine[start:stop] = steps[start:stop]
+                parts.append(mine)
+                start = stop
+            for order in (range(size), reversed(range(size)), rng.permutation(size)):
+                total = np.zeros(N)
+                for p in order:
+                    total = total + parts[p]
+                assert np.array_equal(total, steps)
+    assert lib.stk_slab_dot_work_size(1000, 65) == 2 * 33 * 4  # 33 pairs of steps x 4 blocks of 256 rows
+    assert lib.stk_slab_dot_work_size(1, 1) == 2 and lib.stk_slab_dot_work_size(0, 5) == 0
+    assert lib.stk_pcg_slab_work_size(1000, 65, 66, 65) == 4 * 1000 * 66 + 2 * 33 * 4 + 66
+
+
+def test_thread_communicator_of_the_gpu_parity_tests():
+    """tests/thread_comm.py (ranks as threads of one process: how the 8-rank shapes of the
+    BASELINE configurations fit a box that allows six processes on its card) on CPU
+    tensors: all-reduce, ordered point-to-point exchange with self-sends, broadcast,
+    gather, barrier, and a failing rank that must not leave the others waiting."""
+    import torch
+    from thread_comm import run_ranks
+
+    def body(comm):
+        r, n = comm.Get_rank(), comm.Get_size()
+        t = torch.zeros(n, dtype=torch.float64)
+        t[r] = r + 1.0
+        comm.allreduce_tensor_(t)
+        assert t.tolist() == [p + 1.0 for p in range(n)]
+        assert comm.allreduce(float(r)) == sum(range(n))
+        # two messages to the right neighbour, one to oneself: matched in posting order
+        right, left = (r + 1) % n, (r - 1) % n
+        a, b, c = (torch.empty(3, dtype=torch.float64) for _ in range(3))
+        reqs = comm.exchange([(torch.full((3,), 10.0 * r), right), (torch.full((3,), 10.0 * r + 1), right),
+                              (torch.full((3,), -1.0 - r), r)],
+                             [(a, left), (b, left), (c, r)])
+        comm.wait_all(reqs)
+        assert a[0] == 10.0 * left and b[0] == 10.0 * left + 1 and c[0] == -1.0 - r
+        assert comm.bcast('from %d' % r, root=2) == 'from 2'
+        got = comm.gather(r * r, root=1)
+        assert (got == [p * p for p in range(n)]) if r == 1 else (got is None)
+        comm.Barrier()
+        return r
+
+    assert run_ranks(5, body, timeout=60.0) == [0, 1, 2, 3, 4]
+
+    def failing(comm):
+        if comm.Get_rank() == 1:
+            raise ValueError('rank 1 gives up')
+        comm.Barrier()
+
+    with pytest.raises(ValueError, match='rank 1 gives up'):
+        run_ranks(3, failing, timeout=20.0)
+
+
 # ---- property tests (hypothesis) ---------------------------------------------------
 def test_properties_partition_schedule_staging():
     """Random inputs for three pieces of host logic: the slab partition, the
