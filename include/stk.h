@@ -566,6 +566,16 @@ int stk_kron_plan_ghost_apply(stk_kron_plan *plan, void *stream, int32_t n_loc,
                               const stk_kron_pack_term *terms_host, const double *x,
                               const double *x_lo, const double *x_hi, double *y);
 
+/* The same two steps from the compact records stk_halo_pack_records left (4*M doubles) and
+ * the received rows (interleaved into ghost_work, 2*M doubles): stk_kron_pack_boundary_apply
+ * on the plan's packed form, 2-3 x faster than the slab form above and the same doubles.
+ * records = NULL, or a plan without a packed stream: the slab form (needs x). */
+int stk_kron_plan_boundary_apply(stk_kron_plan *plan, void *stream, int32_t n_loc,
+                                 int32_t ld, int32_t n_terms,
+                                 const stk_kron_pack_term *terms_host, const double *x,
+                                 const double *records, const double *x_lo,
+                                 const double *x_hi, double *ghost_work, double *y);
+
 /* Diagnostic: while `buf` (device, at least 8 * grid * 4 words) is non-NULL,
  * the headline instantiation of the one-row form (2 terms, K = 7, no ghosts;
  * tuning key "pack_rows" = 1) runs a stamped build

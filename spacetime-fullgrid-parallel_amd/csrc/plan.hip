@@ -532,3 +532,36 @@ extern "C" int stk_kron_plan_ghost_apply(stk_kron_plan *p, void *stream, int32_t
         terms[k] = stk_kron_ell_term{t[k].tri, p->ell_vals[t[k].mat], p->ovf_vals[t[k].mat], x, x_lo, x_hi};
     return stk_kron_ell_ghost_apply(stream, &p->ell, n_loc, ld, n_terms, terms, y);
 }
+
+// The boundary steps from the compact operands (stk_halo_pack_records' records, the received
+// rows x_lo / x_hi, interleaved here into ghost_work): the fast form of
+// stk_kron_plan_ghost_apply on plans with a packed stream; plans without one take the
+// slab form (they need `x`).
+extern "C" int stk_kron_plan_boundary_apply(stk_kron_plan *p, void *stream, int32_t n_loc, int32_t ld, int32_t n_terms,
+                                            const stk_kron_pack_term *t, const double *x, const double *records,
+                                            const double *x_lo, const double *x_hi, double *ghost_work, double *y)
+{
+    STK_REQUIRE(p && t && y, "stk_kron_plan_boundary_apply: null pointer");
+    STK_REQUIRE(n_terms >= 1 && n_terms <= 3, "stk_kron_plan_boundary_apply: n_terms=%d not in 1..3", n_terms);
+    for (int k = 0; k < n_terms; ++k)
+        STK_REQUIRE(t[k].mat >= 0 && t[k].mat < p->n_mats,
+                    "stk_kron_plan_boundary_apply: term %d names matrix %d of %d", k, t[k].mat, p->n_mats);
+    if (!x_lo && !x_hi) return 0;
+    const bool pairs_explicit = !p->packed && p->explicit_pairs && n_loc >= 24;
+    if (!records || !(p->packed || pairs_explicit))
+        return stk_kron_plan_ghost_apply(p, stream, n_loc, ld, n_terms, t, x, x_lo, x_hi, y);
+    STK_REQUIRE(ghost_work, "stk_kron_plan_boundary_apply: the received rows need ghost_work (2*M doubles)");
+    int rc = stk_interleave_ghosts(stream, p->M, x_lo, x_hi, ghost_work);
+    if (rc) return rc;
+    if (p->packed) {
+        const stk_pack_pattern *form = p->paired && n_loc >= 8 ? &p->pack_pairs : &p->pack;
+        return stk_kron_pack_boundary_apply(stream, form, n_loc, ld, n_terms, t, records, ghost_work, x_lo != nullptr,
+                                            x_hi != nullptr, y);
+    }
+    stk_pack_pattern form;
+    if (!explicit_pattern_for(p, n_terms, t, &form)) return 1;
+    stk_kron_pack_term in_order[3];
+    for (int k = 0; k < n_terms; ++k) in_order[k] = stk_kron_pack_term{t[k].tri, k};
+    return stk_kron_pack_boundary_apply(stream, &form, n_loc, ld, n_terms, in_order, records, ghost_work,
+                                        x_lo != nullptr, x_hi != nullptr, y);
+}

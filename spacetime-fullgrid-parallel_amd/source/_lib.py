@@ -180,6 +180,9 @@ _PROTOTYPES = {
         c_p, ctypes.POINTER(PackPattern), c_i32, c_i32, c_i32,
         ctypes.POINTER(KronPackTerm), c_p, c_p, c_p, c_p
     ]),
+    'stk_kron_plan_boundary_apply': (ctypes.c_int, [
+        c_p, c_p, c_i32, c_i32, c_i32, ctypes.POINTER(KronPackTerm), c_p, c_p, c_p, c_p, c_p, c_p
+    ]),
     'stk_kron_pack_boundary_apply': (ctypes.c_int, [
         c_p, ctypes.POINTER(PackPattern), c_i32, c_i32, c_i32,
         ctypes.POINTER(KronPackTerm), c_p, c_p, c_i32, c_i32, c_p

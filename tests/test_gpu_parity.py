@@ -2733,6 +2733,19 @@ def test_kron_plan_without_dictionary_through_ctypes_only(stk):
             stk.check(lib.stk_kron_plan_ghost_apply(plan, stk.stream(), n_loc, ld, len(use), terms, stk.ptr(x),
                                                     stk.ptr(d_lo), stk.ptr(d_hi), stk.ptr(y2)))
             assert relerr(y2[:, :n_loc].cpu().numpy(), want) < 1e-13, (n_loc, use)
+            assert torch.equal(y2, y)  # pass + boundary steps = the call with the received rows, bit for bit
+            # ... and the boundary steps from the records of the pack kernel (the fast form;
+            # the slab form again on plans without a packed stream)
+            rec = torch.empty((M, 4), dtype=torch.float64, device='cuda')
+            stk.check(lib.stk_halo_pack_records(stk.stream(), M, n_loc, ld, stk.ptr(x), None, 1, None, 1,
+                                                stk.ptr(rec)))
+            y2r = torch.full((M, ld), float('nan'), dtype=torch.float64, device='cuda')
+            stk.check(lib.stk_kron_plan_apply(plan, stk.stream(), n_loc, ld, len(use), terms, stk.ptr(x), None,
+                                              None, None, 0.0, stk.ptr(y2r)))
+            stk.check(lib.stk_kron_plan_boundary_apply(plan, stk.stream(), n_loc, ld, len(use), terms, stk.ptr(x),
+                                                       stk.ptr(rec), stk.ptr(d_lo), stk.ptr(d_hi), stk.ptr(work),
+                                                       stk.ptr(y2r)))
+            assert torch.equal(y2r, y), (n_loc, use)
             if n_loc >= 24:  # the Python planner's explicit pairs: the same kernel on the same arrays
                 ell = EllMatrices([mats[m] for m in use], [M_x])
                 two = ell.packed_variant(2)
