@@ -450,11 +450,17 @@ def main():
     # bring the device to its steady clocks first: a cold GPU runs the first few
     # milliseconds of work measurably slower (the same kernel: 0.40 ms in the
     # first 10 ms after start-up, 0.37 ms later)
+    # (several ranks: every step is a halo exchange, so the NUMBER of steps must be the same
+    # on all of them -- a clock read per rank is not: the ranks agree after every batch of 20
+    # whether the time is up.  Round 6: until then each rank looped on its own clock, and a run
+    # on two ranks at this size stopped in the first exchange one rank had and the other had not.)
     t_hot = time.perf_counter() + args.preheat
-    while time.perf_counter() < t_hot:
+    while args.preheat > 0:
         for _ in range(20):
             step()
         torch.cuda.synchronize()
+        if comm.allreduce(1.0 if time.perf_counter() >= t_hot else 0.0) > 0.0:
+            break
     for _ in range(args.warmup):
         step()
     comm.Barrier()
