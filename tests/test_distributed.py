@@ -181,7 +181,7 @@ def test_bench_runs_as_the_driver_launches_it(nproc, backend):
            # several ranks: WITH the untimed preheat of the default flags -- its number of
            # steps (each a halo exchange) must be agreed between the ranks, not read off each
            # rank's own clock (round 6: a two-rank run at config 3 stopped there for good)
-           '--preheat', '0' if nproc == 1 else '0.3']
+           '--preheat', '0.3']
     res = subprocess.run(cmd, env=env, capture_output=True, text=True,
                          timeout=600)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
