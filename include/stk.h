@@ -901,6 +901,45 @@ int stk_p1_result_copy(const stk_p1_result *r, int32_t which, int32_t *indptr,
                        int32_t *indices, double *data);
 int stk_p1_result_free(stk_p1_result *r);
 
+/* ---- problem set-up: one uniform refinement of a triangulation ---------------
+ * What the reference takes from Netgen (source/problem.py:7-41: mesh.Refine())
+ * together with NGSolve's parent-vertex table (source/multigrid.py:20-21,
+ * GetParentVertices): every triangle cut into four, the midpoints appended to the
+ * vertices in the order (colour of the bisected edge, y, x) -- the hierarchical
+ * numbering the prolongations and the dof-order sweeps are built on.  HOST arrays:
+ * points [nv][2], tris [nt][3], tri_colors [nt][3] (colour of the edge opposite
+ * each local vertex; the two triangles of an edge must agree).  Written: the
+ * n_new <= capacity new vertices (new_points [.][2], new_parents [.][2] = the ends
+ * of the bisected edge, smaller number first, new_colors [.]), and the 4 nt children
+ * with their edge colours, child b of triangle t at row b * nt + t.  Integer work
+ * and one halving per coordinate on the host threads of the library: the result
+ * does not depend on their number. */
+int stk_tri_refine(int64_t nv, int64_t nt, const double *points,
+                   const int64_t *tris, const int64_t *tri_colors,
+                   int64_t capacity, double *new_points, int64_t *new_parents,
+                   int64_t *new_colors, int64_t *child_tris,
+                   int64_t *child_colors, int64_t *n_new);
+
+/* ---- problem set-up: load vector of a triangulation --------------------------
+ * int f phi_i over the mesh with an nq-point rule given in barycentric
+ * coordinates (rule_points [nq][3], rule_weights [nq], weights summing to 1):
+ * what the reference gets from LinearForm(u0 * v * dx).assemble()
+ * (heateq_mpi.py:102-103).  Two calls around the CALLER's evaluation of f:
+ * stk_p1_load_points_2d writes the coordinates of the quadrature points
+ * (qx, qy [nt][nq]: l0 p0 + l1 p1 + l2 p2, summed from the left);
+ * stk_p1_load_sum_2d takes f [nt][nq] at those points and writes vec [nv] (ALL
+ * vertices; the caller keeps the free ones): the share of triangle t in the entry
+ * of its local vertex a is (sum_q (f_q w_q) l_qa) * |T|, q ascending, and an entry
+ * sums its shares in ascending (t, a) -- no fused multiply-adds, the result depends
+ * on the mesh alone, not on the number of host threads. */
+int stk_p1_load_points_2d(int64_t nt, const double *points, const int64_t *tris,
+                          int32_t nq, const double *rule_points, double *qx,
+                          double *qy);
+int stk_p1_load_sum_2d(int64_t nv, int64_t nt, const double *points,
+                       const int64_t *tris, int32_t nq,
+                       const double *rule_weights, const double *rule_points,
+                       const double *f, double *vec);
+
 #ifdef __cplusplus
 }
 #endif

@@ -250,6 +250,17 @@ class HeatEquationMPI:
         # tools/setup_profile.py --timeline
         self.setup_timeline = []
         mark = lambda label: self.setup_timeline.append((label, MPI.Wtime() - start_time))
+        # (label, begin, end) of what runs in side threads
+        self.setup_threads = []
+
+        def timed(label, fn):
+            def run(*args, **kw):
+                begin = MPI.Wtime() - start_time
+                try:
+                    return fn(*args, **kw)
+                finally:
+                    self.setup_threads.append((label, begin, MPI.Wtime() - start_time))
+            return run
         comm = MPI.COMM_WORLD if comm is None else comm
         assert arithmetic in ('fast', 'accurate', 'reference')
         assert family in ('batched', 'reference'), family
@@ -269,10 +280,10 @@ class HeatEquationMPI:
         # the load vector and the prolongations need the mesh only: beside the
         # assembly, which runs on the host threads of libstk (no GIL held)
         from concurrent.futures import ThreadPoolExecutor
-        u0_x = _Beside(space_load, mesh_space, data['u0'])
+        u0_x = _Beside(timed('load vector', space_load), mesh_space, data['u0'])
         # ... with what every plan on the hierarchy shares (tile orders, candidate
         # bands, the transfer operators on the device) prepared in the same thread
-        hierarchy = _Beside(_lib.in_device_context(lambda m: MeshHierarchy(m).prepare()), mesh_space)
+        hierarchy = _Beside(timed('hierarchy', _lib.in_device_context(lambda m: MeshHierarchy(m).prepare())), mesh_space)
         # --- TIME --- (heateq_mpi.py:78-88)
         self.A_t, self.L_t, self.M_t, self.G_t, self.u0_t = time_matrices(
             mesh_time)
@@ -335,9 +346,9 @@ class HeatEquationMPI:
             with ThreadPoolExecutor(max_workers=4) as pool:
                 if schur != 'reference':  # the Kronecker plan S streams: independent of both
                     n_steps = self.dofs_distr.t_end - self.dofs_distr.t_begin
-                    pool.submit(on_dev(lambda: EllMatrices.shared(
-                        [self.M_x, self.A_x]).packed_for(n_steps)))
-                kinv = pool.submit(on_dev(MultiGrid), self.A_x, hierarchy,
+                    pool.submit(timed('Kronecker plan', on_dev(lambda: EllMatrices.shared(
+                        [self.M_x, self.A_x]).packed_for(n_steps))))
+                kinv = pool.submit(timed('plan of K', on_dev(MultiGrid)), self.A_x, hierarchy,
                                    smoothsteps=smoothsteps, vcycles=vcycles, gs_rows=gs_rows)
                 # bands of 6 mesh rows for the family's strip-wise sweeps on longer slabs
                 # (source/multigrid.py BAND_MERGE: P -2 %, bit-identical); an
@@ -345,7 +356,7 @@ class HeatEquationMPI:
                 n_steps_ = self.dofs_distr.t_end - self.dofs_distr.t_begin
                 merge = None if 'STK_BAND_MERGE_FAMILY' in os.environ else (6 if n_steps_ >= 16 else 1)
                 members = pool.submit(
-                    on_dev(MultiGridFamily), self.A_x, self.M_x, hierarchy, ca=alpha,
+                    timed('plan of the family', on_dev(MultiGridFamily)), self.A_x, self.M_x, hierarchy, ca=alpha,
                     cms=[2**j for j in range(self.J_time + 1)],
                     smoothsteps=smoothsteps, vcycles=vcycles, gs_rows=gs_rows, band_merge=merge,
                     exact_coarse=(arithmetic == 'accurate' and self.ACCURATE['member_coarse_matrices']))

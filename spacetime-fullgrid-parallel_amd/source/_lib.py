@@ -243,6 +243,9 @@ _PROTOTYPES = {
     'stk_p1_result_sizes': (ctypes.c_int, [c_p, c_p, c_p, c_p]),
     'stk_p1_result_copy': (ctypes.c_int, [c_p, c_i32, c_p, c_p, c_p]),
     'stk_p1_result_free': (ctypes.c_int, [c_p]),
+    'stk_p1_load_points_2d': (ctypes.c_int, [c_i64, c_p, c_p, c_i32, c_p, c_p, c_p]),
+    'stk_p1_load_sum_2d': (ctypes.c_int, [c_i64, c_i64, c_p, c_p, c_i32, c_p, c_p, c_p, c_p]),
+    'stk_tri_refine': (ctypes.c_int, [c_i64, c_i64, c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p]),
     'stk_mg_destroy': (ctypes.c_int, [c_p]),
     'stk_mg_set_option': (ctypes.c_int, [c_p, ctypes.c_char_p, c_i32]),
     'stk_mg_apply': (ctypes.c_int,

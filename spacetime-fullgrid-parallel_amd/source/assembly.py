@@ -329,8 +329,48 @@ def _simplex_volumes(mesh):
     return np.abs(e0[:, 0] * e1[:, 1] - e0[:, 1] * e1[:, 0]) / 2.0
 
 
-def space_load(mesh, fn):
-    """int fn * phi_i on the free dofs (heateq_mpi.py:102-103)."""
+def _space_load_libstk(mesh, fn):
+    """The 2-D load vector around libstk's host threads (csrc/mesh_refine.hip): the
+    quadrature points and the sums there, fn -- a pointwise function of arrays, as a
+    coefficient function is -- evaluated here, in slices side by side (NumPy's
+    elementwise loops release the interpreter lock)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+
+    from . import _lib
+    lib = _lib.lib()
+    pts = np.ascontiguousarray(mesh.points, dtype=np.float64)
+    cells = np.ascontiguousarray(mesh.cells, dtype=np.int64)
+    nt, nq = len(cells), len(_QW)
+    qw, ql = np.ascontiguousarray(_QW), np.ascontiguousarray(_QL)
+    qx, qy = np.empty((nt, nq)), np.empty((nt, nq))
+    _lib.check(lib.stk_p1_load_points_2d(nt, pts.ctypes.data, cells.ctypes.data, nq, ql.ctypes.data,
+                                         qx.ctypes.data, qy.ctypes.data))
+    f = np.empty((nt, nq))
+    parts = max(1, min(8, os.cpu_count() or 1, nt // 16384))
+    cuts = [nt * k // parts for k in range(parts + 1)]
+
+    def evaluate(k):
+        f[cuts[k]:cuts[k + 1]] = fn(qx[cuts[k]:cuts[k + 1]], qy[cuts[k]:cuts[k + 1]])
+
+    if parts == 1:
+        evaluate(0)
+    else:
+        with ThreadPoolExecutor(max_workers=parts) as pool:
+            list(pool.map(evaluate, range(parts)))
+    vec = np.empty(mesh.nv)
+    _lib.check(lib.stk_p1_load_sum_2d(mesh.nv, nt, pts.ctypes.data, cells.ctypes.data, nq, qw.ctypes.data,
+                                      ql.ctypes.data, f.ctypes.data, vec.ctypes.data))
+    return vec[free_dofs(mesh)]
+
+
+def space_load(mesh, fn, numpy_path=False):
+    """int fn * phi_i on the free dofs (heateq_mpi.py:102-103).  Triangulations: on
+    the host threads of libstk (stk_p1_load_points_2d / stk_p1_load_sum_2d; the same
+    sums in a fixed order, within rounding of the NumPy form below, which tetrahedral
+    meshes and numpy_path=True take)."""
+    if mesh.cells.shape[1] == 3 and not numpy_path:
+        return _space_load_libstk(mesh, fn)
     vol = _simplex_volumes(mesh)
     p = mesh.points
     c = mesh.cells

@@ -44,6 +44,9 @@ HYPOTENUSE_FIRST = False
 # CLASS_ORDER[c] (None: as coloured; with the default colouring of a three-direction
 # mesh, colour 0 / 1 / 2 = horizontal / vertical / hypotenuse).
 CLASS_ORDER = None
+# True: TriangleMesh.refine takes its NumPy form (the fixture generator under
+# tests/golden loads this file alone, without libstk); the tables are the same.
+REFINE_NUMPY = False
 
 
 class IntervalMesh:
@@ -132,8 +135,13 @@ class TriangleMesh:
         return col[te]
 
     # ------------------------------------------------------------------
-    def refine(self):
-        """One uniform red refinement; new vertices are appended."""
+    def refine(self, numpy_path=None):
+        """One uniform red refinement; new vertices are appended.  On the host threads
+        of libstk (stk_tri_refine, csrc/mesh_refine.hip); numpy_path=True takes the
+        NumPy form below -- the same tables entry for entry
+        (tests/test_host_cpu.py test_refinement_on_host_threads_matches_numpy)."""
+        if not (REFINE_NUMPY if numpy_path is None else numpy_path):
+            return self._refine_libstk()
         edges, te = self._edges()
         ne = len(edges)
         nv = len(self.points)
@@ -176,6 +184,34 @@ class TriangleMesh:
         self._tri_edge_color = cols
         self.boundary = self.boundary_fn(self.points)
 
+    def _refine_libstk(self):
+        import ctypes
+
+        from . import _lib
+        nv, nt = len(self.points), len(self.tris)
+        pts = np.ascontiguousarray(self.points, dtype=np.float64)
+        tris = np.ascontiguousarray(self.tris, dtype=np.int64)
+        cols = np.ascontiguousarray(self._tri_edge_color, dtype=np.int64)
+        cap = 3 * nt  # untouched pages of np.empty cost nothing
+        mid = np.empty((cap, 2), dtype=np.float64)
+        par = np.empty((cap, 2), dtype=np.int64)
+        col = np.empty(cap, dtype=np.int64)
+        kids = np.empty((4 * nt, 3), dtype=np.int64)
+        kcol = np.empty((4 * nt, 3), dtype=np.int64)
+        ne = ctypes.c_int64()
+        _lib.check(_lib.lib().stk_tri_refine(
+            nv, nt, pts.ctypes.data, tris.ctypes.data, cols.ctypes.data, cap, mid.ctypes.data,
+            par.ctypes.data, col.ctypes.data, kids.ctypes.data, kcol.ctypes.data, ctypes.byref(ne)))
+        ne = ne.value
+        self.points = np.vstack([pts, mid[:ne]])
+        self.parents = np.vstack([self.parents, par[:ne]])
+        self.vcolor = np.concatenate([self.vcolor, col[:ne]])
+        self.nverts.append(nv + ne)
+        self.tris = kids
+        self._tri_edge_color = kcol
+        # a pointwise test: the old vertices keep their answer
+        self.boundary = np.concatenate([self.boundary, self.boundary_fn(self.points[nv:])])
+
     @property
     def nv(self):
         return len(self.points)
@@ -189,7 +225,6 @@ class TriangleMesh:
         for l in range(1, len(self.nverts)):
             lv[self.nverts[l - 1]:self.nverts[l]] = l
         return lv
-
 
     @property
     def cells(self):

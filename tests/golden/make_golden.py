@@ -192,6 +192,7 @@ def main():
     from mpi4py import MPI
 
     mesh_mod = load_build_module('mesh')
+    mesh_mod.REFINE_NUMPY = True  # the generator does not load libstk
     asm = load_build_module('assembly')
 
     out_dir = os.environ.get('STK_GOLDEN_OUT', HERE)
@@ -258,7 +259,7 @@ def main():
         M_x, A_x = asm.space_matrices(mesh, scipy_path=True)  # the generator does not load libstk
         P_mats = asm.prolongation_matrices(mesh)
         u0_x = asm.space_load(
-            mesh, lambda *c: np.prod([np.sin(np.pi * ck) for ck in c], axis=0))
+            mesh, lambda *c: np.prod([np.sin(np.pi * ck) for ck in c], axis=0), numpy_path=True)
         N, M = A_t.shape[0], M_x.shape[0]
         dd = DofDistributionMPI(comm, N, M)
         rng = np.random.RandomState(128)

@@ -367,6 +367,92 @@ def test_p1_assembler_matches_scipy_path(monkeypatch):
         assert same(Mt, M1) and same(At, A1), threads
 
 
+def test_refinement_on_host_threads_matches_numpy(monkeypatch):
+    """stk_tri_refine (csrc/mesh_refine.hip; host threads of libstk) against the NumPy
+    form of the same refinement (source/mesh.py; stands for Netgen's Refine() and
+    NGSolve's GetParentVertices, reference problem.py:7-41, multigrid.py:20-21): the
+    same points, triangles, parent pairs, colours and boundary flags entry for entry,
+    on the square and on the L-shape (alternating diagonals), whatever the number of
+    threads -- the last levels are long enough for the sample sort's buckets.  A mesh
+    whose colouring is inconsistent, or with a degenerate triangle, is refused."""
+    import ctypes
+
+    from source import _lib, mesh as M
+
+    tables = ('points', 'tris', 'parents', 'vcolor', 'boundary', '_tri_edge_color')
+
+    def build(make, n, numpy_path):
+        orig = M.TriangleMesh.refine
+        monkeypatch.setattr(M.TriangleMesh, 'refine', lambda self: orig(self, numpy_path=numpy_path))
+        try:
+            return make(n)[0]
+        finally:
+            monkeypatch.setattr(M.TriangleMesh, 'refine', orig)
+
+    for make, n in ((M.construct_2d_square_mesh, 1), (M.construct_2d_square_mesh, 7),
+                    (M.construct_2d_lshape_mesh, 6)):
+        ref = build(make, n, True)
+        for threads in (None, '1', '3', '7'):
+            if threads is None:
+                monkeypatch.delenv('STK_HOST_THREADS', raising=False)
+            else:
+                monkeypatch.setenv('STK_HOST_THREADS', threads)
+            got = build(make, n, False)
+            assert got.nverts == ref.nverts
+            for name in tables:
+                a, b = getattr(got, name), getattr(ref, name)
+                assert a.dtype == b.dtype and np.array_equal(a, b), (make.__name__, n, threads, name)
+    monkeypatch.delenv('STK_HOST_THREADS', raising=False)
+
+    def call(pts, tris, cols):
+        pts, tris, cols = (np.ascontiguousarray(pts, dtype=np.float64), np.ascontiguousarray(tris, dtype=np.int64),
+                           np.ascontiguousarray(cols, dtype=np.int64))
+        nt = len(tris)
+        out = [np.empty((3 * nt, 2)), np.empty((3 * nt, 2), dtype=np.int64), np.empty(3 * nt, dtype=np.int64),
+               np.empty((4 * nt, 3), dtype=np.int64), np.empty((4 * nt, 3), dtype=np.int64)]
+        ne = ctypes.c_int64()
+        return _lib.lib().stk_tri_refine(len(pts), nt, pts.ctypes.data, tris.ctypes.data, cols.ctypes.data, 3 * nt,
+                                         *[o.ctypes.data for o in out], ctypes.byref(ne))
+
+    pts = [[0., 0.], [1., 0.], [1., 1.], [0., 1.]]
+    assert call(pts, [[0, 1, 2], [0, 2, 3]], [[0, 1, 2], [2, 0, 1]]) == 0
+    assert call(pts, [[0, 1, 2], [0, 2, 3]], [[0, 1, 2], [2, 1, 0]]) != 0  # edge (0, 2): colour 1 and colour 0
+    assert b'different colours' in _lib.lib().stk_last_error()
+    assert call(pts, [[0, 1, 1], [0, 2, 3]], [[0, 1, 2], [2, 0, 1]]) != 0
+    assert call(pts, [[0, 1, 4], [0, 2, 3]], [[0, 1, 2], [2, 0, 1]]) != 0
+
+
+def test_load_vector_on_host_threads(monkeypatch):
+    """stk_p1_load_points_2d / stk_p1_load_sum_2d (csrc/mesh_refine.hip) against the NumPy
+    form of the load vector (heateq_mpi.py:102-103): the same sums in a fixed order,
+    so within a few ulp of the largest entry (NumPy's matmul leaves the order to the
+    BLAS); the same doubles whatever the number of host threads and however the
+    evaluation of the function is sliced; a constant function gives the row sums of
+    the mass matrix."""
+    from source.assembly import space_load, space_matrices
+    from source.problem import problem_helper
+
+    for problem, J in (('square', 1), ('square', 6), ('lshape', 5), ('lshape_jitter', 5)):
+        mesh, _, _, data, _ = problem_helper(problem, J_space=J, J_time=2)
+        ref = space_load(mesh, data['u0'], numpy_path=True)
+        monkeypatch.delenv('STK_HOST_THREADS', raising=False)
+        got = space_load(mesh, data['u0'])
+        assert got.shape == ref.shape
+        assert np.max(np.abs(got - ref)) <= 1e-15 * np.max(np.abs(ref)), (problem, J)
+        for threads in ('1', '5'):
+            monkeypatch.setenv('STK_HOST_THREADS', threads)
+            assert np.array_equal(space_load(mesh, data['u0']), got), (problem, J, threads)
+        monkeypatch.delenv('STK_HOST_THREADS', raising=False)
+        M_x, _ = space_matrices(mesh, scipy_path=True)
+        ones = space_load(mesh, lambda x, y: 1.0)  # a scalar broadcasts over the slice
+        assert ones.shape == ref.shape and np.all(ones > 0)
+        # the row sums of the FULL mass matrix are |support| / 3; the free-dof block loses
+        # the boundary columns, so compare where no neighbour is on the boundary
+        inner = np.asarray(abs(M_x).sum(axis=1)).reshape(-1)
+        full = np.isclose(inner, ones, rtol=1e-12)
+        assert full.sum() > 0.5 * len(ones) or len(ones) < 16, (problem, J)
+
+
 def test_numbering_gives_shallow_gauss_seidel_schedules():
     """The build-owned numbering (source/mesh.py) orders the new vertices of a
     level by edge class with the hypotenuse class last: the sequential sweep of

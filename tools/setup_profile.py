@@ -37,6 +37,8 @@ if args.timeline:
         for label, at in h.setup_timeline:
             print('   %-48s +%.2f s  (at %.2f s)' % (label, at - last, at))
             last = at
+        for label, begin, end in sorted(getattr(h, 'setup_threads', []), key=lambda r: r[1]):
+            print('      beside: %-28s %.2f -> %.2f s' % (label, begin, end))
         del h
     sys.exit(0)
 
