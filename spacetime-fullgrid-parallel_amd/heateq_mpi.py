@@ -281,9 +281,22 @@ class HeatEquationMPI:
         # assembly, which runs on the host threads of libstk (no GIL held)
         from concurrent.futures import ThreadPoolExecutor
         u0_x = _Beside(timed('load vector', space_load), mesh_space, data['u0'])
-        # ... with what every plan on the hierarchy shares (tile orders, candidate
-        # bands, the transfer operators on the device) prepared in the same thread
-        hierarchy = _Beside(timed('hierarchy', _lib.in_device_context(lambda m: MeshHierarchy(m).prepare())), mesh_space)
+        # ... and the hierarchy: the object (prolongations) is published as soon as it
+        # exists; the same thread then works ahead on what the plans share (tile orders,
+        # bands, transfer operators on the device) -- plans ask through hierarchy.shared(),
+        # made by whoever asks first
+        import threading
+        published, box = threading.Event(), {}
+
+        def build_hierarchy(mesh):
+            try:
+                box['hierarchy'] = timed('prolongations', MeshHierarchy)(mesh)
+            finally:
+                published.set()
+            if precond == 'multigrid':
+                timed('shares of the hierarchy', _lib.in_device_context(box['hierarchy'].prepare))()
+
+        shares = _Beside(build_hierarchy, mesh_space)
         # --- TIME --- (heateq_mpi.py:78-88)
         self.A_t, self.L_t, self.M_t, self.G_t, self.u0_t = time_matrices(
             mesh_time)
@@ -313,7 +326,10 @@ class HeatEquationMPI:
             raise ValueError(wavelettransform)
 
         # ---- Preconditioners in space ---- (heateq_mpi.py:141-162)
-        hierarchy = hierarchy.result()
+        published.wait()
+        if 'hierarchy' not in box:
+            shares.result()  # raises what the constructor raised
+        hierarchy = box['hierarchy']
         mark('wavelets, prolongations')
         self.hierarchy = hierarchy
         # Row form of the Gauss-Seidel copies.  'owned': the reference's forms where they
@@ -378,6 +394,7 @@ class HeatEquationMPI:
                 for j in range(self.J_time + 1)
             ]
         self.u0_x = u0_x.result()
+        shares.result()
         mark('multigrid plans, Kronecker plan, load vector')
         self.CAC_j = [
             CompositeLinOp([self.C_j[j], self.A_x, self.C_j[j]])

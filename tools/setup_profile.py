@@ -28,6 +28,8 @@ torch.zeros(1, device='cuda')
 
 if args.timeline:
     import heateq_mpi as hm
+    if os.environ.get('STK_SWITCH_INTERVAL'):
+        sys.setswitchinterval(float(os.environ['STK_SWITCH_INTERVAL']))
     for rep in range(3):
         t = time.time()
         h = hm.HeatEquationMPI(J_space=args.J_space, J_time=args.J_time)
