@@ -5,25 +5,26 @@ heateq.py:18-158).
 
 Same structure as the reference: X = H1_t x H1_x, Y = L2_t(order 1) x H1_x,
 B = B1 + B2, K = Kinv_time kron Kinv_space, S = B^T K B + G, P block diagonal
-over the wavelet levels, solved with PCG on flat NumPy vectors.  The matrices
-come from the build's own P1 assembly (source/assembly.py) instead of NGSolve;
-every operator application runs on the GPU (vectors travel over PCIe per
-apply: this is the reference's serial wiring, not the fast path -- that is
-heateq_mpi.py)."""
+over the wavelet levels, solved with PCG.  The matrices come from the build's own
+P1 assembly (source/assembly.py) instead of NGSolve; every operator application
+runs on the GPU.  The operators accept the reference's flat NumPy vectors (one
+round trip over PCIe per apply) and device vectors (source/linop.py:
+DeviceLinearOperator); solve() keeps the whole iteration on the device.  The
+time-parallel path is heateq_mpi.py."""
 import argparse
 import os
 import sys
 
 import numpy as np
 import scipy.sparse as sp
-from scipy.sparse.linalg import LinearOperator
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from source.assembly import (space_load, space_matrices,  # noqa: E402
                              time_matrices, time_matrices_test_space)
 from source.linalg import PCG  # noqa: E402
-from source.linop import (BlockDiagLinOp, CompositeLinOp, InvLinOp,  # noqa: E402
-                          KronLinOp)
+from source.linop import (BlockDiagLinOp, CompositeLinOp,  # noqa: E402
+                          DeviceLinearOperator, InvLinOp, KronLinOp,
+                          device_vector, host_vector)
 from source.multigrid import MeshHierarchy, MultiGrid  # noqa: E402
 from source.problem import problem_helper  # noqa: E402
 from source.wavelets import WaveletTransformOp  # noqa: E402
@@ -43,6 +44,7 @@ class HeatEquation:
         M_Y, Minv_Y, B1_t, B2_t = time_matrices_test_space(mesh_time)
         M_x, A_x = space_matrices(mesh_space)
         self.N, self.M = A_t.shape[0], M_x.shape[0]
+        self.N_Y = M_Y.shape[0]  # time dofs of the test space
         self.M_x, self.A_x = M_x, A_x
         self.time_mats = dict(A_t=A_t, L_t=L_t, M_t=M_t, G_t=G_t, u0_t=u0_t,
                               Minv_Y=Minv_Y, B1_t=B1_t, B2_t=B2_t)
@@ -80,7 +82,9 @@ class HeatEquation:
         self.P = BlockDiagLinOp([self.CAC_j[j] for j in W_t.levels])
 
         # Schur complement (heateq.py:87-91)
-        self.S = LinearOperator(
+        # (a DeviceLinearOperator: the same expression maps flat host vectors, as the
+        # reference's LinearOperator does, and device vectors)
+        self.S = DeviceLinearOperator(
             self.G.shape,
             matvec=lambda v: self.BT @ (self.K @ (self.B @ v)) + self.G @ v)
         self.WT_S_W = self.WT @ self.S @ self.W
@@ -92,17 +96,27 @@ class HeatEquation:
         self.u0_x = space_load(mesh_space, data['u0'])
         self.f = self.BT @ (self.K @ self.g_vec) + np.kron(u0_t, self.u0_x)
 
-    def solve(self, callback=None):
-        """PCG on the wavelet-transformed system; returns (u, iterations)."""
-        w, iters = PCG(self.WT_S_W, self.P, self.WT @ self.f, callback=callback)
-        return self.W @ w, iters
+    def solve(self, callback=None, on_host=False):
+        """PCG on the wavelet-transformed system; returns (u, iterations).  The
+        right-hand side goes to the device once and the solution comes back once: in
+        between, every vector of the iteration is device-resident (the callback sees
+        device vectors; source.linop.host_vector copies one out).  on_host=True runs
+        the reference's wiring literally -- flat NumPy vectors, one round trip over
+        PCIe per operator apply."""
+        if on_host:
+            w, iters = PCG(self.WT_S_W, self.P, self.WT @ self.f, callback=callback)
+            return self.W @ w, iters
+        rhs = device_vector(self.f, self.N)
+        w, iters = PCG(self.WT_S_W, self.P, self.WT @ rhs, callback=callback)
+        return host_vector(self.W @ w), iters
 
     def errors(self, u):
         """(algebraic error of u in the X-norm, error in Y') as the reference's
         driver reports them (heateq.py:147-153)."""
-        residual = self.f - self.S @ u
-        defect = self.g_vec - self.B @ u
-        return residual @ (self.P @ residual), defect @ (self.K @ defect)
+        u = device_vector(u, self.N)
+        residual = device_vector(self.f, self.N) - self.S @ u
+        defect = device_vector(self.g_vec, self.N_Y) - self.B @ u
+        return residual.dot(self.P @ residual), defect.dot(self.K @ defect)
 
 
 _OPTIONS = (

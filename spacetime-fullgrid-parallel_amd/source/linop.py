@@ -11,7 +11,12 @@ shape (M, ld) -- all time columns at once -- through ``apply(x, out)``.
   CompositeLinOp  x -> A B x (reference linop.py:68-79)
   MultiGrid       see multigrid.py
 KronLinOp / BlockDiagLinOp are the serial (single-rank, flat NumPy vector in /
-out) operators of reference linop.py:6-15, 29-44, run on the device.
+out) operators of reference linop.py:6-15, 29-44, run on the device.  They are
+DeviceLinearOperators: applied to a flat NumPy vector they behave as the
+reference's (the vector travels to the device and back per apply); applied to a
+device vector (device_vector(x, n_time): a one-rank KronVectorMPI) they return
+one, sums and products of them do too, and a whole PCG solve then stays in HBM
+(heateq.py: solve()).
 """
 import ctypes
 import os
@@ -961,13 +966,87 @@ class PackedEllMatrices:
 # ----------------------------------------------------------------------------
 # Serial operators of the reference (flat NumPy vectors in and out).
 # ----------------------------------------------------------------------------
+_self_distributions = {}
+
+
+def self_distribution(N, M):
+    """The one-rank DofDistributionMPI of N time steps by M space dofs that the
+    serial operators' device vectors live on (one object per shape: vectors of one
+    shape add up)."""
+    from .comm import Comm
+    from .mpi_vector import DofDistributionMPI
+    key = (int(N), int(M))
+    if key not in _self_distributions:
+        _self_distributions[key] = DofDistributionMPI(Comm(distributed=False), *key)
+    return _self_distributions[key]
+
+
+def device_vector(x, n_time):
+    """A flat host vector of the serial operators (time-major: entry t * M + i, the
+    ordering of np.kron, reference linop.py:9-13) as a device-resident vector: a
+    KronVectorMPI on one rank.  DeviceLinearOperators map it to another one;
+    host_vector brings it back."""
+    from .mpi_vector import KronVectorMPI
+    X = np.ascontiguousarray(np.asarray(x, dtype=np.float64)).reshape(n_time, -1)
+    vec = KronVectorMPI(self_distribution(n_time, X.shape[1]))
+    vec.scatter(X)
+    return vec
+
+
+def host_vector(vec):
+    """The flat host copy of a device vector."""
+    out = np.empty(vec.N * vec.M)
+    vec.gather(out)
+    return out
+
+
+def _is_device_vector(x):
+    from .mpi_vector import KronVectorMPI
+    return isinstance(x, KronVectorMPI)
+
+
+class DeviceLinearOperator(LinearOperator):
+    """A serial operator with the reference's LinearOperator surface (flat NumPy
+    vector in, flat NumPy vector out: reference linop.py:6-65 builds those with
+    SciPy) that ALSO maps device vectors to device vectors.  `matvec` is the
+    function of flat host vectors; `vec_apply` the one of device vectors (default:
+    `matvec` itself -- a function written with `@` and `+` over operators of this
+    class is the same for both).  `A + B` and `A @ B` of two operators of this class
+    are operators of this class; with anything else SciPy's rules apply."""
+    def __init__(self, shape, matvec, vec_apply=None):
+        super().__init__(dtype=np.float64, shape=tuple(int(k) for k in shape))
+        self._host_fn = matvec
+        self._vec_fn = matvec if vec_apply is None else vec_apply
+
+    def _matvec(self, x):
+        return np.asarray(self._host_fn(np.asarray(x, dtype=np.float64).reshape(-1))).reshape(-1)
+
+    def dot(self, x):
+        if _is_device_vector(x):
+            assert x.N * x.M == self.shape[1], 'dimension mismatch'
+            out = self._vec_fn(x)
+            assert out.N * out.M == self.shape[0]
+            return out
+        if isinstance(x, DeviceLinearOperator):
+            assert self.shape[1] == x.shape[0], 'dimension mismatch'
+            return DeviceLinearOperator((self.shape[0], x.shape[1]), lambda v: self.dot(x.dot(v)))
+        return super().dot(x)
+
+    # SciPy routes `*`, `@` and calls through dot()
+    def __add__(self, x):
+        if isinstance(x, DeviceLinearOperator):
+            assert self.shape == x.shape, 'dimension mismatch'
+            return DeviceLinearOperator(self.shape, lambda v: self.dot(v) + x.dot(v))
+        return super().__add__(x)
+
+
 def KronLinOp(mat_time, mat_space):
     """x -> (A kron B) x on the device (reference linop.py:6-15)."""
     from .mpi_kron import SerialKron
     N, K = mat_time.shape
     M, L = mat_space.shape
     op = SerialKron(mat_time, mat_space)
-    return LinearOperator(matvec=op.matvec, shape=(N * M, K * L))
+    return DeviceLinearOperator((N * M, K * L), op.matvec, op.apply_vec)
 
 
 def BlockDiagLinOp(linops):
@@ -1000,7 +1079,20 @@ def BlockDiagLinOp(linops):
             start_r, start_c = end_r, end_c
         return y
 
-    return LinearOperator(matvec=matvec, shape=(height, width))
+    held = {}
+
+    def vec_apply(vec):
+        # device vectors: the blocks are the time steps of the slab -- the parallel
+        # operator of the same name on one rank (mpi_kron.BlockDiagMPI: equal blocks in
+        # one batched call)
+        assert uniform, 'device vectors need square blocks of one size'
+        assert vec.N == len(linops)
+        if 'op' not in held:
+            from .mpi_kron import BlockDiagMPI
+            held['op'] = BlockDiagMPI(self_distribution(len(linops), next(iter(shapes))[0]), linops)
+        return held['op'] @ vec
+
+    return DeviceLinearOperator((height, width), matvec, vec_apply)
 
 
 def BlockLinOp(linops):

@@ -761,6 +761,24 @@ class SerialKron:
         self._time = _lib.to_dev(np.ascontiguousarray(dense, dtype=np.float64))
         self._space = as_space_op(mat_space)
 
+    def _on_slab(self, xin, ld_in):
+        """(L, ld_in) slab of K time steps -> (M, ld_out) slab of N."""
+        ld_out = self.N + (self.N & 1)
+        z = torch.empty((self.L, ld_out), dtype=torch.float64, device=xin.device)
+        _lib.check(_lib.lib().stk_time_dense_apply(
+            _lib.stream(), self.L, self.K, ld_in, self.N, ld_out,
+            _lib.ptr(self._time), _lib.ptr(xin), _lib.ptr(z)))
+        return self._space.apply(z, n_loc=self.N)
+
+    def apply_vec(self, vec):
+        """The same map on a device vector (linop.device_vector: a one-rank
+        KronVectorMPI of K time steps by L space dofs): nothing leaves the device."""
+        from .linop import self_distribution
+        assert isinstance(vec, KronVectorMPI) and vec.dofs_distr.size == 1
+        assert (vec.N, vec.M) == (self.K, self.L), 'dimension mismatch'
+        y = self._on_slab(vec.buf, vec.ld)
+        return KronVectorMPI.around(self_distribution(self.N, self.M), y)
+
     def matvec(self, x):
         X = np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(self.K, self.L))
         ld_in, ld_out = self.K + (self.K & 1), self.N + (self.N & 1)

@@ -267,6 +267,22 @@ class KronVectorMPI:
     __array_ufunc__ = None
 
     def __init__(self, dofs_distr, initial_data=None):
+        self._describe(dofs_distr)
+        self.reset(initial_data)
+
+    @classmethod
+    def around(cls, dofs_distr, buf):
+        """The vector whose slab IS `buf` (an (M, ld) float64 device tensor an operator
+        just produced; ld = the local time steps rounded up to even): no copy."""
+        out = cls.__new__(cls)
+        out._describe(dofs_distr)
+        assert tuple(buf.shape) == (out.M, out.ld) and buf.dtype == torch.float64, (tuple(buf.shape), out.M, out.ld)
+        out.communicated_bdr = False
+        out.X_lo = out.X_hi = out._ghost = out._ghost_il = out._halo_send = out._records = None
+        out._buf = buf
+        return out
+
+    def _describe(self, dofs_distr):
         self.dofs_distr = dofs_distr
 
         # Convenience
@@ -282,8 +298,6 @@ class KronVectorMPI:
         # profiles/r04_b_op_J3_J9_ld16.log; the bytes count, not the alignment)
         self.ld = self.n_loc + (self.n_loc & 1)
         self._pending = None
-
-        self.reset(initial_data)
 
     # -- storage -------------------------------------------------------------
     @property

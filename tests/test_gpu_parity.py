@@ -1038,6 +1038,69 @@ def test_serial_driver_against_oracle(stk, precond):
     assert relerr(_np(hp.S @ xv).reshape(-1), h.S @ x) < 1e-11
 
 
+@pytest.mark.parametrize('precond', ['multigrid', 'direct'])
+def test_serial_operators_on_device_vectors(stk, precond):
+    """The serial operators (reference linop.py:6-65, heateq.py:37-91) applied to device
+    vectors: KronLinOp, sums and products of them, the Schur complement written as a
+    function and BlockDiagLinOp map a one-rank KronVectorMPI to one -- the doubles of
+    the flat-NumPy-vector path where the same kernels run (everything but the block
+    diagonal, whose host path hands each block an (M, k) array of its own stride) --
+    and HeatEquation.solve(), device-resident between one upload and one download,
+    gives the iteration count and the history of the host-vector wiring within 1e-10
+    of the oracle's."""
+    import heateq as hs
+    from oracle.heat_serial import HeatSerialOracle
+    from oracle.krylov import pcg
+    from source.assembly import prolongation_matrices
+    from source.linalg import PCG
+    from source.linop import DeviceLinearOperator, device_vector, host_vector
+    from source.mesh import construct_2d_square_mesh
+    from source.mpi_vector import KronVectorMPI
+    J_space, J_time = 3, 3
+    h = hs.HeatEquation(J_space=J_space, J_time=J_time, precond=precond)
+    x = np.random.RandomState(5).rand(h.N * h.M)
+    xd = device_vector(x, h.N)
+    assert np.array_equal(host_vector(xd), x)
+    for name in ('B', 'G', 'W', 'WT', 'S'):
+        op = getattr(h, name)
+        assert isinstance(op, DeviceLinearOperator), name
+        yd = op @ xd
+        assert isinstance(yd, KronVectorMPI) and yd.N * yd.M == op.shape[0], name
+        assert np.array_equal(host_vector(yd), op @ x), name
+    y = h.B @ x  # a vector of the test space: another number of time steps
+    yd = device_vector(y, h.N_Y)
+    assert np.array_equal(host_vector(h.K @ yd), h.K @ y)
+    assert np.array_equal(host_vector(h.BT @ yd), h.BT @ y)
+    for name in ('P', 'WT_S_W'):
+        op = getattr(h, name)
+        assert relerr(host_vector(op @ xd), op @ x) < 1e-12, name
+    # mixed use keeps SciPy's rules: a product with a plain LinearOperator is one
+    from scipy.sparse.linalg import LinearOperator, aslinearoperator
+    import scipy.sparse as sp
+    mixed = h.G @ aslinearoperator(sp.identity(h.N * h.M, format='csr'))
+    assert isinstance(mixed, LinearOperator) and not isinstance(mixed, DeviceLinearOperator)
+    assert relerr(mixed @ x, h.G @ x) < 1e-15
+    # the solve
+    seen = []
+    u, iters = h.solve(callback=lambda w, r, k: seen.append(type(w)))
+    u_host, iters_host = h.solve(on_host=True)
+    assert iters == iters_host and seen and all(t is KronVectorMPI for t in seen)
+    assert isinstance(u, np.ndarray) and relerr(u, u_host) < 1e-10
+    hist = []
+    PCG(h.WT_S_W, h.P, h.WT @ device_vector(h.f, h.N), history=hist)
+    mats = dict(h.time_mats, M_x=h.M_x, A_x=h.A_x, u0_x=h.u0_x,
+                P_mats=prolongation_matrices(construct_2d_square_mesh(J_space)[0]))
+    o = HeatSerialOracle(mats, J_time, precond=precond)
+    wo, iters_o, hist_o = pcg(o.WT_S_W, o.P, o.WT(o.f()))
+    assert iters == iters_o
+    _hist_dev('serial_driver_on_device_%s' % precond, hist, hist_o, 1e-10)
+    assert relerr(u, o.W(wo)) < 1e-10
+    e_alg, e_y = h.errors(u)  # device vectors inside; against the host-vector formulas
+    residual, defect = h.f - h.S @ u, h.g_vec - h.B @ u
+    assert abs(e_alg - residual @ (h.P @ residual)) <= 1e-9 * e_alg + 1e-24
+    assert abs(e_y - defect @ (h.K @ defect)) <= 1e-12 * e_y
+
+
 def test_c_pcg_solve_matches_python_pcg(stk):
     """stk_pcg_solve (C ABI, reference linalg.py:6-42) driven through ctypes
     callbacks into the same operators as the Python PCG: identical iteration
