@@ -20,13 +20,20 @@ import os
 import sys
 import time
 
-import numpy as np
-
 REPO = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(REPO, 'spacetime-fullgrid-parallel_amd')
 for p in (REPO, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
+if __name__ == '__main__':
+    # the allocator policy the drivers run under (source/host_malloc.py), set before
+    # anything starts a thread; reported in the line as pcg.host_allocator
+    from source.host_malloc import keep_to_the_heap
+    HOST_ALLOCATOR = 'heap' if keep_to_the_heap() else 'default'
+else:
+    HOST_ALLOCATOR = 'default'
+
+import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 XGMI_LINK_GBS_PER_DIRECTION = 76.8  # xGMI: 7 point-to-point links per GPU, ~153.6 GB/s bidirectional each
@@ -574,7 +581,7 @@ def main():
         if size > 1:
             dist.all_reduce(mb, op=dist.ReduceOp.SUM)
         model_total, model_tight = float(mb[0]), float(mb[1])
-        return {'arithmetic': arithmetic, 'setup_s': h.setup_time, 'per_rank': phases,
+        return {'arithmetic': arithmetic, 'setup_s': h.setup_time, 'host_allocator': HOST_ALLOCATOR, 'per_rank': phases,
                 'iters_timed': n_it, 'iters_per_s': n_it / ds,
                 'ms_per_iter': ds / n_it * 1e3,
                 'r_dot_Pr': [float(v) for v in hist],

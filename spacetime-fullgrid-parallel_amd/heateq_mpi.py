@@ -10,12 +10,17 @@ Launch one process per GPU:
 import os
 import sys
 
-import numpy as np
-import torch
-
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+if __name__ == '__main__':
+    # run as the driver, the allocator of the process is ours to set, and the time to do
+    # it is before anything starts a thread (source/host_malloc.py)
+    from source.host_malloc import keep_to_the_heap
+    keep_to_the_heap()
 
-from source import _lib, driver
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from source import _lib, driver  # noqa: E402
 from source.assembly import (prolongation_matrices, space_load,
                              space_matrices, time_matrices)
 from source.comm import MPI
@@ -245,6 +250,14 @@ class HeatEquationMPI:
                  family='batched',
                  arithmetic='accurate',
                  comm=None):
+        # the set-up's large host temporaries come from the heap (source/_lib.py: the
+        # planner threads otherwise queue on the address-space lock of the process)
+        with _lib.host_heap_for_setup():
+            self._set_up(J_space, J_time, problem, wavelettransform, precond, smoothsteps, alpha,
+                         vcycles, schur, family, arithmetic, comm)
+
+    def _set_up(self, J_space, J_time, problem, wavelettransform, precond, smoothsteps, alpha,
+                vcycles, schur, family, arithmetic, comm):
         start_time = MPI.Wtime()
         # (label, seconds since the start) of the stages of the set-up, for
         # tools/setup_profile.py --timeline

@@ -10,6 +10,9 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+if __name__ == '__main__':  # as heateq_mpi.py: before anything starts a thread
+    from source.host_malloc import keep_to_the_heap
+    keep_to_the_heap()
 
 from heateq_mpi import HeatEquationMPI  # noqa: E402
 from source import driver  # noqa: E402

@@ -347,6 +347,9 @@ def in_device_context(fn):
     return run
 
 
+from .host_malloc import host_heap_for_setup, keep_to_the_heap  # noqa: E402,F401
+
+
 def to_dev(array, dtype=None):
     """Uploads a NumPy array (used for CSR arrays and small tables)."""
     t = torch.from_numpy(np.ascontiguousarray(array))

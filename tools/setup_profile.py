@@ -1,6 +1,17 @@
 #!/usr/bin/env python3
 """Where the host time of the set-up goes: cProfile of the pieces of
 HeatEquationMPI.__init__ run one after the other (the driver overlaps them)."""
+import ctypes
+import os as _os
+import sys as _sys
+# tools/setup_malloc_ab.sh: allocator settings made before anything starts a thread
+if _os.environ.get('STK_EARLY_ARENA') == '1':
+    ctypes.CDLL(None).mallopt(-8, 1)
+if _os.environ.get('STK_HEAP') == '1':  # what bench.py and the drivers do
+    _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))),
+                                      'spacetime-fullgrid-parallel_amd'))
+    from source.host_malloc import keep_to_the_heap
+    keep_to_the_heap()
 import argparse
 import cProfile
 import os
