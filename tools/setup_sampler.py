@@ -12,6 +12,8 @@ import time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, 'spacetime-fullgrid-parallel_amd'))
+from source.host_malloc import keep_to_the_heap  # noqa: E402
+keep_to_the_heap()  # the allocator policy of the drivers (STK_KEEP_MALLOC=1: untouched)
 import torch  # noqa: E402
 import heateq_mpi as hm  # noqa: E402
 
