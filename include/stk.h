@@ -932,9 +932,9 @@ int stk_tri_refine(int64_t nv, int64_t nt, const double *points,
  * of its local vertex a is (sum_q (f_q w_q) l_qa) * |T|, q ascending, and an entry
  * sums its shares in ascending (t, a) -- no fused multiply-adds, the result depends
  * on the mesh alone, not on the number of host threads. */
-int stk_p1_load_points_2d(int64_t nt, const double *points, const int64_t *tris,
-                          int32_t nq, const double *rule_points, double *qx,
-                          double *qy);
+int stk_p1_load_points_2d(int64_t nv, int64_t nt, const double *points,
+                          const int64_t *tris, int32_t nq,
+                          const double *rule_points, double *qx, double *qy);
 int stk_p1_load_sum_2d(int64_t nv, int64_t nt, const double *points,
                        const int64_t *tris, int32_t nq,
                        const double *rule_weights, const double *rule_points,

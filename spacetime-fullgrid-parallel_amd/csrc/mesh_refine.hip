@@ -256,10 +256,14 @@ extern "C" int stk_tri_refine(int64_t nv, int64_t nt, const double *points, cons
 // source/assembly.py:space_load is the NumPy form).  Two calls around the caller's
 // evaluation of f at the quadrature points: their coordinates, then the sums.
 
-extern "C" int stk_p1_load_points_2d(int64_t nt, const double *points, const int64_t *tris, int32_t nq,
+extern "C" int stk_p1_load_points_2d(int64_t nv, int64_t nt, const double *points, const int64_t *tris, int32_t nq,
                                      const double *rule_points, double *qx, double *qy)
 {
-    STK_REQUIRE(nt > 0 && points && tris && nq > 0 && rule_points && qx && qy, "stk_p1_load_points_2d: bad arguments");
+    STK_REQUIRE(nv > 0 && nt > 0 && points && tris && nq > 0 && rule_points && qx && qy,
+                "stk_p1_load_points_2d: bad arguments");
+    for (int64_t q = 0; q < 3 * nt; ++q)
+        STK_REQUIRE(tris[q] >= 0 && tris[q] < nv, "stk_p1_load_points_2d: triangle %lld names vertex %lld",
+                    (long long)(q / 3), (long long)tris[q]);
     const int T = host_threads(nt * nq);
     on_threads(T, [&](int k) {
         for (int64_t t = share(nt, T, k); t < share(nt, T, k + 1); ++t) {

@@ -243,7 +243,7 @@ _PROTOTYPES = {
     'stk_p1_result_sizes': (ctypes.c_int, [c_p, c_p, c_p, c_p]),
     'stk_p1_result_copy': (ctypes.c_int, [c_p, c_i32, c_p, c_p, c_p]),
     'stk_p1_result_free': (ctypes.c_int, [c_p]),
-    'stk_p1_load_points_2d': (ctypes.c_int, [c_i64, c_p, c_p, c_i32, c_p, c_p, c_p]),
+    'stk_p1_load_points_2d': (ctypes.c_int, [c_i64, c_i64, c_p, c_p, c_i32, c_p, c_p, c_p]),
     'stk_p1_load_sum_2d': (ctypes.c_int, [c_i64, c_i64, c_p, c_p, c_i32, c_p, c_p, c_p, c_p]),
     'stk_tri_refine': (ctypes.c_int, [c_i64, c_i64, c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p]),
     'stk_mg_destroy': (ctypes.c_int, [c_p]),

@@ -344,7 +344,7 @@ def _space_load_libstk(mesh, fn):
     nt, nq = len(cells), len(_QW)
     qw, ql = np.ascontiguousarray(_QW), np.ascontiguousarray(_QL)
     qx, qy = np.empty((nt, nq)), np.empty((nt, nq))
-    _lib.check(lib.stk_p1_load_points_2d(nt, pts.ctypes.data, cells.ctypes.data, nq, ql.ctypes.data,
+    _lib.check(lib.stk_p1_load_points_2d(mesh.nv, nt, pts.ctypes.data, cells.ctypes.data, nq, ql.ctypes.data,
                                          qx.ctypes.data, qy.ctypes.data))
     f = np.empty((nt, nq))
     parts = max(1, min(8, os.cpu_count() or 1, nt // 16384))
