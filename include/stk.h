@@ -940,6 +940,28 @@ int stk_p1_load_sum_2d(int64_t nv, int64_t nt, const double *points,
                        const double *rule_weights, const double *rule_points,
                        const double *f, double *vec);
 
+/* ---- plan construction on the host threads: processing order and union pattern ---
+ * stk_tile_order: the mesh-tile order of n dofs with coordinates coords [n][d]
+ * (d = 2 or 3): the bounding box cut into cubes of edge `side` from the corner `lo`
+ * (the caller's choice: source/assembly.py takes about 2 048 dofs per tile), tiles
+ * visited lexicographically with the last axis slowest and the dofs of a tile
+ * likewise; ties by index.  A performance hint for the gather kernels
+ * (stk_kron_*_apply's row_ids): results never depend on it.
+ * stk_csr_union_count / _fill: one CSR pattern holding the patterns of n_mats
+ * matrices of n rows (each with strictly ascending columns per row), and every
+ * matrix's values on it, zeros where it has no entry -- what SumMPI's terms
+ * (mpi_kron.py:186-200) become for a fused pass.  _count writes out_indptr [n + 1];
+ * the caller allocates out_indices and out_data[k] of out_indptr[n] entries;
+ * _fill writes them. */
+int stk_tile_order(int64_t n, int32_t d, const double *coords, const double *lo,
+                   double side, int32_t *order);
+int stk_csr_union_count(int64_t n, int32_t n_mats, const int32_t *const *indptr,
+                        const int32_t *const *indices, int32_t *out_indptr);
+int stk_csr_union_fill(int64_t n, int32_t n_mats, const int32_t *const *indptr,
+                       const int32_t *const *indices, const double *const *data,
+                       const int32_t *out_indptr, int32_t *out_indices,
+                       double *const *out_data);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -65,7 +66,8 @@ inline int64_t share(int64_t n, int T, int k) { return n * k / T; }
 
 // keys[0 .. n) into ascending order: samples pick T - 1 splitters, every thread
 // scatters its share into the buckets and then sorts one bucket
-void sample_sort(std::vector<EdgeKey> &keys, int T)
+template <class Key, class Less>
+void sample_sort(std::vector<Key> &keys, int T, Less before)
 {
     const int64_t n = (int64_t)keys.size();
     if (T == 1 || n < 65536) {
@@ -73,13 +75,13 @@ void sample_sort(std::vector<EdgeKey> &keys, int T)
         return;
     }
     const int per = 64;
-    std::vector<EdgeKey> sample;
+    std::vector<Key> sample;
     sample.reserve((size_t)T * per);
     for (int64_t s = 0; s < (int64_t)T * per; ++s) sample.push_back(keys[(size_t)((2 * s + 1) * n / (2 * (int64_t)T * per))]);
     std::sort(sample.begin(), sample.end(), before);
-    std::vector<EdgeKey> split;
+    std::vector<Key> split;
     for (int k = 1; k < T; ++k) split.push_back(sample[(size_t)k * per]);
-    auto bucket_of = [&](const EdgeKey &q) {
+    auto bucket_of = [&](const Key &q) {
         return (int)(std::upper_bound(split.begin(), split.end(), q, before) - split.begin());
     };
     std::vector<int32_t> where((size_t)n);
@@ -101,7 +103,7 @@ void sample_sort(std::vector<EdgeKey> &keys, int T)
         }
     }
     begin[T] = run;
-    std::vector<EdgeKey> out((size_t)n);
+    std::vector<Key> out((size_t)n);
     on_threads(T, [&](int k) {
         int64_t *mine = &at[(size_t)k * T];
         for (int64_t i = share(n, T, k); i < share(n, T, k + 1); ++i) out[mine[where[i]]++] = keys[i];
@@ -109,6 +111,12 @@ void sample_sort(std::vector<EdgeKey> &keys, int T)
     on_threads(T, [&](int b) { std::sort(out.begin() + begin[b], out.begin() + begin[b + 1], before); });
     keys.swap(out);
 }
+
+struct TileKey {  // sort key of a dof in the mesh-tile order
+    int64_t t[3];
+    double c[3];
+    int64_t i;
+};
 
 }  // namespace
 
@@ -222,7 +230,7 @@ extern "C" int stk_tri_refine(int64_t nv, int64_t nt, const double *points, cons
     });
     STK_REQUIRE(!clash.load(), "stk_tri_refine: the two triangles of an edge give it different colours");
     // --- numbering of the new vertices ---
-    sample_sort(keys, T);
+    sample_sort(keys, T, before);
     std::vector<int64_t> new_id((size_t)ne);
     on_threads(T, [&](int k) {
         for (int64_t r = share(ne, T, k); r < share(ne, T, k + 1); ++r) {
@@ -338,5 +346,125 @@ extern "C" int stk_p1_load_sum_2d(int64_t nv, int64_t nt, const double *points, 
             vec[v] = sum;
         }
     });
+    return 0;
+}
+
+// ---- processing order of the dofs: mesh tiles ------------------------------------
+// (source/assembly.py:tile_order_from_coords, its NumPy form: np.lexsort over the
+// coordinates and the tile indices floor((p - lo) / side), last axis slowest.)  The
+// caller computes lo and side, so the only arithmetic here is that subtraction,
+// division and floor: the order is NumPy's, index for index.
+
+extern "C" int stk_tile_order(int64_t n, int32_t d, const double *coords, const double *lo, double side,
+                              int32_t *order)
+{
+    STK_REQUIRE(n > 0 && (d == 2 || d == 3) && coords && lo && side > 0 && order, "stk_tile_order: bad arguments");
+    STK_REQUIRE(n < ((int64_t)1 << 31), "stk_tile_order: %lld points do not fit 32-bit indices", (long long)n);
+    const int T = host_threads(n);
+    std::vector<TileKey> keys((size_t)n);
+    on_threads(T, [&](int k) {
+        for (int64_t i = share(n, T, k); i < share(n, T, k + 1); ++i) {
+            TileKey &q = keys[i];
+            for (int a = 0; a < 3; ++a) q.t[a] = 0, q.c[a] = 0.0;
+            for (int a = 0; a < d; ++a) {
+                q.c[a] = coords[i * d + a];
+                q.t[a] = (int64_t)std::floor((q.c[a] - lo[a]) / side);
+            }
+            q.i = i;
+        }
+    });
+    sample_sort(keys, T, [](const TileKey &a, const TileKey &b) {
+        for (int k = 2; k >= 0; --k)
+            if (a.t[k] != b.t[k]) return a.t[k] < b.t[k];
+        for (int k = 2; k >= 0; --k)
+            if (a.c[k] != b.c[k]) return a.c[k] < b.c[k];
+        return a.i < b.i;  // lexsort is stable
+    });
+    on_threads(T, [&](int k) {
+        for (int64_t r = share(n, T, k); r < share(n, T, k + 1); ++r) order[r] = (int32_t)keys[r].i;
+    });
+    return 0;
+}
+
+// ---- one CSR pattern for several matrices -----------------------------------------
+// (source/linop.py:union_pattern: the fused kernels walk one pattern for all terms of
+// a Kronecker sum, mpi_kron.py:186-200 SumMPI.)  Rows with ascending columns and no
+// duplicates in, the merged rows out; every matrix's values land on the union in their
+// own order, zeros where it has no entry.  Two calls: the row sizes, then the entries.
+
+extern "C" int stk_csr_union_count(int64_t n, int32_t n_mats, const int32_t *const *indptr,
+                                   const int32_t *const *indices, int32_t *out_indptr)
+{
+    STK_REQUIRE(n > 0 && n_mats >= 1 && n_mats <= 30 && indptr && indices && out_indptr, "stk_csr_union_count: bad arguments");
+    const int T = host_threads(n * 8);
+    std::atomic<int> bad{0};
+    std::vector<int32_t> count((size_t)n);
+    on_threads(T, [&](int k) {
+        std::vector<int32_t> at((size_t)n_mats);
+        for (int64_t r = share(n, T, k); r < share(n, T, k + 1); ++r) {
+            for (int m = 0; m < n_mats; ++m) {
+                at[m] = indptr[m][r];
+                for (int32_t p = indptr[m][r] + 1; p < indptr[m][r + 1]; ++p)
+                    if (indices[m][p] <= indices[m][p - 1]) bad = 1;
+            }
+            int32_t c = 0;
+            for (;;) {
+                int64_t col = INT64_MAX;
+                for (int m = 0; m < n_mats; ++m)
+                    if (at[m] < indptr[m][r + 1]) col = std::min<int64_t>(col, indices[m][at[m]]);
+                if (col == INT64_MAX) break;
+                for (int m = 0; m < n_mats; ++m)
+                    if (at[m] < indptr[m][r + 1] && indices[m][at[m]] == col) ++at[m];
+                ++c;
+            }
+            count[r] = c;
+        }
+    });
+    STK_REQUIRE(!bad.load(), "stk_csr_union_count: a row's columns are not strictly ascending");
+    int64_t run = 0;
+    for (int64_t r = 0; r < n; ++r) {
+        out_indptr[r] = (int32_t)run;
+        run += count[r];
+    }
+    STK_REQUIRE(run < ((int64_t)1 << 31), "stk_csr_union_count: %lld entries do not fit 32-bit offsets", (long long)run);
+    out_indptr[n] = (int32_t)run;
+    return 0;
+}
+
+extern "C" int stk_csr_union_fill(int64_t n, int32_t n_mats, const int32_t *const *indptr,
+                                  const int32_t *const *indices, const double *const *data,
+                                  const int32_t *out_indptr, int32_t *out_indices, double *const *out_data)
+{
+    STK_REQUIRE(n > 0 && n_mats >= 1 && n_mats <= 30 && indptr && indices && data && out_indptr && out_indices && out_data,
+                "stk_csr_union_fill: bad arguments");
+    const int T = host_threads(n * 8);
+    std::atomic<int> bad{0};
+    on_threads(T, [&](int k) {
+        std::vector<int32_t> at((size_t)n_mats);
+        for (int64_t r = share(n, T, k); r < share(n, T, k + 1); ++r) {
+            for (int m = 0; m < n_mats; ++m) at[m] = indptr[m][r];
+            int32_t o = out_indptr[r];
+            for (;;) {
+                int64_t col = INT64_MAX;
+                for (int m = 0; m < n_mats; ++m)
+                    if (at[m] < indptr[m][r + 1]) col = std::min<int64_t>(col, indices[m][at[m]]);
+                if (col == INT64_MAX) break;
+                if (o >= out_indptr[r + 1]) {
+                    bad = 1;
+                    break;
+                }
+                out_indices[o] = (int32_t)col;
+                for (int m = 0; m < n_mats; ++m) {
+                    if (at[m] < indptr[m][r + 1] && indices[m][at[m]] == col)
+                        out_data[m][o] = data[m][at[m]++];
+                    else
+                        out_data[m][o] = 0.0;
+                }
+                ++o;
+            }
+            if (o != out_indptr[r + 1]) bad = 1;
+        }
+    });
+    STK_REQUIRE(!bad.load(), "stk_csr_union_fill: the row sizes are not those of stk_csr_union_count");
     return 0;
 }

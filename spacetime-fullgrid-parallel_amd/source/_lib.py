@@ -245,6 +245,9 @@ _PROTOTYPES = {
     'stk_p1_result_free': (ctypes.c_int, [c_p]),
     'stk_p1_load_points_2d': (ctypes.c_int, [c_i64, c_i64, c_p, c_p, c_i32, c_p, c_p, c_p]),
     'stk_p1_load_sum_2d': (ctypes.c_int, [c_i64, c_i64, c_p, c_p, c_i32, c_p, c_p, c_p, c_p]),
+    'stk_tile_order': (ctypes.c_int, [c_i64, c_i32, c_p, c_p, c_f64, c_p]),
+    'stk_csr_union_count': (ctypes.c_int, [c_i64, c_i32, c_p, c_p, c_p]),
+    'stk_csr_union_fill': (ctypes.c_int, [c_i64, c_i32, c_p, c_p, c_p, c_p, c_p, c_p]),
     'stk_tri_refine': (ctypes.c_int, [c_i64, c_i64, c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p]),
     'stk_mg_destroy': (ctypes.c_int, [c_p]),
     'stk_mg_set_option': (ctypes.c_int, [c_p, ctypes.c_char_p, c_i32]),

@@ -154,6 +154,10 @@ def _rows_per_tile(rows_per_tile):
     return rows_per_tile
 
 
+# point sets of at least this many dofs are ordered by libstk's host threads
+TILE_ORDER_ON_HOST_THREADS = 16384
+
+
 def tile_order_from_coords(coords, rows_per_tile=None, small_lexsort=True):
     """A processing order that follows the geometry: the bounding box is cut
     into square (cubic) tiles of about `rows_per_tile` vertices, tiles are
@@ -168,9 +172,21 @@ def tile_order_from_coords(coords, rows_per_tile=None, small_lexsort=True):
     ext = np.maximum(hi - lo, 1e-30)
     ntiles = max(1.0, len(p) / float(rows_per_tile))
     side = (np.prod(ext) / ntiles)**(1.0 / d)
+    snake = os.environ.get('STK_TILE_WALK') == 'snake' and d == 2
+    if len(p) >= TILE_ORDER_ON_HOST_THREADS and d in (2, 3) and not snake and __package__:
+        # the same order on the host threads of libstk (stk_tile_order: a sample sort;
+        # tests/test_host_cpu.py test_plan_helpers_on_host_threads).  Not when this file
+        # is loaded alone, without its package (the fixture generator under tests/golden)
+        from . import _lib
+        pts = np.ascontiguousarray(p, dtype=np.float64)
+        corner = np.ascontiguousarray(lo, dtype=np.float64)
+        order = np.empty(len(p), dtype=np.int32)
+        _lib.check(_lib.lib().stk_tile_order(len(p), d, pts.ctypes.data, corner.ctypes.data, float(side),
+                                             order.ctypes.data))
+        return order
     tiles = tuple(np.floor((p[:, k] - lo[k]) / side).astype(np.int64)
                   for k in range(d))
-    if os.environ.get('STK_TILE_WALK') == 'snake' and d == 2:
+    if snake:
         # EXPERIMENT (measured and not adopted):
         # a boustrophedon walk inside a tile -- every other mesh row of a tile from right to
         # left, so that the two readers of a gathered row above / below sit closer together

@@ -118,11 +118,12 @@ class MeshHierarchy:
         """Everything plans share, ahead of time (the driver calls it in the thread
         that builds the hierarchy, beside the assembly of the matrices)."""
         sizes = [P.shape[1] for P in self.P_mats] + ([self.P_mats[-1].shape[0]] if self.P_mats else [])
-        for n in sizes:
+        # finest first: the plans start with their finest level, and it is the long one
+        for n in reversed(sizes):
             self.tile_order(n)
             self.coord_band(n)
         if _lib.compute_device().type == 'cuda':
-            for j in range(1, self.J + 1):
+            for j in reversed(range(1, self.J + 1)):
                 self.transfer_copies(j)
         return self
 

@@ -505,6 +505,100 @@ def test_host_allocator_policy():
     assert out[('heap', True)][0] == 0 and out[('heap', True)][1] * 2 > later_default
 
 
+def test_plan_helpers_on_host_threads(monkeypatch):
+    """stk_tile_order and stk_csr_union_count / _fill (csrc/mesh_refine.hip; host threads
+    of libstk) against the NumPy / SciPy forms they stand in for on large inputs
+    (source/assembly.py:tile_order_from_coords, source/linop.py:_union_pattern): the same
+    arrays entry for entry, in two and three dimensions, for two and three matrices with
+    explicit zeros and empty rows, whatever the number of threads; unsorted rows are
+    refused."""
+    import ctypes
+
+    import scipy.sparse as sp
+    from source import _lib, assembly, linop
+    from source.problem import problem_helper
+
+    rng = np.random.RandomState(3)
+    # ---- tile order ----
+    grid = np.stack(np.meshgrid(*[np.arange(1, 30) / 30.0] * 3, indexing='ij'), axis=-1).reshape(-1, 3)
+    for problem, J in (('square', 7), ('lshape', 6), ('grid points in the cube', None)):
+        if J is None:
+            pts = grid[rng.permutation(len(grid))]
+        else:
+            mesh = problem_helper(problem, J_space=J, J_time=2)[0]
+            pts = mesh.points[~mesh.boundary]
+        assert len(pts) >= assembly.TILE_ORDER_ON_HOST_THREADS, (problem, len(pts))
+        monkeypatch.setattr(assembly, 'TILE_ORDER_ON_HOST_THREADS', 1 << 60)
+        ref = assembly.tile_order_from_coords(pts, small_lexsort=False)
+        ref_small = assembly.tile_order_from_coords(pts, rows_per_tile=300, small_lexsort=False)
+        monkeypatch.setattr(assembly, 'TILE_ORDER_ON_HOST_THREADS', 16384)
+        for threads in (None, '1', '3'):
+            if threads is None:
+                monkeypatch.delenv('STK_HOST_THREADS', raising=False)
+            else:
+                monkeypatch.setenv('STK_HOST_THREADS', threads)
+            got = assembly.tile_order_from_coords(pts, small_lexsort=False)
+            assert got.dtype == ref.dtype and np.array_equal(got, ref), (problem, threads)
+            assert np.array_equal(assembly.tile_order_from_coords(pts, rows_per_tile=300, small_lexsort=False),
+                                  ref_small)
+    monkeypatch.delenv('STK_HOST_THREADS', raising=False)
+    # points that coincide in every key keep their index order (lexsort is stable)
+    same = np.repeat(rng.rand(4000, 2), 5, axis=0)
+    monkeypatch.setattr(assembly, 'TILE_ORDER_ON_HOST_THREADS', 1 << 60)
+    ref = assembly.tile_order_from_coords(same, small_lexsort=False)
+    monkeypatch.setattr(assembly, 'TILE_ORDER_ON_HOST_THREADS', 16384)
+    assert np.array_equal(assembly.tile_order_from_coords(same, small_lexsort=False), ref)
+
+    # ---- union pattern ----
+    def csr32(m):
+        m = sp.csr_matrix(m)
+        m.sort_indices()
+        m.sum_duplicates()
+        m.indices, m.indptr = m.indices.astype(np.int32), m.indptr.astype(np.int32)
+        return m
+
+    n = 30000
+    mats = [csr32(sp.coo_matrix((rng.rand(4 * n), (rng.randint(n, size=4 * n), rng.randint(n, size=4 * n))),
+                                shape=(n, n))) for _ in range(3)]
+    mats[0].data[::7] = 0.0  # explicit zeros stay entries of the pattern
+    mats[1] = csr32(mats[1] + sp.identity(n, format='csr'))
+    for group in (mats[:2], mats, [mats[2], mats[0]]):
+        monkeypatch.setattr(linop, 'UNION_ON_HOST_THREADS', 1 << 60)
+        ref = linop._union_pattern(group)
+        monkeypatch.setattr(linop, 'UNION_ON_HOST_THREADS', 1)
+        for threads in (None, '1', '5'):
+            if threads is None:
+                monkeypatch.delenv('STK_HOST_THREADS', raising=False)
+            else:
+                monkeypatch.setenv('STK_HOST_THREADS', threads)
+            got = linop._union_pattern(group)
+            assert got[0].dtype == ref[0].dtype and np.array_equal(got[0], ref[0])
+            assert got[1].dtype == ref[1].dtype and np.array_equal(got[1], ref[1])
+            assert len(got[2]) == len(ref[2])
+            for a, b in zip(got[2], ref[2]):
+                assert a.dtype == b.dtype and np.array_equal(a, b)
+    monkeypatch.delenv('STK_HOST_THREADS', raising=False)
+    # the assembled matrices of a mesh (what the plans unite)
+    mesh = problem_helper('square', J_space=6, J_time=2)[0]
+    M_x, A_x = assembly.space_matrices(mesh)
+    monkeypatch.setattr(linop, 'UNION_ON_HOST_THREADS', 1 << 60)
+    ref = linop._union_pattern([M_x, A_x])
+    monkeypatch.setattr(linop, 'UNION_ON_HOST_THREADS', 1)
+    got = linop._union_pattern([M_x, A_x])
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    assert all(np.array_equal(a, b) for a, b in zip(got[2], ref[2]))
+    # unsorted rows
+    bad = mats[0].copy()
+    row = int(np.argmax(np.diff(bad.indptr) >= 2))
+    lo = bad.indptr[row]
+    bad.indices[lo], bad.indices[lo + 1] = bad.indices[lo + 1], bad.indices[lo]
+    ptrs = (ctypes.c_void_p * 2)(bad.indptr.ctypes.data, mats[1].indptr.ctypes.data)
+    idxs = (ctypes.c_void_p * 2)(bad.indices.ctypes.data, mats[1].indices.ctypes.data)
+    out = np.empty(n + 1, dtype=np.int32)
+    assert _lib.lib().stk_csr_union_count(n, 2, ptrs, idxs, out.ctypes.data) != 0
+    assert b'ascending' in _lib.lib().stk_last_error()
+
+
 def test_numbering_gives_shallow_gauss_seidel_schedules():
     """The build-owned numbering (source/mesh.py) orders the new vertices of a
     level by edge class with the hypotenuse class last: the sequential sweep of
