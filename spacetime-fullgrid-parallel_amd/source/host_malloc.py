@@ -57,7 +57,8 @@ class host_heap_for_setup:
     """The same for the duration of a set-up only (HeatEquationMPI.__init__): on exit the
     defaults are back and the free pages are returned to the system (malloc_trim).
     Helps as far as the planner threads allocate from the main arena (see
-    keep_to_the_heap); a no-op once keep_to_the_heap() was called."""
+    keep_to_the_heap); a no-op once keep_to_the_heap() was called.  The limit of one
+    arena for threads started from now on is the one setting that stays."""
     def __enter__(self):
         global _users
         self._libc = None if _permanent else _libc()
