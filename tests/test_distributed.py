@@ -105,6 +105,25 @@ def test_baseline_config_in_its_eight_rank_shape_equals_the_one_rank_solve(J_tim
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('problem,J_time,J_space,ranks,wavelets', [
+    ('lshape', 5, 8, 8, 'composite'), ('square', 5, 8, 3, 'original'), ('square', 5, 8, 5, 'interleaved')])
+def test_other_shapes_of_the_solve_on_several_ranks_equal_the_one_rank_solve(problem, J_time, J_space, ranks, wavelets):
+    """What the eight-rank tests above leave out: BASELINE config 4 (the L-shape, J_time = 5,
+    J_space = 8: matrices without the square's repeated values, i.e. the plans with explicit
+    values) cut into eight slabs, and the wavelet transform as a matrix between two
+    all-to-all exchanges (heateq_mpi.py:126-139 'original' and 'interleaved':
+    MatKronIdentityMPI, mpi_kron.py:225-256) on three and five ranks -- each bit for bit
+    the one-rank solve; the L-shape also within 1e-10 of the oracle's trajectory."""
+    env = dict(os.environ, STK_TEST_THREAD_RANKS=str(ranks), STK_TEST_J_TIME=str(J_time),
+               STK_TEST_J_SPACE=str(J_space), STK_TEST_PROBLEM=problem, STK_TEST_WAVELETS=wavelets,
+               OMP_NUM_THREADS='1')
+    res = subprocess.run([sys.executable, os.path.join(HERE, 'mp_parity_worker.py')], env=env,
+                         capture_output=True, text=True, timeout=1500)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    assert 'mp_parity_worker ok' in res.stdout
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('nproc', [1, 2, 3])
 def test_every_operator_class_on_several_ranks(nproc):
     """Every operator class and the vector algebra against dense NumPy ground
