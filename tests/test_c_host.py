@@ -1,4 +1,6 @@
-"""A host without Python on the C ABI: tests/c_host/kron_host.c is plain C99, compiled
+"""Hosts without Python on the C ABI.  tests/c_host/setup_host.c drives the set-up entry
+points that run on the library's host threads (no GPU needed: it runs in the CPU suite).
+tests/c_host/kron_host.c is plain C99, compiled
 with gcc against include/stk.h and linked with libstk.so -- plan from CSR arrays, slab
 storage, the Kronecker apply and a dot product, checked inside the program against the
 triple loop of the definition.  Without a GPU the program is compiled and linked (the
@@ -12,10 +14,11 @@ import pytest
 from conftest import PKG, REPO
 
 SRC = os.path.join(REPO, 'tests', 'c_host', 'kron_host.c')
+SETUP_SRC = os.path.join(REPO, 'tests', 'c_host', 'setup_host.c')
 ROCM = os.environ.get('ROCM_PATH', '/opt/rocm')
 
 
-def _build(out):
+def _build(out, src=SRC):
     # a host without the ROCm headers, libamdhip64 or a built libstk.so (a sanitiser
     # build of the host library, a CPU-only machine) cannot compile or link the
     # program: skip, do not fail the CPU suite
@@ -27,7 +30,7 @@ def _build(out):
     if missing:
         pytest.skip('cannot build the C host here: %s missing' % ', '.join(missing))
     cmd = ['gcc', '-std=c99', '-O2', '-Wall', '-Werror', '-D__HIP_PLATFORM_AMD__',
-           '-I' + os.path.join(REPO, 'include'), '-I' + os.path.join(ROCM, 'include'), SRC, '-o', out,
+           '-I' + os.path.join(REPO, 'include'), '-I' + os.path.join(ROCM, 'include'), src, '-o', out,
            '-L' + PKG, '-lstk', '-L' + os.path.join(ROCM, 'lib'), '-lamdhip64', '-lm',
            '-Wl,-rpath,' + PKG, '-Wl,-rpath,' + os.path.join(ROCM, 'lib')]
     res = subprocess.run(cmd, capture_output=True, text=True)
@@ -37,6 +40,20 @@ def _build(out):
 
 def test_c_host_compiles_and_links(tmp_path):
     _build(str(tmp_path / 'kron_host'))
+
+
+@pytest.mark.parametrize('levels', [1, 5, 7])
+def test_c_host_runs_the_set_up_calls(tmp_path, levels):
+    """tests/c_host/setup_host.c: the set-up entry points that run on the host threads of
+    the library -- stk_tri_refine, stk_p1_assemble_2d, stk_p1_load_*, stk_csr_union_*,
+    stk_tile_order -- from plain C, on the unit square, checked in the program against
+    what the mesh dictates (vertex and entry counts of the three-direction grid, the area,
+    the integral of x, the union pattern of (M, A) being M's).  No GPU is touched."""
+    exe = _build(str(tmp_path / 'setup_host'), SETUP_SRC)
+    res = subprocess.run([exe, str(levels)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and 'setup_host ok' in res.stdout, res.stdout + res.stderr
+    side = 2 ** levels
+    assert '%d vertices' % ((side + 1) ** 2) in res.stdout and '%d free dofs' % ((side - 1) ** 2) in res.stdout
 
 
 @pytest.mark.gpu
