@@ -7,16 +7,22 @@ the reference's ``source`` package, so that directory is put on sys.path.
 import os
 import sys
 
-import numpy as np
-import pytest
-import scipy.sparse as sp
-
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(REPO, 'spacetime-fullgrid-parallel_amd')
 GOLDEN = os.path.join(REPO, 'tests', 'golden')
 for p in (REPO, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
+if os.environ.get('STK_TEST_HEAP') == '1':
+    # the suite under the allocator policy the drivers and bench.py run with
+    # (source/host_malloc.py; by default a test process keeps glibc's settings and every
+    # HeatEquationMPI scopes the heap mode to its own set-up)
+    from source.host_malloc import keep_to_the_heap
+    keep_to_the_heap()
+
+import numpy as np  # noqa: E402
+import pytest  # noqa: E402
+import scipy.sparse as sp  # noqa: E402
 
 
 def pytest_configure(config):
