@@ -39,6 +39,7 @@ PROBLEM = os.environ.get('STK_TEST_PROBLEM', 'square')
 # 'composite' (the default; the oracle's trajectories were produced with it), 'original' or
 # 'interleaved': the wavelet transform as a matrix between two all-to-all exchanges
 WAVELETS = os.environ.get('STK_TEST_WAVELETS', 'composite')
+LANCZOS = os.environ.get('STK_TEST_LANCZOS') == '1'
 SETUP = threading.Lock()  # plan construction reads process-wide tuning keys: one rank at a time
 # The overlapped halo form (pass without the ghost steps beside the exchange, boundary
 # steps recomputed afterwards from the records the pack leaves) is the default; one case of
@@ -73,10 +74,19 @@ def solve(comm):
         return out
 
     y = gathered(metric @ x)
-    del x, metric
+    del metric
     hist = []
     w, its = PCG(h.WT_S_W, h.P, h.rhs, history=hist)
-    return its, np.asarray(hist), gathered(w), y, (h.N, h.M)
+    out = (its, np.asarray(hist), gathered(w), y, (h.N, h.M))
+    if LANCZOS:
+        # the condition-number estimate of the preconditioned system (reference
+        # lanczos.py:9-171) from the bench vector: its recurrence is inner products and
+        # applies only, so its coefficients do not see the partition either
+        from source.lanczos import Lanczos
+        lz = Lanczos(h.WT_S_W, h.P, w=x)
+        k = int(np.flatnonzero(lz.alpha)[-1]) + 1
+        out = out + ((lz.alpha[:k].copy(), lz.beta[:k - 1].copy(), lz.lmax, lz.lmin),)
+    return out
 
 
 def main():
@@ -95,8 +105,15 @@ def main():
     if rank != 0:
         return
     torch.cuda.empty_cache()
-    its, hist, w, y, (N, M) = got
-    its1, hist1, w1, y1, _ = solve(Comm(distributed=False))
+    its, hist, w, y, (N, M) = got[:5]
+    one = solve(Comm(distributed=False))
+    its1, hist1, w1, y1, _ = one[:5]
+    if LANCZOS:
+        (alpha, beta, lmax, lmin), (alpha1, beta1, lmax1, lmin1) = got[5], one[5]
+        assert len(alpha) == len(alpha1) > 3, (len(alpha), len(alpha1))
+        assert np.array_equal(alpha, alpha1) and np.array_equal(beta, beta1), 'Lanczos coefficients'
+        assert lmax == lmax1 and lmin == lmin1 and 0 < lmin < lmax, (lmax, lmin)
+        print('Lanczos: %d steps, lmax %.6f lmin %.6f, equal to the one-rank run' % (len(alpha), lmax, lmin))
     # the partition of the time axis leaves no trace
     assert np.array_equal(y, y1), ('metric operator', float(np.max(np.abs(y - y1))))
     assert its == its1, (its, its1)

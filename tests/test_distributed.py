@@ -113,10 +113,14 @@ def test_other_shapes_of_the_solve_on_several_ranks_equal_the_one_rank_solve(pro
     values) cut into eight slabs, and the wavelet transform as a matrix between two
     all-to-all exchanges (heateq_mpi.py:126-139 'original' and 'interleaved':
     MatKronIdentityMPI, mpi_kron.py:225-256) on three and five ranks -- each bit for bit
-    the one-rank solve; the L-shape also within 1e-10 of the oracle's trajectory."""
+    the one-rank solve; the L-shape also within 1e-10 of the oracle's trajectory, and with
+    the coefficients and the extreme Ritz values of the Lanczos recurrence on the
+    preconditioned system equal to the one-rank run's."""
     env = dict(os.environ, STK_TEST_THREAD_RANKS=str(ranks), STK_TEST_J_TIME=str(J_time),
                STK_TEST_J_SPACE=str(J_space), STK_TEST_PROBLEM=problem, STK_TEST_WAVELETS=wavelets,
                OMP_NUM_THREADS='1')
+    if problem == 'lshape':  # ... and the Lanczos recurrence (lanczos.py:9-171) on the eight slabs
+        env['STK_TEST_LANCZOS'] = '1'
     res = subprocess.run([sys.executable, os.path.join(HERE, 'mp_parity_worker.py')], env=env,
                          capture_output=True, text=True, timeout=1500)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
