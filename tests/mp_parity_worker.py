@@ -40,6 +40,7 @@ PROBLEM = os.environ.get('STK_TEST_PROBLEM', 'square')
 # 'interleaved': the wavelet transform as a matrix between two all-to-all exchanges
 WAVELETS = os.environ.get('STK_TEST_WAVELETS', 'composite')
 LANCZOS = os.environ.get('STK_TEST_LANCZOS') == '1'
+PRECOND = os.environ.get('STK_TEST_PRECOND', 'multigrid')  # or 'direct' (heateq_mpi.py:155-157)
 SETUP = threading.Lock()  # plan construction reads process-wide tuning keys: one rank at a time
 # The overlapped halo form (pass without the ghost steps beside the exchange, boundary
 # steps recomputed afterwards from the records the pack leaves) is the default; one case of
@@ -62,7 +63,7 @@ def solve(comm):
     """(iterations, history, iterate, metric output) -- the last two gathered on rank 0."""
     with SETUP:
         h = hm.HeatEquationMPI(J_space=J_SPACE, J_time=J_TIME, problem=PROBLEM, comm=comm,
-                               wavelettransform=WAVELETS)
+                               wavelettransform=WAVELETS, precond=PRECOND)
     dd = h.dofs_distr
     X = bench_vector(h.N, h.M)
     x = KronVectorMPI(dd, X[dd.t_begin:dd.t_end])
@@ -125,7 +126,8 @@ def main():
                                              'threads' if threads else 'processes', WAVELETS, its))
         return
     # ... and the trajectory is the CPU path's
-    g = np.load(os.path.join(HERE, 'golden', 'o1_pcg_%s_J%d_J%d.npz' % (PROBLEM, J_TIME, J_SPACE)))
+    g = np.load(os.path.join(HERE, 'golden', 'o1_pcg_%s_J%d_J%d%s.npz' % (
+        PROBLEM, J_TIME, J_SPACE, '' if PRECOND == 'multigrid' else '_' + PRECOND)))
     assert its == int(g['iters']), (its, int(g['iters']))
     dev = float(np.max(np.abs(hist / g['hist'] - 1.0)))
     assert dev < 1e-10, dev
@@ -139,7 +141,8 @@ def main():
         import json
         path = os.path.join(out, 'parity_multi_rank.json')
         rec = json.load(open(path)) if os.path.exists(path) else {}
-        rec['%s_J%d_J%d_%d_%s' % (PROBLEM, J_TIME, J_SPACE, size, 'threads' if threads else 'processes')] = {
+        rec['%s_J%d_J%d_%d_%s%s' % (PROBLEM, J_TIME, J_SPACE, size, 'threads' if threads else 'processes',
+                                     '' if PRECOND == 'multigrid' else '_' + PRECOND)] = {
             'iterations': int(its), 'history_equal_to_one_rank': True, 'iterate_equal_to_one_rank': True,
             'metric_operator_equal_to_one_rank': True, 'max_rel_dev_from_oracle_history': dev,
             'iterate_sample_rel_err_vs_oracle': float(err)}

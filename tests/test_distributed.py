@@ -106,7 +106,8 @@ def test_baseline_config_in_its_eight_rank_shape_equals_the_one_rank_solve(J_tim
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('problem,J_time,J_space,ranks,wavelets', [
-    ('lshape', 5, 8, 8, 'composite'), ('square', 5, 8, 3, 'original'), ('square', 5, 8, 5, 'interleaved')])
+    ('lshape', 5, 8, 8, 'composite'), ('square', 5, 8, 3, 'original'), ('square', 5, 8, 5, 'interleaved'),
+    ('square', 3, 6, 4, 'direct')])
 def test_other_shapes_of_the_solve_on_several_ranks_equal_the_one_rank_solve(problem, J_time, J_space, ranks, wavelets):
     """What the eight-rank tests above leave out: BASELINE config 4 (the L-shape, J_time = 5,
     J_space = 8: matrices without the square's repeated values, i.e. the plans with explicit
@@ -115,12 +116,16 @@ def test_other_shapes_of_the_solve_on_several_ranks_equal_the_one_rank_solve(pro
     MatKronIdentityMPI, mpi_kron.py:225-256) on three and five ranks -- each bit for bit
     the one-rank solve; the L-shape also within 1e-10 of the oracle's trajectory, and with
     the coefficients and the extreme Ritz values of the Lanczos recurrence on the
-    preconditioned system equal to the one-rank run's."""
+    preconditioned system equal to the one-rank run's.  Last case: config 1 with
+    precond='direct' (heateq_mpi.py:155-157; InvLinOp's factors on the device)
+    on four ranks, against tests/golden/o1_pcg_square_J3_J6_direct."""
     env = dict(os.environ, STK_TEST_THREAD_RANKS=str(ranks), STK_TEST_J_TIME=str(J_time),
                STK_TEST_J_SPACE=str(J_space), STK_TEST_PROBLEM=problem, STK_TEST_WAVELETS=wavelets,
                OMP_NUM_THREADS='1')
     if problem == 'lshape':  # ... and the Lanczos recurrence (lanczos.py:9-171) on the eight slabs
         env['STK_TEST_LANCZOS'] = '1'
+    if wavelets == 'direct':  # config 1 with the direct preconditioner: SuperLU's factors on every rank's device
+        env.update(STK_TEST_WAVELETS='composite', STK_TEST_PRECOND='direct')
     res = subprocess.run([sys.executable, os.path.join(HERE, 'mp_parity_worker.py')], env=env,
                          capture_output=True, text=True, timeout=1500)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
