@@ -350,7 +350,7 @@ def in_device_context(fn):
     return run
 
 
-from .host_malloc import host_heap_for_setup, keep_to_the_heap  # noqa: E402,F401
+from .host_malloc import give_back, host_heap_for_setup, keep_to_the_heap  # noqa: E402,F401
 
 
 def to_dev(array, dtype=None):
