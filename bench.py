@@ -147,7 +147,7 @@ def pcg_cpu_baseline(problem, J_time, J_space):
     M_x, A_x = space_matrices(mesh, scipy_path=True)
     o = HeatEquationOracle(dict(A_t=A_t, L_t=L_t, M_t=M_t, G_t=G_t, M_x=M_x, A_x=A_x,
                                 P_mats=prolongation_matrices(mesh), u0_t=u0_t,
-                                u0_x=space_load(mesh, data['u0'])), J_time)
+                                u0_x=space_load(mesh, data['u0'], numpy_path=True)), J_time)
     # threads actually used: batches of time slices are cut into at most N chunks
     cores = min(len(os.sched_getaffinity(0)), o.N)
     omg.THREADS = cores

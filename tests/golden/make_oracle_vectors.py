@@ -50,7 +50,7 @@ def build_oracle(problem, J_time, J_space, precond='multigrid'):
     M_x, A_x = space_matrices(mesh, scipy_path=True)  # the generator does not load libstk
     mats = dict(A_t=A_t, L_t=L_t, M_t=M_t, G_t=G_t, M_x=M_x, A_x=A_x,
                 P_mats=prolongation_matrices(mesh), u0_t=u0_t,
-                u0_x=space_load(mesh, data['u0']))
+                u0_x=space_load(mesh, data['u0'], numpy_path=True))  # the form the fixtures were made with
     return HeatEquationOracle(mats, J_time, precond=precond)
 
 

@@ -244,7 +244,7 @@ def test_serial_wiring_equals_parallel_wiring():
         M_x, A_x = space_matrices(mesh)
         mats = dict(A_t=A_t, L_t=L_t, M_t=M_t, G_t=G_t, M_x=M_x, A_x=A_x,
                     P_mats=prolongation_matrices(mesh), u0_t=u0_t,
-                    u0_x=space_load(mesh, data['u0']))
+                    u0_x=space_load(mesh, data['u0'], numpy_path=True))
         par = HeatEquationOracle(mats, J_time)
         ser = HeatSerialOracle(dict(mats, Minv_Y=Minv_Y, B1_t=B1_t, B2_t=B2_t),
                                J_time)
