@@ -23,7 +23,10 @@ for name in ('enabled', 'defrag', 'shmem_enabled'):
         print(name, err)
 torch.zeros(1, device='cuda')
 # what bench.py has done before its first set-up: a mesh, its matrices, kernels launched
-mesh = problem_helper('square', J_space=9, J_time=6)[0]
+J_space = int(sys.argv[1]) if len(sys.argv) > 1 else 9
+J_time = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+mesh = problem_helper('square', J_space=J_space, J_time=J_time)[0]
 space_matrices(mesh)
 
 
@@ -32,9 +35,9 @@ def usage():
     return r.ru_minflt, r.ru_majflt, r.ru_utime, r.ru_stime
 
 
-for rep in range(3):
+for rep in range(reps):
     before, t = usage(), time.time()
-    h = hm.HeatEquationMPI(J_space=9, J_time=6)
+    h = hm.HeatEquationMPI(J_space=J_space, J_time=J_time)
     torch.cuda.synchronize()
     dt, after = time.time() - t, usage()
     rss = int(open('/proc/self/statm').read().split()[1]) * 4096 / 1e9
