@@ -581,7 +581,11 @@ def main():
         if size > 1:
             dist.all_reduce(mb, op=dist.ReduceOp.SUM)
         model_total, model_tight = float(mb[0]), float(mb[1])
-        return {'arithmetic': arithmetic, 'setup_s': h.setup_time, 'host_allocator': HOST_ALLOCATOR, 'per_rank': phases,
+        return {'arithmetic': arithmetic, 'setup_s': h.setup_time, 'host_allocator': HOST_ALLOCATOR,
+                # when each stage of the set-up was done, and what ran in side threads (begin, end)
+                'setup_stages_s': {label: round(at, 3) for label, at in h.setup_timeline},
+                'setup_threads_s': {label: [round(b, 3), round(e, 3)] for label, b, e in h.setup_threads},
+                'per_rank': phases,
                 'iters_timed': n_it, 'iters_per_s': n_it / ds,
                 'ms_per_iter': ds / n_it * 1e3,
                 'r_dot_Pr': [float(v) for v in hist],
